@@ -1,0 +1,256 @@
+"""Generate golden vectors from the REFERENCE ITSELF (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports the read-only reference at /root/reference (pure-PyTorch CPU half; the
+tinycudann half is not importable offline) and stores inputs + expected outputs
+as small ``.npz`` files next to this script.  The reference never travels to
+the GPU box; these vectors do.  Only data is stored here (SURVEY.md section 8c,
+G1-G8, G11).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+import yaml  # noqa: E402
+from src.core import NeuralField  # noqa: E402
+from src.dataset import BlenderDataset  # noqa: E402
+from src.embeddings import FourierRepresentation  # noqa: E402
+from src.renderer import (DensityGrid, render_image, render_rays,  # noqa: E402
+                          sample_stratified, volume_render)
+from src.utils import compute_psnr  # noqa: E402
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"  {name}.npz  " + ", ".join(f"{k}{tuple(np.shape(v))}" for k, v in out.items()))
+
+
+def synth_rays(n, gen):
+    """Cameras on a radius-4.03 sphere looking roughly at the origin."""
+    o = torch.randn(n, 3, generator=gen)
+    o = o / o.norm(dim=-1, keepdim=True) * 4.0311
+    tgt = (torch.rand(n, 3, generator=gen) - 0.5) * 1.6
+    d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o, d
+
+
+def g1_fourier():
+    g = torch.Generator().manual_seed(101)
+    for dim in (1, 2, 3):
+        for L in (4, 6, 10, 15):
+            x = (torch.rand(257, dim, generator=g) - 0.5) * 3.0
+            y = FourierRepresentation(input_dim=dim, L=L)(x)
+            save(f"g1_fourier_d{dim}_L{L}", x=x, y=y)
+
+
+def g2_sampling():
+    g = torch.Generator().manual_seed(102)
+    for S in (64, 128):
+        z0 = sample_stratified(2.0, 6.0, S, 5, "cpu", False)
+        # the reference draws its jitter from the global RNG: seed, record, re-seed
+        torch.manual_seed(7)
+        u_ref = torch.rand(5, S)
+        torch.manual_seed(7)
+        z1 = sample_stratified(2.0, 6.0, S, 5, "cpu", True)
+        save(f"g2_sampling_S{S}", z_plain=z0, u=u_ref, z_jitter=z1)
+
+
+def g3_mask():
+    g = torch.Generator().manual_seed(103)
+    for res in (64, 128):
+        grid = DensityGrid(resolution=res, bound=1.5, threshold=0.01)
+        bits = torch.rand(res, res, res, generator=g) < 0.3
+        grid.binary_grid = bits
+        pts = (torch.rand(4096, 3, generator=g) - 0.5) * 3.4
+        edge = torch.tensor([[-1.505, 0.0, 0.0], [-1.5, -1.5, -1.5], [1.4999, 1.4999, 1.4999],
+                             [1.5, 0.0, 0.0], [0.0, -1.52, 0.0], [0.0, 0.0, 1.49999],
+                             [-1.5 - 1.0 / 64, 0.1, 0.1], [0.3, 0.3, -1.5234]])
+        pts = torch.cat([edge, pts], dim=0)
+        idx = ((pts + grid.offset) * grid.scale).long()
+        mask = grid.get_active_mask(pts)
+        save(f"g3_mask_res{res}", pts=pts, bits=bits, idx=idx, mask=mask)
+
+
+def g4_decoder():
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs", "part2.yaml.example")))
+    torch.manual_seed(0)
+    model = NeuralField(cfg)
+    g = torch.Generator().manual_seed(104)
+    pts = (torch.rand(512, 3, generator=g) - 0.5) * 3.0
+    dirs = torch.randn(512, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    with torch.no_grad():
+        rgb, sigma = model(pts, dirs)
+    sd = {k.replace("decoder.", ""): v for k, v in model.state_dict().items() if k.startswith("decoder.")}
+    save("g4_decoder", pts=pts, dirs=dirs, rgb=rgb, sigma=sigma, **{"w:" + k: v for k, v in sd.items()})
+    return model, sd
+
+
+def g5_composite():
+    g = torch.Generator().manual_seed(105)
+    for S in (64, 128):
+        R = 48
+        z = sample_stratified(2.0, 6.0, S, R, "cpu", True)
+        sig = torch.rand(R, S, generator=g) * 4.0
+        sig[torch.rand(R, S, generator=g) < 0.4] = 0.0
+        sig[torch.rand(R, S, generator=g) < 0.03] = 1e3
+        sig[:4] = 0.0                                      # empty rays
+        rgb = torch.rand(R, S, 3, generator=g)
+        _, d = synth_rays(R, g)
+        d = d * (0.5 + torch.rand(R, 1, generator=g))      # non-unit directions
+        for tag, bg in (("none", None), ("vec", torch.tensor([0.2, 0.5, 0.9])),
+                        ("ray", torch.rand(R, 3, generator=g))):
+            rgb_ = rgb.clone().requires_grad_(True)
+            sig_ = sig.clone().requires_grad_(True)
+            c, dep, acc = volume_render(rgb_, sig_, z, d, bg_color=bg)
+            gc = torch.rand(R, 3, generator=g)
+            gd = torch.rand(R, generator=g) * 0.1
+            ga = torch.rand(R, generator=g) * 0.1
+            ((c * gc).sum() + (dep * gd).sum() + (acc * ga).sum()).backward()
+            save(f"g5_composite_S{S}_{tag}", z=z, sigma=sig, rgb=rgb, rays_d=d,
+                 bg=(np.zeros(0, np.float32) if bg is None else bg),
+                 out_rgb=c, out_depth=dep, out_acc=acc, g_rgb_map=gc, g_depth=gd, g_acc=ga,
+                 d_sigma=sig_.grad, d_rgb=rgb_.grad)
+
+
+def g6_render(model):
+    g = torch.Generator().manual_seed(106)
+    o, d = synth_rays(96, g)
+    with torch.no_grad():
+        c0, dep0, acc0 = render_rays(model, o, d, 2.0, 6.0, 64, False)
+    torch.manual_seed(11)
+    u = torch.rand(96, 64)
+    torch.manual_seed(11)
+    target = torch.rand(96, 3, generator=g)
+    model.zero_grad()
+    c1, dep1, acc1 = render_rays(model, o, d, 2.0, 6.0, 64, True)
+    loss = torch.nn.functional.mse_loss(c1, target)
+    loss.backward()
+    grads = {"dw:" + k.replace("decoder.", ""): p.grad for k, p in model.named_parameters()}
+    save("g6_render", rays_o=o, rays_d=d, rgb_plain=c0, depth_plain=dep0, acc_plain=acc0,
+         u=u, target=target, rgb_jitter=c1, depth_jitter=dep1, acc_jitter=acc1,
+         loss=loss.detach(), **grads)
+    # occupancy-masked path with a synthetic bitfield
+    grid = DensityGrid(resolution=128, bound=1.5, threshold=0.01)
+    ax = torch.linspace(-1.5, 1.5, 128)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    grid.binary_grid = (gx ** 2 + gy ** 2 + gz ** 2) < 0.8 ** 2
+    with torch.no_grad():
+        c2, dep2, acc2 = render_rays(model, o, d, 2.0, 6.0, 64, False, density_grid=grid,
+                                     bg_color=torch.tensor([0.1, 0.2, 0.3]))
+        img = render_image(model, o[:64].reshape(8, 8, 3), d[:64].reshape(8, 8, 3), 2.0, 6.0, 64, 24, True)
+    save("g6_render_masked", rays_o=o, rays_d=d, radius=np.float32(0.8),
+         bg=np.array([0.1, 0.2, 0.3], np.float32), rgb=c2, depth=dep2, acc=acc2, image8x8=img)
+
+
+class _Blob(torch.nn.Module):
+    mode = "part2_nerf"
+
+    def forward(self, x, d):
+        r2 = ((x - torch.tensor([0.2, -0.1, 0.3])) ** 2).sum(-1, keepdim=True)
+        return torch.zeros(x.shape[0], 3), 5.0 * torch.exp(-r2 / 0.18)
+
+
+class _BlobDyn(_Blob):
+    mode = "part3"
+
+    def forward(self, x, d, t=None):
+        rgb, s = super().forward(x + t * 0.3, d)
+        return rgb, s, torch.zeros_like(x)
+
+
+def g7_grid():
+    for res in (32, 64):
+        grid = DensityGrid(resolution=res, bound=1.5, threshold=0.12)
+        ratio = grid.update(_Blob(), device="cpu")
+        save(f"g7_grid_static_res{res}", grid=grid.grid, binary=grid.binary_grid, ratio=np.float64(ratio))
+    grid = DensityGrid(resolution=32, bound=1.5, threshold=0.12)
+    r1 = grid.update(_BlobDyn(), device="cpu", time=torch.tensor([[0.0]]), decay=0.95)
+    r2 = grid.update(_BlobDyn(), device="cpu", time=torch.tensor([[1.0]]), decay=0.95)
+    save("g7_grid_dynamic_res32", grid=grid.grid, binary=grid.binary_grid,
+         ratios=np.array([r1, r2]), decay=np.float32(0.95))
+    sched = [(s, i, w, bool(grid.should_update(s, i, w))) for s in (0, 15, 16, 255, 256, 288, 300)
+             for i, w in ((16, 0), (32, 256))]
+    save("g7_should_update", table=np.array(sched, dtype=np.int64))
+
+
+def g8_rays():
+    ds = BlenderDataset.__new__(BlenderDataset)
+    ds.H, ds.W = 20, 24
+    ds.camera_angle_x = 0.6911112070083618
+    ds.focal = 0.5 * ds.W / np.tan(0.5 * ds.camera_angle_x)
+    ds.scene_scale = 0.8
+    ds._directions = ds._build_directions()
+    th, ph = 0.7, 0.4
+    rot = torch.tensor([[np.cos(th), -np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph)],
+                        [np.sin(th), np.cos(th) * np.cos(ph), -np.cos(th) * np.sin(ph)],
+                        [0.0, np.sin(ph), np.cos(ph)]], dtype=torch.float32)
+    c2w = torch.eye(4)
+    c2w[:3, :3] = rot
+    c2w[:3, 3] = torch.tensor([1.0, -2.0, 3.0])
+    ro, rd = ds.get_rays(c2w)
+    save("g8_rays", c2w=c2w, H=np.int64(ds.H), W=np.int64(ds.W), focal=np.float64(ds.focal),
+         scene_scale=np.float32(ds.scene_scale), rays_o=ro.contiguous(), rays_d=rd)
+
+
+def g10_optim():
+    torch.manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(11)), torch.nn.Parameter(torch.randn(3, 2))]
+    init = [p.detach().clone() for p in ps]
+    gs = [[torch.randn_like(p) for p in ps] for _ in range(5)]
+    out = {}
+    for name, make in (("adam", lambda: torch.optim.Adam(ps, lr=5e-4)),
+                       ("adamw", lambda: torch.optim.AdamW(ps, lr=1e-2, weight_decay=1e-5))):
+        for p, i in zip(ps, init):
+            p.data.copy_(i)
+        opt = make()
+        sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=2000, eta_min=1e-4) if name == "adamw" else None
+        lrs = []
+        for step in range(5):
+            for p, g in zip(ps, gs[step]):
+                p.grad = g.clone()
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            if sch is not None:
+                sch.step()
+        for k, p in enumerate(ps):
+            out[f"{name}_p{k}"] = p.detach().clone()
+        out[f"{name}_lrs"] = np.array(lrs)
+    for k in range(3):
+        out[f"init_p{k}"] = init[k]
+        out[f"grads_p{k}"] = torch.stack([gs[s][k] for s in range(5)])
+    save("g10_optim", **out)
+
+
+def g11_psnr():
+    mse = np.array([1e-4, 3.3e-3, 0.02, 0.25])
+    save("g11_psnr", mse=mse, psnr=np.array([compute_psnr(m) for m in mse]))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    print("writing golden vectors from", REF)
+    g1_fourier()
+    g2_sampling()
+    g3_mask()
+    model, _ = g4_decoder()
+    g5_composite()
+    g6_render(model)
+    g7_grid()
+    g8_rays()
+    g10_optim()
+    g11_psnr()
