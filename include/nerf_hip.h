@@ -1,0 +1,134 @@
+/* nerf_hip.h -- C ABI of the MI355X (gfx950) NeRF volumetric-rendering hot path.
+ *
+ * Drop-in boundary for CV-Project2025/Project-NeRF.  The reference has no FFI of
+ * its own: the path sits behind two Python operator surfaces (src/renderer.py,
+ * src/core.py + src/abstract.py) and, for the Instant variants, behind the
+ * third-party `tinycudann` bindings.  Every entry point below names the
+ * reference interface (file:line) it replaces.  INTEGRATION.md shows the ctypes
+ * stubs a maintainer of the reference would add.
+ *
+ * Conventions (all functions):
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`.
+ *   - pointers are borrowed for the duration of the call only; no hidden
+ *     allocation: the caller passes outputs and workspaces.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     asynchronous w.r.t. the host and safe to capture in a hipGraph.
+ *   - return 0 on success, a negative NERF_E* code otherwise; never throws.
+ *     nerf_last_error() returns a thread-local, NUL-terminated description.
+ *   - fp32 tensors are row-major and densely packed.
+ */
+#ifndef NERF_HIP_H
+#define NERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_OK 0
+#define NERF_EINVAL (-22)  /* bad argument (shape, alignment, NULL) */
+#define NERF_ELAUNCH (-5)  /* HIP launch / runtime failure          */
+#define NERF_ENOSYS (-38)  /* configuration not compiled in         */
+
+#define NERF_ABI_VERSION 1
+
+typedef void* nerf_stream_t;
+
+const char* nerf_last_error(void);
+int nerf_abi_version(void);
+
+/* ---- a1+a2: stratified depths and ray points ------------------------------
+ * replaces sample_stratified (src/renderer.py:186-201) and the pts/view_dirs
+ * block of render_rays (src/renderer.py:291-299).
+ *   rays_o, rays_d [R,3]; u [R,S] uniform jitter or NULL (no perturbation);
+ *   z_out [R,S]; pts_out / dirs_out [R*S,3] or NULL (skip materialisation).
+ * z is bit-exact w.r.t. the reference's CPU path for the same `u`. */
+int nerf_sample_rays(const float* rays_o, const float* rays_d, const float* u,
+                     int64_t n_rays, int n_samples, float near_plane, float far_plane,
+                     float* z_out, float* pts_out, float* dirs_out, nerf_stream_t stream);
+
+/* ---- a3: occupancy lookup ---------------------------------------------------
+ * replaces DensityGrid.get_active_mask (src/renderer.py:134-166).
+ *   pts [N,3]; binary_grid [res,res,res] bytes (torch.bool storage);
+ *   mask_out [N] bytes (0/1); idx_out [N,3] int64 voxel indices or NULL.
+ * Index arithmetic is bit-exact: fp32 add, fp32 multiply by (float)(res/(2*bound)),
+ * truncation toward zero. */
+int nerf_active_mask(const float* pts, int64_t n, const uint8_t* binary_grid, int resolution,
+                     float bound, uint8_t* mask_out, int64_t* idx_out, nerf_stream_t stream);
+
+/* ---- a5: Fourier features ---------------------------------------------------
+ * replaces FourierRepresentation.forward (src/embeddings.py:22-32).
+ *   x [N,dim] -> out [N, dim + 2*dim*n_freq] laid out [x | sin f0 | cos f0 | sin f1 | ...]. */
+int nerf_fourier_encode(const float* x, int64_t n, int dim, int n_freq, float* out,
+                        nerf_stream_t stream);
+
+/* ---- a9: alpha compositing (wave-level transmittance scan) -----------------
+ * replaces volume_render (src/renderer.py:204-237) and the second weights pass
+ * for mean_delta_x (src/renderer.py:367-380).
+ *   rgb [R,S,3], sigma [R,S], z [R,S], rays_d [R,3];
+ *   bg: NULL, [3] (bg_rows = 1) or [R,3] (bg_rows = R);
+ *   extra [R,S,3] or NULL -> extra_map [R,3] = sum_s w * extra  (delta_x mean);
+ *   out_rgb [R,3], out_depth [R], out_acc [R]; weights_out [R,S] or NULL. */
+int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z, const float* rays_d,
+                       const float* bg, int64_t bg_rows, const float* extra,
+                       int64_t n_rays, int n_samples,
+                       float* out_rgb, float* out_depth, float* out_acc,
+                       float* extra_map, float* weights_out, nerf_stream_t stream);
+
+/* backward of the above w.r.t. rgb, sigma (and extra when given).
+ *   g_rgb [R,3], g_depth [R] or NULL, g_acc [R] or NULL, g_extra [R,3] or NULL;
+ *   d_rgb [R,S,3], d_sigma [R,S], d_extra [R,S,3] or NULL. */
+int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z, const float* rays_d,
+                       const float* bg, int64_t bg_rows, const float* extra,
+                       const float* g_rgb, const float* g_depth, const float* g_acc,
+                       const float* g_extra, int64_t n_rays, int n_samples,
+                       float* d_rgb, float* d_sigma, float* d_extra, nerf_stream_t stream);
+
+/* ---- a6: fused Fourier-encode + 8x256 density/colour decoder (bf16 MFMA) ----
+ * replaces NeuralField.forward for mode part2_nerf (src/core.py:354-359) =
+ * FourierRepresentation x2 (src/embeddings.py:22-32) + NeRFDecoder.forward
+ * (src/decoders.py:68-87).  Architecture is fixed to the reference defaults the
+ * kernels are specialised for: L_embed 10, L_embed_dir 4, hidden 256, 8 layers,
+ * skip at 4, view_dim 128 (configs/part2.yaml.example); anything else returns
+ * NERF_ENOSYS.
+ *
+ * Weights live in ONE flat fp32 buffer in reference state_dict order
+ * (decoder.pts_layers.{0..7}.{weight,bias}, sigma_layer, feature_layer,
+ * view_layer, rgb_layer; nn.Linear [out,in] row-major): 595,844 floats.
+ * nerf_mlp_pack() converts it into the MFMA-fragment-ordered bf16 streams the
+ * kernels read (forward stream, transposed stream for dgrad, fp32 biases).    */
+#define NERF_MLP_PARAM_COUNT 595844
+
+/* sizes (bytes) of the packed buffers the caller must allocate */
+size_t nerf_mlp_packed_bytes(void);
+/* params_f32 [595844] -> packed (nerf_mlp_packed_bytes() bytes, 256-B aligned) */
+int nerf_mlp_pack(const float* params_f32, void* packed, nerf_stream_t stream);
+
+/* Inputs, one of:
+ *   ray mode   : rays_o/rays_d [R,3] + z [R,S]  (n = R*S samples, sample i -> ray i / S)
+ *   point mode : pts/dirs [n,3] (rays_o = pts, rays_d = dirs, z = NULL, n_samples = 0);
+ *                dirs are used as given (NeuralField.forward takes unit view dirs).
+ * Outputs rgb [n,3], sigma [n] fp32.
+ * stash: NULL for inference; for training a workspace of nerf_mlp_stash_bytes(n)
+ * that nerf_mlp_bwd consumes (bf16 activations per layer + relu bitmasks). */
+size_t nerf_mlp_stash_bytes(int64_t n);
+int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                 int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
+                 nerf_stream_t stream);
+
+/* ---- a14: optimiser ---------------------------------------------------------
+ * replaces torch.optim.Adam / AdamW .step() (run.py:307,338; run.py:546,629) for
+ * one flat fp32 parameter vector.  step counts from 1.  weight_decay is the
+ * decoupled (AdamW) form; 0 gives plain Adam.  grad_scale multiplies the
+ * gradient first (used for clip_grad_norm_, run.py:624-627, and 1/world). */
+int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   int64_t n, int step, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, const float* grad_scale_dev, nerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_HIP_H */

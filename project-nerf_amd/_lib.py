@@ -1,0 +1,70 @@
+"""ctypes binding of libnerf_hip.so (C ABI declared in include/nerf_hip.h).
+
+The library is loaded lazily and exactly once; a missing library is a hard error (there is
+no CPU or PyTorch fallback for the hot path).  ``torch`` must be imported first so that the
+HIP runtime the process already uses (torch's bundled libamdhip64.so.7) satisfies our
+DT_NEEDED entry instead of a second copy.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerf_hip.so")
+
+c_f32p = ctypes.c_void_p
+c_ptr = ctypes.c_void_p
+i64 = ctypes.c_int64
+i32 = ctypes.c_int
+f32 = ctypes.c_float
+size_t = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/nerf_hip.h one to one
+PROTOTYPES = {
+    "nerf_last_error": (ctypes.c_char_p, []),
+    "nerf_abi_version": (i32, []),
+    "nerf_sample_rays": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_active_mask": (i32, [c_ptr, i64, c_ptr, i32, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_fourier_encode": (i32, [c_ptr, i64, i32, i32, c_ptr, c_ptr]),
+    "nerf_composite_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, i64, i32,
+                                 c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_composite_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr,
+                                 c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_mlp_packed_bytes": (size_t, []),
+    "nerf_mlp_pack": (i32, [c_ptr, c_ptr, c_ptr]),
+    "nerf_mlp_stash_bytes": (size_t, [i64]),
+    "nerf_mlp_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_adam_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, c_ptr]),
+}
+
+_lib = None
+
+
+class NerfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Returns the loaded library; raises NerfHipError if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NerfHipError(
+            f"{LIB_PATH} not found: build it with `python project-nerf_amd/build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    import torch  # noqa: F401  (brings the process-wide HIP runtime in first)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nerf_abi_version() != 1:
+        raise NerfHipError(f"ABI version mismatch: library reports {lib.nerf_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().nerf_last_error().decode("utf-8", "replace")
+        raise NerfHipError(f"{what} failed ({code}): {msg}")

@@ -1,0 +1,95 @@
+// Shared helpers for the gfx950 kernels (error reporting, launch checks, wave ops).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/nerf_hip.h"
+
+namespace nerf {
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+int fail(int code, const char* fmt, ...);  // records nerf_last_error(), returns code
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NERF_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return NERF_OK;
+}
+
+inline hipStream_t as_stream(nerf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define NERF_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) return ::nerf::fail(NERF_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+// ---- individually rounded fp32 ops: never contracted into FMAs (hipcc defaults to
+// -ffp-contract=fast; the reference's eager ops round after every multiply and add) ----
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
+// ---- wave-level scans on DPP (row_shr within 16-lane rows, then readlane across rows) ----
+// v_mov_dpp row_shr:n  -> lane i receives lane i-n of its 16-lane row, `identity` when i-n < 0.
+template <int N>
+__device__ __forceinline__ float dpp_row_shr(float v, float identity) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity),
+                                                              __builtin_bit_cast(int, v),
+                                                              0x110 + N, 0xF, 0xF, false));
+}
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v, float identity) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity),
+                                                              __builtin_bit_cast(int, v),
+                                                              0x100 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_read(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// inclusive product over the 64 lanes, in lane order
+__device__ __forceinline__ float wave_inclusive_prod(float v) {
+  v *= dpp_row_shr<1>(v, 1.0f);
+  v *= dpp_row_shr<2>(v, 1.0f);
+  v *= dpp_row_shr<4>(v, 1.0f);
+  v *= dpp_row_shr<8>(v, 1.0f);
+  const int lane = __lane_id();
+  const float r0 = lane_read(v, 15), r1 = lane_read(v, 31), r2 = lane_read(v, 47);
+  const float p1 = r0, p2 = r0 * r1, p3 = p2 * r2;
+  const int row = lane >> 4;
+  const float carry = row == 0 ? 1.0f : (row == 1 ? p1 : (row == 2 ? p2 : p3));
+  return v * carry;
+}
+
+// inclusive suffix sum: lane i gets sum_{k>=i} v_k
+__device__ __forceinline__ float wave_inclusive_suffix_sum(float v) {
+  v += dpp_row_shl<1>(v, 0.0f);
+  v += dpp_row_shl<2>(v, 0.0f);
+  v += dpp_row_shl<4>(v, 0.0f);
+  v += dpp_row_shl<8>(v, 0.0f);
+  const int lane = __lane_id();
+  const float r1 = lane_read(v, 16), r2 = lane_read(v, 32), r3 = lane_read(v, 48);
+  const float s3 = r3, s2 = r3 + r2, s1 = s2 + r1;
+  const int row = lane >> 4;
+  const float carry = row == 3 ? 0.0f : (row == 2 ? s3 : (row == 1 ? s2 : s1));
+  return v + carry;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+}  // namespace nerf

@@ -1,0 +1,254 @@
+// Alpha compositing along rays: one wavefront per ray, samples
+// on lanes (K = ceil(S/64) consecutive samples per lane), transmittance as a
+// wave-level exclusive product scan on DPP, weighted sums as wave reductions.
+// HBM-bound: 20 B/sample in, 20 B/ray out (forward).
+#include "common.h"
+
+namespace nerf {
+
+constexpr int kMaxPerLane = 4;  // S <= 256
+
+struct RayCtx {
+  float e[kMaxPerLane];      // exp(-sigma*delta)
+  float alpha[kMaxPerLane];  // 1 - e
+  float q[kMaxPerLane];      // 1 - alpha + 1e-10
+  float T[kMaxPerLane];      // exclusive transmittance
+  float z[kMaxPerLane];
+  float delta[kMaxPerLane];
+};
+
+// loads sigma/z for the lane's K samples of ray r and builds alpha / transmittance
+template <int K>
+__device__ __forceinline__ void ray_setup(const float* __restrict__ sigma, const float* __restrict__ z,
+                                          const float* __restrict__ rays_d, int64_t r, int S, int lane,
+                                          RayCtx& c, float* sig_out) {
+  const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  const int s0 = lane * K;
+  float zn[K + 1];
+#pragma unroll
+  for (int k = 0; k <= K; ++k) {
+    const int s = s0 + k;
+    zn[k] = s < S ? z[r * S + s] : 0.0f;
+  }
+  float local = 1.0f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int s = s0 + k;
+    const bool valid = s < S;
+    const float sg = valid ? sigma[r * S + s] : 0.0f;
+    sig_out[k] = sg;
+    float dl = (s < S - 1) ? (zn[k + 1] - zn[k]) : 1e10f;   // src/renderer.py:213-214
+    dl = dl * dnorm;
+    const float e = valid ? __expf(-sg * dl) : 1.0f;
+    c.z[k] = zn[k];
+    c.delta[k] = dl;
+    c.e[k] = e;
+    c.alpha[k] = 1.0f - e;
+    c.q[k] = valid ? (1.0f - c.alpha[k] + 1e-10f) : 1.0f;
+    local *= c.q[k];
+  }
+  // exclusive scan over lanes of the per-lane products, then walk the lane's own samples
+  const float incl = wave_inclusive_prod(local);
+  float run = dpp_row_shr<1>(incl, 1.0f);
+  // row_shr does not cross 16-lane rows: patch lanes 16/32/48 from the previous row's last lane
+  {
+    const float p15 = lane_read(incl, 15), p31 = lane_read(incl, 31), p47 = lane_read(incl, 47);
+    if (lane == 16) run = p15;
+    if (lane == 32) run = p31;
+    if (lane == 48) run = p47;
+    if (lane == 0) run = 1.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    c.T[k] = run;
+    run *= c.q[k];
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+composite_fwd_kernel(const float* __restrict__ rgb, const float* __restrict__ sigma,
+                     const float* __restrict__ z, const float* __restrict__ rays_d,
+                     const float* __restrict__ bg, int64_t bg_rows, const float* __restrict__ extra,
+                     int64_t R, int S, float* __restrict__ out_rgb, float* __restrict__ out_depth,
+                     float* __restrict__ out_acc, float* __restrict__ extra_map,
+                     float* __restrict__ weights_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < R; r += nwave) {
+    RayCtx c;
+    float sg[K];
+    ray_setup<K>(sigma, z, rays_d, r, S, lane, c, sg);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, aw = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int s = lane * K + k;
+      if (s < S) {
+        const float w = c.alpha[k] * c.T[k];
+        const float* p = rgb + (r * S + s) * 3;
+        a0 += w * p[0];
+        a1 += w * p[1];
+        a2 += w * p[2];
+        ad += w * c.z[k];
+        aw += w;
+        if (extra != nullptr) {
+          const float* q = extra + (r * S + s) * 3;
+          x0 += w * q[0];
+          x1 += w * q[1];
+          x2 += w * q[2];
+        }
+        if (weights_out != nullptr) weights_out[r * S + s] = w;
+      }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    ad = wave_sum(ad); aw = wave_sum(aw);
+    if (extra != nullptr) { x0 = wave_sum(x0); x1 = wave_sum(x1); x2 = wave_sum(x2); }
+    if (lane == 0) {
+      if (bg != nullptr) {
+        const float* b = bg + (bg_rows > 1 ? r * 3 : 0);
+        const float rest = 1.0f - aw;
+        a0 += rest * b[0];
+        a1 += rest * b[1];
+        a2 += rest * b[2];
+      }
+      out_rgb[r * 3 + 0] = a0;
+      out_rgb[r * 3 + 1] = a1;
+      out_rgb[r * 3 + 2] = a2;
+      out_depth[r] = ad;
+      out_acc[r] = aw;
+      if (extra_map != nullptr) {
+        extra_map[r * 3 + 0] = x0;
+        extra_map[r * 3 + 1] = x1;
+        extra_map[r * 3 + 2] = x2;
+      }
+    }
+  }
+}
+
+// dL/dw_i = G_i = g_rgb.(c_i - bg) + g_depth z_i + g_acc + g_extra.x_i
+// dL/dalpha_i = G_i T_i - (sum_{k>i} G_k w_k) / q_i ;  dL/dsigma_i = dL/dalpha_i * delta_i * e_i
+template <int K>
+__global__ void __launch_bounds__(256)
+composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ sigma,
+                     const float* __restrict__ z, const float* __restrict__ rays_d,
+                     const float* __restrict__ bg, int64_t bg_rows, const float* __restrict__ extra,
+                     const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                     const float* __restrict__ g_acc, const float* __restrict__ g_extra, int64_t R, int S,
+                     float* __restrict__ d_rgb, float* __restrict__ d_sigma, float* __restrict__ d_extra) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < R; r += nwave) {
+    RayCtx c;
+    float sg[K];
+    ray_setup<K>(sigma, z, rays_d, r, S, lane, c, sg);
+    const float gr0 = g_rgb[r * 3 + 0], gr1 = g_rgb[r * 3 + 1], gr2 = g_rgb[r * 3 + 2];
+    const float gd = g_depth ? g_depth[r] : 0.0f;
+    float ga = g_acc ? g_acc[r] : 0.0f;
+    if (bg != nullptr) {
+      const float* b = bg + (bg_rows > 1 ? r * 3 : 0);
+      ga -= gr0 * b[0] + gr1 * b[1] + gr2 * b[2];
+    }
+    float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
+    if (g_extra != nullptr) { gx0 = g_extra[r * 3 + 0]; gx1 = g_extra[r * 3 + 1]; gx2 = g_extra[r * 3 + 2]; }
+    float G[K], w[K];
+    float local = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int s = lane * K + k;
+      G[k] = 0.0f;
+      w[k] = 0.0f;
+      if (s < S) {
+        const float* p = rgb + (r * S + s) * 3;
+        w[k] = c.alpha[k] * c.T[k];
+        float g = gr0 * p[0] + gr1 * p[1] + gr2 * p[2] + gd * c.z[k] + ga;
+        float* o = d_rgb + (r * S + s) * 3;
+        o[0] = w[k] * gr0;
+        o[1] = w[k] * gr1;
+        o[2] = w[k] * gr2;
+        if (extra != nullptr && g_extra != nullptr) {
+          const float* q = extra + (r * S + s) * 3;
+          g += gx0 * q[0] + gx1 * q[1] + gx2 * q[2];
+          if (d_extra != nullptr) {
+            float* oe = d_extra + (r * S + s) * 3;
+            oe[0] = w[k] * gx0;
+            oe[1] = w[k] * gx1;
+            oe[2] = w[k] * gx2;
+          }
+        }
+        G[k] = g;
+        local += g * w[k];
+      }
+    }
+    // suffix sum over later samples: lanes after this one, then within the lane
+    const float incl = wave_inclusive_suffix_sum(local);
+    float after = incl - local;  // sum over lanes > this lane
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+      const int s = lane * K + k;
+      if (s < S) {
+        const float dalpha = G[k] * c.T[k] - after / c.q[k];
+        d_sigma[r * S + s] = dalpha * c.delta[k] * c.e[k];
+      }
+      after += G[k] * w[k];
+    }
+  }
+}
+
+static int per_lane(int S) { return (S + 63) / 64; }
+
+}  // namespace nerf
+
+using namespace nerf;
+
+#define DISPATCH_K(K, KERNEL, ...)                                                        \
+  switch (K) {                                                                            \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+  }
+
+extern "C" int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z,
+                                  const float* rays_d, const float* bg, int64_t bg_rows,
+                                  const float* extra, int64_t n_rays, int n_samples, float* out_rgb,
+                                  float* out_depth, float* out_acc, float* extra_map,
+                                  float* weights_out, nerf_stream_t stream) {
+  NERF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 64 * kMaxPerLane,
+               "nerf_composite_fwd: n_rays=%lld n_samples=%d (max %d)", (long long)n_rays, n_samples,
+               64 * kMaxPerLane);
+  if (n_rays == 0) return NERF_OK;
+  NERF_REQUIRE(rgb && sigma && z && rays_d && out_rgb && out_depth && out_acc,
+               "nerf_composite_fwd: NULL pointer");
+  NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_fwd: bg_rows=%lld",
+               (long long)bg_rows);
+  NERF_REQUIRE((extra == nullptr) == (extra_map == nullptr), "nerf_composite_fwd: extra/extra_map mismatch");
+  int64_t blocks = (n_rays + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const dim3 grid((int)blocks);
+  DISPATCH_K(per_lane(n_samples), composite_fwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, extra, n_rays,
+             n_samples, out_rgb, out_depth, out_acc, extra_map, weights_out);
+  return check_launch("nerf_composite_fwd");
+}
+
+extern "C" int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z,
+                                  const float* rays_d, const float* bg, int64_t bg_rows,
+                                  const float* extra, const float* g_rgb, const float* g_depth,
+                                  const float* g_acc, const float* g_extra, int64_t n_rays,
+                                  int n_samples, float* d_rgb, float* d_sigma, float* d_extra,
+                                  nerf_stream_t stream) {
+  NERF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 64 * kMaxPerLane,
+               "nerf_composite_bwd: n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
+  if (n_rays == 0) return NERF_OK;
+  NERF_REQUIRE(rgb && sigma && z && rays_d && g_rgb && d_rgb && d_sigma, "nerf_composite_bwd: NULL pointer");
+  NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_bwd: bg_rows=%lld",
+               (long long)bg_rows);
+  int64_t blocks = (n_rays + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const dim3 grid((int)blocks);
+  DISPATCH_K(per_lane(n_samples), composite_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, extra, g_rgb,
+             g_depth, g_acc, g_extra, n_rays, n_samples, d_rgb, d_sigma, d_extra);
+  return check_launch("nerf_composite_bwd");
+}

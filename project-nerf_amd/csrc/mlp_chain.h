@@ -1,0 +1,183 @@
+// Building blocks of the decoder chain kernels (forward and dgrad): LDS weight ring fed by
+// global_load_lds_dwordx4, the per-m-tile MFMA loop, accumulator -> bf16 operand conversion,
+// and the in-register Fourier codes.  See mlp_plan.h for the data layout.
+#pragma once
+#include "common.h"
+#include "mlp_plan.h"
+
+namespace nerf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChainThreads = 512;                 // 8 waves, 2 per SIMD
+constexpr int kWaveSamples = 32;                   // one 32-column MFMA tile per wave
+constexpr int kTileSamples = 8 * kWaveSamples;     // 256 samples per workgroup pass
+constexpr int kRingSlotBytes = plan::kChunkFrags * 1024;
+constexpr int kRingBytes = 2 * kRingSlotBytes;     // 128 KiB
+// LDS map: [bias table | ring slot 0 | ring slot 1].  The bias table sits first so that its
+// reads are `small base + 16-bit immediate`; ring reads carry the slot in the address VGPR.
+constexpr int kBiasLdsBytes = ((plan::kBiasFloats * 4 + 1023) / 1024) * 1024;
+constexpr int kChainLds = kBiasLdsBytes + kRingBytes;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ---------------------------------------------------------------------------
+// Weight ring.  Chunk c of the stream lives in slot (phase & 1); `advance<C>()`
+// is called right before the first m-tile of chunk C is consumed:
+//   barrier  -> every wave's DMA for chunk C has landed (hipcc drains vmcnt before
+//               __syncthreads) and every wave is done reading the other slot
+//   issue    -> DMA chunk C+1 (or chunk 0 of the next pass) into the other slot
+// ---------------------------------------------------------------------------
+template <bool BWD>
+struct WeightRing {
+  static constexpr const plan::Chunks& chunks() { return BWD ? plan::kBwdChunks : plan::kFwdChunks; }
+  const char* stream;   // packed fragment stream in global memory
+  char* lds;            // ring base
+  int slot;             // slot holding the chunk being consumed
+  int wave, lane;
+
+  __device__ __forceinline__ void init(const char* s, char* l, int w, int ln) {
+    stream = s; lds = l; slot = 1; wave = w; lane = ln;
+  }
+  template <int C>
+  __device__ __forceinline__ void issue(int dst_slot) const {
+    constexpr int frag0 = chunks().chunk_frag0[C];
+    constexpr int count = chunks().chunk_count[C];
+    // wave-uniform source base (SGPR pair) + per-lane 32-bit offset; the empty asm keeps the
+    // compiler from hoisting ~160 loop-invariant 64-bit addresses out of the tile loop
+    const char* sbase = stream;
+    asm volatile("" : "+s"(sbase));
+    sbase += (size_t)(frag0 + wave) * 1024;
+    char* dst = lds + dst_slot * kRingSlotBytes + wave * 1024;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    // every wave issues ceil(count/8) pieces unconditionally: the tail pieces read the next
+    // chunk's fragments (the stream is padded by 8 KiB) into unused slot space
+#pragma unroll
+    for (int i = 0; i < (count + 7) / 8; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(sbase + i * 8192 + voff), (lptr_t)(dst + i * 8192), 16, 0, 0);
+  }
+  __device__ __forceinline__ void prologue() { issue<0>(0); }
+  // returns the LDS address lane `lane` reads its A fragments of the current chunk from
+  template <int C>
+  __device__ __forceinline__ const char* advance(bool more_passes) {
+    constexpr int n = chunks().n_chunks;
+    __syncthreads();
+    slot ^= 1;
+    if constexpr (C + 1 < n) issue<C + 1>(slot ^ 1);
+    else if (more_passes) issue<0>(slot ^ 1);
+    return lds + slot * kRingSlotBytes + lane * 16;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// One 32-row output tile: acc = bias; acc += A[m][ks] * B[ks] over all k-steps.
+// ---------------------------------------------------------------------------
+// A fragments are read kAhead k-steps ahead of the MFMA that consumes them; the
+// sched_group_barrier sequence pins that software pipeline (hipcc otherwise serialises
+// ds_read -> wait -> mfma on one fragment register when VGPRs are tight).
+constexpr int kAhead = 6;
+template <int KS>
+__device__ __forceinline__ f32x16 mtile_mfma(const char* a_base, int frag_off, const bf16x8 (&b)[KS], f32x16 acc) {
+  bf16x8 a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(a_base + (frag_off + ks) * 1024);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks], acc, 0, 0, 0);
+  constexpr int pre = KS < kAhead ? KS : kAhead;
+  __builtin_amdgcn_sched_group_barrier(0x100, pre, 0);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (ks + pre < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+  }
+  return acc;
+}
+
+// accumulator rows of register r in lane-half h: (r&3) + 8*(r>>2) + 4h  -> bias as 4 x float4
+__device__ __forceinline__ f32x16 bias_tile(const float* bias_lds, int row0, int half) {
+  f32x16 acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_lds + row0 + 8 * g + 4 * half);
+    acc[4 * g + 0] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
+  }
+  return acc;
+}
+
+// fp32 accumulator tile -> the two bf16 B fragments (k-steps 2m, 2m+1) of the next step
+__device__ __forceinline__ void acc_to_operand(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    lo[j] = (__bf16)acc[j];
+    hi[j] = (__bf16)acc[8 + j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fourier code of one coordinate triple, element f of
+// [x(3) | sin(2^0 pi x)(3) | cos(2^0 pi x)(3) | sin(2^1 pi x)(3) | ...]  (src/embeddings.py:28-32).
+// The reference evaluates sin(fl(fl(x*2^b)*pi_f32)); we reproduce that argument exactly:
+// y = x*2^b is exact, r0 = fract(y/2) is exact, and the rounding error of the reference's
+// fp32 product (recovered with one fma) is added back as a correction in revolutions.
+// v_sin_f32 takes revolutions; cos = sin(r + 1/4).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sincos_rev(float xa, float scale, float phase) {
+  constexpr float kPiF = 3.14159274101257324f;            // fp32(pi)
+  constexpr float kPiErr = 8.74227766e-8f;                // fp32(pi) - pi
+  constexpr float kInv2Pi = 0.15915494309189535f;
+  const float y = xa * scale;                              // exact (power-of-two scale)
+  const float t = y * kPiF;                                // the reference's rounded argument
+  const float resid = __builtin_fmaf(y, kPiF, -t);         // y*pi_f - t, exact
+  const float corr = (y * kPiErr - resid) * kInv2Pi;       // (t - y*pi) / 2pi
+  const float r = __builtin_amdgcn_fractf(0.5f * y) + (corr + phase);
+  return __builtin_amdgcn_sinf(r);
+}
+
+struct FeatSpec { int axis; float scale; float phase; int raw; };   // raw: 0 trig, 1 coordinate, 2 const 1, 3 zero
+template <int VALID>
+constexpr FeatSpec feat_spec(int f) {
+  if (f < 3) return {f, 1.0f, 0.0f, 1};
+  if (f == VALID) return {0, 1.0f, 0.0f, 2};              // pad column = 1 (bias column of wgrad)
+  if (f > VALID) return {0, 1.0f, 0.0f, 3};
+  const int c = f - 3, band = c / 6, rem = c % 6;
+  return {rem % 3, (float)(1 << band), rem >= 3 ? 0.25f : 0.0f, 0};
+}
+
+template <int VALID>
+__device__ __forceinline__ float feat_eval(const FeatSpec s, float x0, float x1, float x2) {
+  const float xa = s.axis == 0 ? x0 : (s.axis == 1 ? x1 : x2);
+  if (s.raw == 1) return xa;
+  if (s.raw == 2) return 1.0f;
+  if (s.raw == 3) return 0.0f;
+  return sincos_rev(xa, s.scale, s.phase);
+}
+
+// B fragments (natural k order) of a Fourier code with KS k-steps; feature f = 16*ks + 8*half + j
+template <int KS, int VALID>
+__device__ __forceinline__ void fourier_operand(float x0, float x1, float x2, int half, bf16x8 (&out)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      constexpr int dummy = 0; (void)dummy;
+      const FeatSpec s0 = feat_spec<VALID>(16 * ks + j), s1 = feat_spec<VALID>(16 * ks + 8 + j);
+      float v;
+      if (s0.raw == 0 && s1.raw == 0) {
+        // both halves evaluate a trig feature: select the parameters, evaluate once
+        const float xa0 = s0.axis == 0 ? x0 : (s0.axis == 1 ? x1 : x2);
+        const float xa1 = s1.axis == 0 ? x0 : (s1.axis == 1 ? x1 : x2);
+        v = sincos_rev(half ? xa1 : xa0, half ? s1.scale : s0.scale, half ? s1.phase : s0.phase);
+      } else {
+        const float v0 = feat_eval<VALID>(s0, x0, x1, x2), v1 = feat_eval<VALID>(s1, x0, x1, x2);
+        v = half ? v1 : v0;
+      }
+      out[ks][j] = (__bf16)v;
+    }
+  }
+}
+
+}  // namespace nerf

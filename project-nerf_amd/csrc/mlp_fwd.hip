@@ -1,0 +1,296 @@
+// Fused Fourier-encode + 8x256 density/colour decoder, forward.
+//
+// One 512-thread workgroup per CU walks 256-sample tiles; each wave owns 32 samples and
+// carries their activations through all 11 GEMM steps in registers (the fp32 accumulator
+// tile of one step, cast to bf16, IS the MFMA B operand of the next).  Weights stream
+// through a 2 x 64 KiB LDS ring (global_load_lds_dwordx4), biases sit in LDS as the
+// accumulators' initial values.  MFMA-bound: 1,186,816 FLOP per sample (+ padding).
+// TRAIN additionally stashes bf16 activations (row-major [n, width], the wgrad kernel's B
+// operands) and ReLU bitmasks for the backward chain.
+#include <type_traits>
+#include <utility>
+#include "mlp_chain.h"
+
+namespace nerf {
+using namespace plan;
+
+struct FwdArgs {
+  const char* packed;
+  const float* rays_o;
+  const float* rays_d;
+  const float* z;
+  int64_t n;
+  int n_samples;        // 0: point mode (rays_o = pts[n,3], rays_d = dirs[n,3] used as given)
+  float* rgb;
+  float* sigma;
+  // training stash
+  __bf16* st_xenc;      // [n,64]
+  __bf16* st_h;         // 8 x [n,256], layer l at st_h + l*n*256
+  __bf16* st_feat;      // [n,256]
+  __bf16* st_hv;        // [n,128]
+  __bf16* st_denc;      // [n,32]
+  uint4* st_mask;       // [tiles][9][512] relu bits: word (m>>1), bits 16*(m&1) + r
+};
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// Runs one GEMM step; epi(mc, acc) consumes each finished 32-row tile.
+template <bool BWD, int KIND, int KS, class Epi>
+__device__ __forceinline__ void run_step(WeightRing<BWD>& ring, const char*& a_base, bool more_passes,
+                                         const bf16x8 (&b)[KS], const float* bias_lds, int half, Epi&& epi) {
+  constexpr Step st = step_of(KIND);
+  static_assert(KS == st.ks_acc + st.ks_nat, "operand k-steps");
+  static_for<st.mt>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int g = group_of(KIND, m);
+    constexpr const Chunks& ch = WeightRing<BWD>::chunks();
+    if constexpr (ch.group_first[g]) a_base = ring.template advance<ch.group_chunk[g]>(more_passes);
+    f32x16 acc;
+    if constexpr (BWD) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    } else {
+      acc = bias_tile(bias_lds, bias_off(KIND) + 32 * m, half);
+    }
+    acc = mtile_mfma<KS>(a_base, ch.group_off[g], b, acc);
+    epi(mc, acc);
+  });
+}
+
+template <bool TRAIN>
+__global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+
+  const float* bias_g = reinterpret_cast<const float*>(a.packed + kPackBiasOff);
+  for (int i = tid; i < kBiasFloats; i += kChainThreads) bias_lds[i] = bias_g[i];
+
+  WeightRing<false> ring;
+  ring.init(a.packed + kPackFwdOff, smem + kBiasLdsBytes, wave, lane);
+  ring.prologue();
+  const char* a_base = nullptr;
+
+  const int64_t n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const bool more = tile + gridDim.x < n_tiles;
+    const int64_t n = tile * kTileSamples + wave * kWaveSamples + col;
+    const bool live = n < a.n;
+    const int64_t nc = live ? n : a.n - 1;
+
+    // ---- a2: sample position and unit view direction ----
+    float px, py, pz, vx, vy, vz;
+    if (a.n_samples > 0) {
+      const int64_t ray = (uint32_t)nc / (uint32_t)a.n_samples;
+      const float zz = a.z[nc];
+      const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
+      const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+      px = add_rn(ox, mul_rn(dx, zz));
+      py = add_rn(oy, mul_rn(dy, zz));
+      pz = add_rn(oz, mul_rn(dz, zz));
+      const float nrm = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
+      vx = (dx / nrm); vy = (dy / nrm); vz = (dz / nrm);
+    } else {
+      px = a.rays_o[nc * 3 + 0]; py = a.rays_o[nc * 3 + 1]; pz = a.rays_o[nc * 3 + 2];
+      vx = a.rays_d[nc * 3 + 0]; vy = a.rays_d[nc * 3 + 1]; vz = a.rays_d[nc * 3 + 2];
+    }
+
+    // ---- a5: Fourier codes straight into MFMA B fragments ----
+    bf16x8 xenc[4], denc[2];
+    fourier_operand<4, kPosDim>(px, py, pz, half, xenc);
+    fourier_operand<2, kDirDim>(vx, vy, vz, half, denc);
+    if constexpr (TRAIN) {
+      if (live) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          *reinterpret_cast<bf16x8*>(a.st_xenc + n * 64 + 16 * ks + 8 * half) = xenc[ks];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          *reinterpret_cast<bf16x8*>(a.st_denc + n * 32 + 16 * ks + 8 * half) = denc[ks];
+      }
+    }
+
+    uint32_t mask_words[4];
+    // hidden-layer epilogue: relu, bf16 operand for the next step, optional stash + mask
+    auto hidden = [&](bf16x8* out, __bf16* stash, int width, bool relu) {
+      return [=, &mask_words](auto mc, f32x16 acc) {
+        constexpr int m = decltype(mc)::value;
+        if (relu) {
+          uint32_t bits = 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
+            acc[r] = fmaxf(acc[r], 0.0f);
+          }
+          if constexpr (TRAIN) {
+            if constexpr ((m & 1) == 0) mask_words[m >> 1] = bits;
+            else mask_words[m >> 1] |= bits << 16;
+          }
+        }
+        acc_to_operand(acc, out[2 * m], out[2 * m + 1]);
+        if constexpr (TRAIN) {
+          if (live) {
+            __bf16* row = stash + n * width + 32 * m + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              bf16x4 v;
+              const bf16x8& src = out[2 * m + (g >> 1)];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = src[(g & 1) * 4 + e];
+              *reinterpret_cast<bf16x4*>(row + 8 * g) = v;
+            }
+          }
+        }
+      };
+    };
+    auto flush_mask = [&](int layer) {
+      if constexpr (TRAIN) {
+        a.st_mask[(tile * 9 + layer) * kChainThreads + tid] =
+            make_uint4(mask_words[0], mask_words[1], mask_words[2], mask_words[3]);
+      }
+    };
+
+    bf16x8 hA[16], hB[16];
+    // ---- a6: pts_layers.0 .. 7 (src/decoders.py:70-74) ----
+    run_step<false, F_PTS0, 4>(ring, a_base, more, xenc, bias_lds, half, hidden(hA, a.st_h + 0 * a.n * 256, 256, true));
+    flush_mask(0);
+    run_step<false, F_PTS1, 16>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 1 * a.n * 256, 256, true));
+    flush_mask(1);
+    run_step<false, F_PTS2, 16>(ring, a_base, more, hB, bias_lds, half, hidden(hA, a.st_h + 2 * a.n * 256, 256, true));
+    flush_mask(2);
+    run_step<false, F_PTS3, 16>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 3 * a.n * 256, 256, true));
+    flush_mask(3);
+    {
+      bf16x8 cat[20];   // skip connection: [h3 | xenc], hidden first (src/decoders.py:73)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cat[i] = hB[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cat[16 + i] = xenc[i];
+      run_step<false, F_PTS4, 20>(ring, a_base, more, cat, bias_lds, half, hidden(hA, a.st_h + 4 * a.n * 256, 256, true));
+      flush_mask(4);
+    }
+    run_step<false, F_PTS5, 16>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 5 * a.n * 256, 256, true));
+    flush_mask(5);
+    run_step<false, F_PTS6, 16>(ring, a_base, more, hB, bias_lds, half, hidden(hA, a.st_h + 6 * a.n * 256, 256, true));
+    flush_mask(6);
+    run_step<false, F_PTS7, 16>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 7 * a.n * 256, 256, true));
+    flush_mask(7);
+
+    // ---- feature_layer (linear) + sigma_layer (relu) (src/decoders.py:77-80) ----
+    {
+      auto feat_epi = hidden(hA, a.st_feat, 256, false);
+      run_step<false, F_HEAD, 16>(ring, a_base, more, hB, bias_lds, half, [&](auto mc, f32x16 acc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m < 8) feat_epi(mc, acc);
+        else if (live && half == 0) a.sigma[n] = fmaxf(acc[0], 0.0f);
+      });
+    }
+    // ---- view_layer on [feat | denc] (relu), rgb_layer (sigmoid) (src/decoders.py:83-85) ----
+    {
+      bf16x8 cat[18];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cat[i] = hA[i];
+      cat[16] = denc[0];
+      cat[17] = denc[1];
+      mask_words[0] = mask_words[1] = mask_words[2] = mask_words[3] = 0;
+      run_step<false, F_VIEW, 18>(ring, a_base, more, cat, bias_lds, half, hidden(hB, a.st_hv, 128, true));
+      flush_mask(8);
+    }
+    {
+      bf16x8 hv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hv[i] = hB[i];
+      run_step<false, F_RGB, 8>(ring, a_base, more, hv, bias_lds, half, [&](auto, f32x16 acc) {
+        if (live && half == 0) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a.rgb[n * 3 + c] = 1.0f / (1.0f + __expf(-acc[c]));
+        }
+      });
+    }
+  }
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+// stash layout (bytes), all offsets 256-B aligned for n % 128 == 0; computed for any n
+namespace {
+struct StashLayout {
+  size_t xenc, h, feat, hv, denc, mask, total;
+};
+StashLayout stash_layout(int64_t n) {
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  StashLayout s{};
+  size_t o = 0;
+  s.xenc = o; o = up(o + (size_t)n * 64 * 2);
+  s.h = o;    o = up(o + (size_t)n * 256 * 2 * 8);
+  s.feat = o; o = up(o + (size_t)n * 256 * 2);
+  s.hv = o;   o = up(o + (size_t)n * 128 * 2);
+  s.denc = o; o = up(o + (size_t)n * 32 * 2);
+  const size_t tiles = (n + kTileSamples - 1) / kTileSamples;
+  s.mask = o; o = up(o + tiles * 9 * kChainThreads * 16);
+  s.total = o;
+  return s;
+}
+}  // namespace
+
+extern "C" size_t nerf_mlp_stash_bytes(int64_t n) { return n > 0 ? stash_layout(n).total : 0; }
+
+extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                            int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
+                            nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "nerf_mlp_fwd: n=%lld out of range", (long long)n);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(packed && rays_o && rays_d && rgb && sigma, "nerf_mlp_fwd: NULL pointer");
+  NERF_REQUIRE((n_samples == 0) == (z == nullptr), "nerf_mlp_fwd: z must be given exactly in ray mode");
+  NERF_REQUIRE(n_samples >= 0 && (n_samples == 0 || n % n_samples == 0),
+               "nerf_mlp_fwd: n=%lld is not a multiple of n_samples=%d", (long long)n, n_samples);
+  NERF_REQUIRE(((uintptr_t)packed & 255) == 0 && ((uintptr_t)stash & 255) == 0,
+               "nerf_mlp_fwd: packed/stash must be 256-byte aligned");
+  FwdArgs a{};
+  a.packed = static_cast<const char*>(packed);
+  a.rays_o = rays_o; a.rays_d = rays_d; a.z = z;
+  a.n = n; a.n_samples = n_samples; a.rgb = rgb; a.sigma = sigma;
+  if (stash != nullptr) {
+    const StashLayout s = stash_layout(n);
+    char* b = static_cast<char*>(stash);
+    a.st_xenc = reinterpret_cast<__bf16*>(b + s.xenc);
+    a.st_h = reinterpret_cast<__bf16*>(b + s.h);
+    a.st_feat = reinterpret_cast<__bf16*>(b + s.feat);
+    a.st_hv = reinterpret_cast<__bf16*>(b + s.hv);
+    a.st_denc = reinterpret_cast<__bf16*>(b + s.denc);
+    a.st_mask = reinterpret_cast<uint4*>(b + s.mask);
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_mlp_fwd: cannot query device");
+    n_cu = prop.multiProcessorCount;
+  }
+  const int64_t tiles = (n + kTileSamples - 1) / kTileSamples;
+  const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_mlp_fwd: cannot raise dynamic LDS limit to %d", kChainLds);
+    attr_set = true;
+  }
+  if (stash != nullptr)
+    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  else
+    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  return check_launch("nerf_mlp_fwd");
+}

@@ -1,0 +1,123 @@
+// Stratified depths, ray points and occupancy lookup.
+// Built with -ffp-contract=off: the reference's eager ops round after every
+// multiply and add, and sample / voxel indices must match it bit for bit.
+#include "common.h"
+
+namespace nerf {
+
+// torch.linspace(0,1,S) on CPU: step = 1/(S-1) in fp32; the lower half walks up
+// from 0, the upper half walks down from 1, each with ONE rounding.
+__device__ __forceinline__ float linspace01(int i, int n, float step) {
+  if (i < n / 2) return mul_rn(step, (float)i);
+  return __builtin_fmaf(-step, (float)(n - 1 - i), 1.0f);
+}
+
+__device__ __forceinline__ float plain_depth(int i, int n, float step, float near_p, float far_p) {
+  const float t = linspace01(i, n, step);
+  // near*(1-t) + far*t, three roundings (src/renderer.py:190)
+  return add_rn(mul_rn(near_p, sub_rn(1.0f, t)), mul_rn(far_p, t));
+}
+
+__device__ __forceinline__ float sample_depth(int i, int n, float step, float near_p, float far_p,
+                                              const float* u_row) {
+  const float zi = plain_depth(i, n, step, near_p, far_p);
+  if (u_row == nullptr) return zi;
+  // mids / upper / lower (src/renderer.py:195-199)
+  float lo = zi, hi = zi;
+  if (i > 0) lo = mul_rn(0.5f, add_rn(zi, plain_depth(i - 1, n, step, near_p, far_p)));
+  if (i < n - 1) hi = mul_rn(0.5f, add_rn(plain_depth(i + 1, n, step, near_p, far_p), zi));
+  return add_rn(lo, mul_rn(sub_rn(hi, lo), u_row[i]));
+}
+
+__global__ void __launch_bounds__(256)
+sample_rays_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                   const float* __restrict__ u, int64_t n_rays, int n_samples, float near_p,
+                   float far_p, float step, float* __restrict__ z_out, float* __restrict__ pts_out,
+                   float* __restrict__ dirs_out) {
+  const int64_t total = n_rays * (int64_t)n_samples;
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = g / n_samples;
+    const int s = (int)(g - r * n_samples);
+    const float z = sample_depth(s, n_samples, step, near_p, far_p, u ? u + r * n_samples : nullptr);
+    z_out[g] = z;
+    if (pts_out != nullptr || dirs_out != nullptr) {
+      const float ox = rays_o[r * 3 + 0], oy = rays_o[r * 3 + 1], oz = rays_o[r * 3 + 2];
+      const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+      if (pts_out != nullptr) {
+        pts_out[g * 3 + 0] = add_rn(ox, mul_rn(dx, z));
+        pts_out[g * 3 + 1] = add_rn(oy, mul_rn(dy, z));
+        pts_out[g * 3 + 2] = add_rn(oz, mul_rn(dz, z));
+      }
+      if (dirs_out != nullptr) {
+        const float nrm =
+            sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
+        dirs_out[g * 3 + 0] = (dx / nrm);
+        dirs_out[g * 3 + 1] = (dy / nrm);
+        dirs_out[g * 3 + 2] = (dz / nrm);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+active_mask_kernel(const float* __restrict__ pts, int64_t n, const uint8_t* __restrict__ grid, int res,
+                   float bound, float scale, uint8_t* __restrict__ mask_out,
+                   int64_t* __restrict__ idx_out) {
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v[3];
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      // (pts + bound) * scale, then .long(): truncation toward zero (src/renderer.py:145)
+      const float f = mul_rn(add_rn(pts[g * 3 + a], bound), scale);
+      v[a] = (int64_t)f;
+      inside = inside && v[a] >= 0 && v[a] < res;
+      if (idx_out != nullptr) idx_out[g * 3 + a] = v[a];
+    }
+    uint8_t m = 0;
+    if (inside) m = grid[(v[0] * res + v[1]) * res + v[2]] != 0;
+    mask_out[g] = m;
+  }
+}
+
+static inline int grid_for(int64_t work, int block) {
+  int64_t b = (work + block - 1) / block;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" int nerf_sample_rays(const float* rays_o, const float* rays_d, const float* u,
+                                int64_t n_rays, int n_samples, float near_plane, float far_plane,
+                                float* z_out, float* pts_out, float* dirs_out, nerf_stream_t stream) {
+  NERF_REQUIRE(n_rays >= 0 && n_samples >= 2, "nerf_sample_rays: n_rays=%lld n_samples=%d",
+               (long long)n_rays, n_samples);
+  NERF_REQUIRE(z_out != nullptr, "nerf_sample_rays: z_out is NULL");
+  NERF_REQUIRE((pts_out == nullptr && dirs_out == nullptr) || (rays_o && rays_d),
+               "nerf_sample_rays: rays_o/rays_d required when pts/dirs are requested");
+  if (n_rays == 0) return NERF_OK;
+  const float step = 1.0f / (float)(n_samples - 1);
+  hipLaunchKernelGGL(sample_rays_kernel, dim3(grid_for(n_rays * n_samples, 256)), dim3(256), 0,
+                     as_stream(stream), rays_o, rays_d, u, n_rays, n_samples, near_plane, far_plane,
+                     step, z_out, pts_out, dirs_out);
+  return check_launch("nerf_sample_rays");
+}
+
+extern "C" int nerf_active_mask(const float* pts, int64_t n, const uint8_t* binary_grid,
+                                int resolution, float bound, uint8_t* mask_out, int64_t* idx_out,
+                                nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && resolution > 0 && bound > 0.0f, "nerf_active_mask: bad sizes");
+  NERF_REQUIRE(n == 0 || (pts && binary_grid && mask_out), "nerf_active_mask: NULL pointer");
+  if (n == 0) return NERF_OK;
+  // the Python double res/(2*bound) is demoted to fp32 before the multiply
+  const float scale = (float)((double)resolution / (2.0 * (double)bound));
+  hipLaunchKernelGGL(active_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), pts,
+                     n, binary_grid, resolution, bound, scale, mask_out, idx_out);
+  return check_launch("nerf_active_mask");
+}

@@ -1,0 +1,208 @@
+"""Tensor-level entry points of the HIP hot path.
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; all arithmetic
+happens in libnerf_hip.so through the C ABI (include/nerf_hip.h).  Every function insists on
+contiguous fp32 tensors that live on a HIP device and raises otherwise -- there is no CPU
+or eager fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Tensor, name: str, dtype=torch.float32) -> Tensor:
+    if not isinstance(t, Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if t.device.type != "cuda":
+        raise _lib.NerfHipError(f"{name} is on {t.device}; the hot path only runs on a HIP device (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------- a1-a3
+def sample_rays(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_samples: int,
+                u: Optional[Tensor] = None, want_points: bool = False):
+    """z[R,S] (+ pts[R*S,3], dirs[R*S,3]); ``u`` [R,S] is the jitter draw or None."""
+    lib = _lib.load()
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    R = rays_o.shape[0]
+    if u is not None:
+        u = _dev(u, "u")
+        if tuple(u.shape) != (R, n_samples):
+            raise ValueError(f"u must be [{R},{n_samples}]")
+    z = torch.empty(R, n_samples, device=rays_o.device, dtype=torch.float32)
+    pts = dirs = None
+    if want_points:
+        pts = torch.empty(R * n_samples, 3, device=rays_o.device, dtype=torch.float32)
+        dirs = torch.empty_like(pts)
+    _lib.check(lib.nerf_sample_rays(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far,
+                                    _p(z), _p(pts), _p(dirs), _stream()), "nerf_sample_rays")
+    return (z, pts, dirs) if want_points else z
+
+
+def active_mask(pts: Tensor, binary_grid: Tensor, bound: float, want_index: bool = False):
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    grid = _dev(binary_grid, "binary_grid", torch.bool)
+    res = grid.shape[0]
+    n = pts.shape[0]
+    mask = torch.empty(n, device=pts.device, dtype=torch.bool)
+    idx = torch.empty(n, 3, device=pts.device, dtype=torch.int64) if want_index else None
+    _lib.check(lib.nerf_active_mask(_p(pts), n, _p(grid), res, float(bound), _p(mask), _p(idx), _stream()),
+               "nerf_active_mask")
+    return (mask, idx) if want_index else mask
+
+
+# --------------------------------------------------------------------------- a5
+def fourier_encode(x: Tensor, n_freq: int) -> Tensor:
+    lib = _lib.load()
+    x = _dev(x, "x")
+    n, dim = x.shape
+    out = torch.empty(n, dim + 2 * dim * n_freq, device=x.device, dtype=torch.float32)
+    _lib.check(lib.nerf_fourier_encode(_p(x), n, dim, n_freq, _p(out), _stream()), "nerf_fourier_encode")
+    return out
+
+
+# --------------------------------------------------------------------------- a9
+def composite_fwd(rgb: Tensor, sigma: Tensor, z: Tensor, rays_d: Tensor, bg: Optional[Tensor] = None,
+                  extra: Optional[Tensor] = None, want_weights: bool = False):
+    lib = _lib.load()
+    rgb, sigma, z, rays_d = _dev(rgb, "rgb"), _dev(sigma, "sigma"), _dev(z, "z"), _dev(rays_d, "rays_d")
+    R, S = z.shape
+    bg_rows = 0
+    if bg is not None:
+        bg = _dev(bg, "bg")
+        bg_rows = 1 if bg.dim() == 1 else bg.shape[0]
+    out_rgb = torch.empty(R, 3, device=z.device, dtype=torch.float32)
+    depth = torch.empty(R, device=z.device, dtype=torch.float32)
+    acc = torch.empty(R, device=z.device, dtype=torch.float32)
+    extra_map = None
+    if extra is not None:
+        extra = _dev(extra, "extra")
+        extra_map = torch.empty(R, 3, device=z.device, dtype=torch.float32)
+    w = torch.empty(R, S, device=z.device, dtype=torch.float32) if want_weights else None
+    _lib.check(lib.nerf_composite_fwd(_p(rgb), _p(sigma), _p(z), _p(rays_d), _p(bg), bg_rows, _p(extra),
+                                      R, S, _p(out_rgb), _p(depth), _p(acc), _p(extra_map), _p(w), _stream()),
+               "nerf_composite_fwd")
+    return out_rgb, depth, acc, extra_map, w
+
+
+def composite_bwd(rgb, sigma, z, rays_d, bg, extra, g_rgb, g_depth, g_acc, g_extra):
+    lib = _lib.load()
+    rgb, sigma, z, rays_d = _dev(rgb, "rgb"), _dev(sigma, "sigma"), _dev(z, "z"), _dev(rays_d, "rays_d")
+    R, S = z.shape
+    bg_rows = 0
+    if bg is not None:
+        bg = _dev(bg, "bg")
+        bg_rows = 1 if bg.dim() == 1 else bg.shape[0]
+    g_rgb = _dev(g_rgb, "g_rgb")
+    g_depth = None if g_depth is None else _dev(g_depth, "g_depth")
+    g_acc = None if g_acc is None else _dev(g_acc, "g_acc")
+    d_rgb = torch.empty(R, S, 3, device=z.device, dtype=torch.float32)
+    d_sigma = torch.empty(R, S, device=z.device, dtype=torch.float32)
+    d_extra = None
+    if extra is not None and g_extra is not None:
+        extra, g_extra = _dev(extra, "extra"), _dev(g_extra, "g_extra")
+        d_extra = torch.empty(R, S, 3, device=z.device, dtype=torch.float32)
+    else:
+        extra = g_extra = None
+    _lib.check(lib.nerf_composite_bwd(_p(rgb), _p(sigma), _p(z), _p(rays_d), _p(bg), bg_rows, _p(extra),
+                                      _p(g_rgb), _p(g_depth), _p(g_acc), _p(g_extra), R, S,
+                                      _p(d_rgb), _p(d_sigma), _p(d_extra), _stream()), "nerf_composite_bwd")
+    return d_rgb, d_sigma, d_extra
+
+
+class _Composite(torch.autograd.Function):
+    """volume_render (reference src/renderer.py:204-237) as one fused kernel per direction."""
+
+    @staticmethod
+    def forward(ctx, rgb, sigma, z, rays_d, bg, extra):
+        out_rgb, depth, acc, extra_map, _ = composite_fwd(rgb, sigma, z, rays_d, bg, extra)
+        ctx.save_for_backward(rgb, sigma, z, rays_d, bg, extra)
+        if extra_map is None:
+            extra_map = out_rgb.new_zeros(0)
+        return out_rgb, depth, acc, extra_map
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc, g_extra):
+        rgb, sigma, z, rays_d, bg, extra = ctx.saved_tensors
+        d_rgb, d_sigma, d_extra = composite_bwd(rgb, sigma, z, rays_d, bg, extra, g_rgb.contiguous(),
+                                                g_depth.contiguous(), g_acc.contiguous(),
+                                                None if extra is None else g_extra.contiguous())
+        return d_rgb, d_sigma, None, None, None, d_extra
+
+
+def composite(rgb: Tensor, sigma: Tensor, z: Tensor, rays_d: Tensor, bg: Optional[Tensor] = None,
+              extra: Optional[Tensor] = None):
+    """Differentiable w.r.t. rgb [R,S,3], sigma [R,S] (and extra [R,S,3])."""
+    out_rgb, depth, acc, extra_map = _Composite.apply(rgb, sigma, z, rays_d, bg, extra)
+    return out_rgb, depth, acc, (extra_map if extra is not None else None)
+
+
+# --------------------------------------------------------------------------- a6
+MLP_PARAM_COUNT = 595844
+
+
+def mlp_packed_bytes() -> int:
+    return _lib.load().nerf_mlp_packed_bytes()
+
+
+def mlp_pack(params: Tensor, packed: Optional[Tensor] = None) -> Tensor:
+    """flat fp32 [595844] (reference state_dict order) -> fragment-ordered bf16 streams."""
+    lib = _lib.load()
+    params = _dev(params, "params")
+    if params.numel() != MLP_PARAM_COUNT:
+        raise ValueError(f"params must have {MLP_PARAM_COUNT} elements, got {params.numel()}")
+    if packed is None:
+        packed = torch.empty(lib.nerf_mlp_packed_bytes(), device=params.device, dtype=torch.uint8)
+    _lib.check(lib.nerf_mlp_pack(_p(params), _p(packed), _stream()), "nerf_mlp_pack")
+    return packed
+
+
+def mlp_stash_bytes(n: int) -> int:
+    return _lib.load().nerf_mlp_stash_bytes(n)
+
+
+def mlp_fwd(packed: Tensor, rays_o: Tensor, rays_d: Tensor, z: Optional[Tensor],
+            stash: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """ray mode (z [R,S] given): rgb [R*S,3], sigma [R*S]; point mode (z None): per point."""
+    lib = _lib.load()
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    if z is not None:
+        z = _dev(z, "z")
+        n, S = z.numel(), z.shape[1]
+    else:
+        n, S = rays_o.shape[0], 0
+    rgb = torch.empty(n, 3, device=rays_o.device, dtype=torch.float32)
+    sigma = torch.empty(n, device=rays_o.device, dtype=torch.float32)
+    _lib.check(lib.nerf_mlp_fwd(_p(packed), _p(rays_o), _p(rays_d), _p(z), n, S, _p(rgb), _p(sigma),
+                                _p(stash), _stream()), "nerf_mlp_fwd")
+    return rgb, sigma
+
+
+# --------------------------------------------------------------------------- a14
+def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0,
+              grad_scale: Optional[Tensor] = None) -> None:
+    lib = _lib.load()
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if _dev(t, nm) is not t:
+            raise ValueError(f"{nm} must be contiguous")
+    _lib.check(lib.nerf_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), step,
+                                  lr, beta1, beta2, eps, weight_decay, _p(grad_scale), _stream()),
+               "nerf_adam_step")

@@ -1,0 +1,70 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/nerf_hip.h declares, and the ctypes table matches the header."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nerf_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import project_nerf_amd
+    from project_nerf_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("nerf_build", os.path.join(ROOT, "project-nerf_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    return _lib
+
+
+def test_header_declares_functions():
+    names = declared_functions()
+    assert "nerf_mlp_fwd" in names and "nerf_composite_fwd" in names and len(names) >= 12
+
+
+def test_library_exports_every_declared_symbol(lib):
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    missing = [n for n in declared_functions() if not hasattr(handle, n)]
+    assert not missing, f"declared in nerf_hip.h but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header(lib):
+    assert sorted(lib.PROTOTYPES) == declared_functions()
+    text = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, (_, argtypes) in lib.PROTOTYPES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, text, flags=re.S)
+        assert m, name
+        args = m.group(1).strip()
+        n_args = 0 if args in ("", "void") else len(args.split(","))
+        assert n_args == len(argtypes), f"{name}: header has {n_args} args, ctypes table {len(argtypes)}"
+
+
+def test_load_and_size_queries(lib):
+    h = lib.load()
+    assert h.nerf_abi_version() == 1
+    assert h.nerf_mlp_packed_bytes() % 256 == 0 and h.nerf_mlp_packed_bytes() > 2 * 1024 * 1024
+    assert h.nerf_mlp_stash_bytes(0) == 0
+    per_sample = h.nerf_mlp_stash_bytes(262144) / 262144
+    assert 5000 < per_sample < 6000          # ~5.3 KB of bf16 activations + relu bits per sample
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    """No CPU fallback: host tensors are an error, not a slow path."""
+    import torch
+    from project_nerf_amd import ops
+    with pytest.raises(lib.NerfHipError):
+        ops.fourier_encode(torch.zeros(4, 3), 10)
+    with pytest.raises(lib.NerfHipError):
+        ops.sample_rays(torch.zeros(4, 3), torch.zeros(4, 3), 2.0, 6.0, 64)

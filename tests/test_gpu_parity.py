@@ -1,0 +1,228 @@
+"""HIP-vs-oracle parity, through the C ABI, on a real MI355X (pytest -m gpu).
+
+Bit-exact for sample depths / voxel indices / masks; stated fp tolerance elsewhere.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test on a box without a HIP device")
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import ops as _ops
+    _ops._lib.load()
+    return _ops
+
+
+def dev(a):
+    if isinstance(a, np.ndarray):
+        a = T(a)
+    return a.cuda()
+
+
+def synth_rays(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * 4.0311
+    tgt = (torch.rand(n, 3, generator=g) - 0.5) * 1.6
+    d = tgt - o
+    return o, d / d.norm(dim=-1, keepdim=True)
+
+
+# ------------------------------------------------------------------ a1 / a2
+@pytest.mark.parametrize("S", [2, 3, 64, 65, 96, 128, 192, 256])
+def test_depths_bit_exact_vs_oracle(ops, S):
+    R = 37
+    o, d = synth_rays(R, 1)
+    z = ops.sample_rays(dev(o), dev(d), 2.0, 6.0, S)
+    assert torch.equal(z.cpu(), O.stratified_depths(2.0, 6.0, S, R, False))
+    u = torch.rand(R, S, generator=torch.Generator().manual_seed(S))
+    z = ops.sample_rays(dev(o), dev(d), 2.0, 6.0, S, u=dev(u))
+    assert torch.equal(z.cpu(), O.stratified_depths(2.0, 6.0, S, R, True, u=u))
+
+
+@pytest.mark.parametrize("S", [64, 128])
+def test_depths_bit_exact_vs_reference_golden(ops, S):
+    g = golden(f"g2_sampling_S{S}")
+    o, d = synth_rays(5, 2)
+    z0 = ops.sample_rays(dev(o), dev(d), 2.0, 6.0, S)
+    z1 = ops.sample_rays(dev(o), dev(d), 2.0, 6.0, S, u=dev(g["u"]))
+    assert np.array_equal(z0.cpu().numpy(), g["z_plain"])
+    assert np.array_equal(z1.cpu().numpy(), g["z_jitter"])
+
+
+def test_ray_points(ops):
+    R, S = 129, 64
+    o, d = synth_rays(R, 3)
+    d = d * 1.7
+    u = torch.rand(R, S, generator=torch.Generator().manual_seed(9))
+    z, pts, dirs = ops.sample_rays(dev(o), dev(d), 2.0, 6.0, S, u=dev(u), want_points=True)
+    zc = O.stratified_depths(2.0, 6.0, S, R, True, u=u)
+    p_ref, d_ref = O.ray_points(o, d, zc)
+    assert torch.equal(pts.cpu(), p_ref)           # mul then add, no FMA: bit-exact
+    np.testing.assert_allclose(dirs.cpu().numpy(), d_ref.numpy(), rtol=2e-7, atol=0)
+
+
+def test_empty_batches(ops):
+    e3 = torch.empty(0, 3).cuda()
+    assert ops.sample_rays(e3, e3, 2.0, 6.0, 64).shape == (0, 64)
+    assert ops.fourier_encode(e3, 10).shape == (0, 63)
+    grid = torch.ones(8, 8, 8, dtype=torch.bool).cuda()
+    assert ops.active_mask(e3, grid, 1.5).shape == (0,)
+
+
+# ------------------------------------------------------------------ a3
+@pytest.mark.parametrize("res", [64, 128])
+def test_voxel_index_and_mask_bit_exact(ops, res):
+    g = golden(f"g3_mask_res{res}")
+    mask, idx = ops.active_mask(dev(g["pts"]), dev(g["bits"]), 1.5, want_index=True)
+    assert np.array_equal(idx.cpu().numpy(), g["idx"])
+    assert np.array_equal(mask.cpu().numpy(), g["mask"])
+
+
+def test_mask_large_random_vs_oracle(ops):
+    gen = torch.Generator().manual_seed(5)
+    pts = (torch.rand(200_000, 3, generator=gen) - 0.5) * 3.3
+    bits = torch.rand(128, 128, 128, generator=gen) < 0.1
+    mask, idx = ops.active_mask(dev(pts), dev(bits), 1.5, want_index=True)
+    assert torch.equal(idx.cpu(), O.voxel_index(pts, 1.5, 128))
+    assert torch.equal(mask.cpu(), O.active_mask(pts, bits, 1.5))
+
+
+# ------------------------------------------------------------------ a5
+@pytest.mark.parametrize("dim,L", [(1, 10), (2, 15), (3, 4), (3, 10), (1, 6)])
+def test_fourier_vs_reference_golden(ops, dim, L):
+    g = golden(f"g1_fourier_d{dim}_L{L}")
+    y = ops.fourier_encode(dev(g["x"]), L).cpu().numpy()
+    assert y.shape == g["y"].shape
+    # sinf/cosf of the identically rounded fp32 argument: a few ulp of 1.0
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=4e-7)
+    assert np.array_equal(y[:, :dim], g["x"])
+
+
+# ------------------------------------------------------------------ a9
+@pytest.mark.parametrize("S", [64, 128])
+@pytest.mark.parametrize("tag", ["none", "vec", "ray"])
+def test_composite_fwd_bwd_vs_reference_golden(ops, S, tag):
+    g = golden(f"g5_composite_S{S}_{tag}")
+    bg = None if g["bg"].size == 0 else dev(g["bg"])
+    rgb, sig = dev(g["rgb"]).requires_grad_(True), dev(g["sigma"]).requires_grad_(True)
+    c, dep, acc, _ = ops.composite(rgb, sig, dev(g["z"]), dev(g["rays_d"]), bg)
+    np.testing.assert_allclose(c.detach().cpu().numpy(), g["out_rgb"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dep.detach().cpu().numpy(), g["out_depth"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(acc.detach().cpu().numpy(), g["out_acc"], rtol=2e-5, atol=2e-6)
+    ((c * dev(g["g_rgb_map"])).sum() + (dep * dev(g["g_depth"])).sum() + (acc * dev(g["g_acc"])).sum()).backward()
+    np.testing.assert_allclose(rgb.grad.cpu().numpy(), g["d_rgb"], rtol=2e-5, atol=1e-7)
+    ds, ref = sig.grad.cpu().numpy(), g["d_sigma"]
+    scale = np.abs(ref).max(axis=1, keepdims=True) + 1e-12
+    assert np.max(np.abs(ds - ref) / scale) < 5e-5
+
+
+@pytest.mark.parametrize("S", [1, 17, 64, 100, 129, 256])
+def test_composite_ragged_sample_counts(ops, S):
+    gen = torch.Generator().manual_seed(S)
+    R = 33
+    z = torch.sort(torch.rand(R, S, generator=gen) * 4 + 2, dim=-1).values
+    sig = torch.rand(R, S, generator=gen) * 3
+    rgb = torch.rand(R, S, 3, generator=gen)
+    extra = torch.randn(R, S, 3, generator=gen)
+    _, d = synth_rays(R, S)
+    c, dep, acc, ex, w = ops.composite_fwd(dev(rgb), dev(sig), dev(z), dev(d), dev(torch.ones(3)), dev(extra), True)
+    rc, rd, ra, rw = O.composite(rgb, sig, z, d, torch.ones(3), return_weights=True)
+    np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dep.cpu().numpy(), rd.numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(w.cpu().numpy(), rw.numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(ex.cpu().numpy(), (rw[..., None] * extra).sum(1).numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_composite_far_sample_absorbs_remainder(ops):
+    """sigma > 0 everywhere => alpha_last = 1 => acc == 1 (reference quirk)."""
+    R, S = 16, 64
+    z = O.stratified_depths(2.0, 6.0, S, R, False).contiguous()
+    sig = torch.full((R, S), 1e-3)
+    rgb = torch.rand(R, S, 3)
+    _, d = synth_rays(R, 4)
+    _, _, acc, _, _ = ops.composite_fwd(dev(rgb), dev(sig), dev(z), dev(d))
+    np.testing.assert_allclose(acc.cpu().numpy(), 1.0, atol=1e-6)
+
+
+# ------------------------------------------------------------------ a6
+def bf16_decoder(params, pts, dirs):
+    """The oracle decoder with the product's numerics: bf16 weights/activations, fp32 accumulate."""
+    q = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    x, d = q(O.fourier_encode(pts, 10)), q(O.fourier_encode(dirs, 4))
+    W = {k: (q(v) if k.endswith("weight") else v) for k, v in params.items()}
+    h = x
+    for i in range(8):
+        if i == 4:
+            h = torch.cat([h, x], -1)
+        h = q(torch.relu(torch.nn.functional.linear(h, W[f"pts_layers.{i}.weight"], W[f"pts_layers.{i}.bias"])))
+    sigma = torch.relu(torch.nn.functional.linear(h, W["sigma_layer.weight"], W["sigma_layer.bias"]))
+    feat = q(torch.nn.functional.linear(h, W["feature_layer.weight"], W["feature_layer.bias"]))
+    hv = q(torch.relu(torch.nn.functional.linear(torch.cat([feat, d], -1), W["view_layer.weight"], W["view_layer.bias"])))
+    rgb = torch.sigmoid(torch.nn.functional.linear(hv, W["rgb_layer.weight"], W["rgb_layer.bias"]))
+    return rgb, sigma
+
+
+def flat_params(params):
+    return torch.cat([params[k].reshape(-1) for k, _ in O.nerf_param_shapes()])
+
+
+def golden_params():
+    g = golden("g4_decoder")
+    return {k[2:]: T(v) for k, v in g.items() if k.startswith("w:")}, g
+
+
+def test_decoder_point_mode_vs_reference_golden(ops):
+    params, g = golden_params()
+    packed = ops.mlp_pack(dev(flat_params(params)))
+    rgb, sigma = ops.mlp_fwd(packed, dev(g["pts"]), dev(g["dirs"]), None)
+    # fp32 reference vs bf16-MFMA product: stated tolerance 2e-2 abs on rgb, 3% of max on sigma
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb"], atol=2e-2)
+    np.testing.assert_allclose(sigma.cpu().numpy(), g["sigma"][:, 0], atol=0.03 * max(1.0, g["sigma"].max()))
+    # against the same numerics (bf16 operands, fp32 accumulate) the match is tight
+    rb, sb = bf16_decoder(params, T(g["pts"]), T(g["dirs"]))
+    np.testing.assert_allclose(rgb.cpu().numpy(), rb.numpy(), atol=3e-3)
+    np.testing.assert_allclose(sigma.cpu().numpy(), sb[:, 0].numpy(), atol=3e-3 * max(1.0, float(sb.max())))
+
+
+@pytest.mark.parametrize("R,S", [(1, 64), (7, 64), (96, 64), (33, 128), (300, 2)])
+def test_decoder_ray_mode_ragged_tiles(ops, R, S):
+    """Tiles that are not multiples of 256 samples, scaled weights so that outputs vary."""
+    params = O.nerf_init_params(seed=R + S)
+    params = {k: (v * 2.5 if k.endswith("weight") else v) for k, v in params.items()}
+    o, d = synth_rays(R, 7)
+    u = torch.rand(R, S, generator=torch.Generator().manual_seed(1))
+    z = O.stratified_depths(2.0, 6.0, S, R, True, u=u)
+    packed = ops.mlp_pack(dev(flat_params(params)))
+    rgb, sigma = ops.mlp_fwd(packed, dev(o), dev(d), dev(z.contiguous()))
+    pts, dirs = O.ray_points(o, d, z)
+    rb, sb = bf16_decoder(params, pts, dirs)
+    assert rgb.shape == (R * S, 3) and sigma.shape == (R * S,)
+    np.testing.assert_allclose(rgb.cpu().numpy(), rb.numpy(), atol=6e-3)
+    np.testing.assert_allclose(sigma.cpu().numpy(), sb[:, 0].numpy(), atol=6e-3 * max(1.0, float(sb.max())))
+    r32, s32 = O.nerf_field(params, pts, dirs)
+    assert float((rgb.cpu() - r32).abs().max()) < 5e-2
+
+
+# ------------------------------------------------------------------ a14
+def test_adam_and_adamw_vs_reference_golden(ops):
+    g = golden("g10_optim")
+    for name, lr0, wd in (("adam", 5e-4, 0.0), ("adamw", 1e-2, 1e-5)):
+        for k in range(3):
+            p = dev(g[f"init_p{k}"]).reshape(-1).clone()
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            for step in range(5):
+                lr = lr0 if name == "adam" else O.cosine_lr(1e-2, 1e-4, step, 2000)
+                ops.adam_step(p, dev(g[f"grads_p{k}"][step]).reshape(-1), m, v, step + 1, lr, weight_decay=wd)
+            np.testing.assert_allclose(p.cpu().numpy(), g[f"{name}_p{k}"].reshape(-1), rtol=3e-6, atol=2e-7)
