@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""Headline benchmark: vanilla NeRF (BASELINE.json configs[1]) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one training step of the hot path on one batch of synthetic rays: 4096 rays x 64
+stratified samples (configs/part2.yaml.example: batch_size 4096, n_samples 64) through
+sample -> fused bf16-MFMA decoder fwd -> composite -> MSE -> composite bwd -> dgrad chain ->
+wgrad -> (RCCL all-reduce) -> Adam -> weight repack, inputs resident in HBM.  Rays shard across
+ranks (weak scaling: every rank owns its own 4096-ray batch; one gradient all-reduce per step).
+``value`` = rays/s summed over ranks.  The same run also times the 800x800, 128-samples/ray
+render (640,000 rays; FPS reported as ``render_fps``), each kernel of the step on its own with
+HIP events (``kernels``), the roofline of the dominant kernel, and -- on rank 0 at N=1 -- the
+CPU oracle on a bounded sample of the same step (``cpu_baseline``).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_FLOP = 1186816           # per sample, forward  (2 x 593,408 MAC)
+TRAIN_FLOP = 3489024         # per sample, fwd + dgrad + wgrad
+DGRAD_FLOP = 2 * (593408 - 35712 - 256 * 63)   # transposed chain, code columns and layer 0 skipped
+WGRAD_FLOP = 2 * 593408
+MFMA_PEAK_TFLOPS = 2500.0    # gfx950 dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_rays(n, seed, device):
+    """Cameras on the NeRF-Synthetic hemisphere (radius 4.0311) looking at the scene."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(n, 3, generator=g)
+    o[:, 2] = o[:, 2].abs()
+    o = o / o.norm(dim=-1, keepdim=True) * 4.0311
+    tgt = (torch.rand(n, 3, generator=g) - 0.5) * 2.0
+    d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    target = torch.rand(n, 3, generator=g)
+    return o.to(device), d.to(device), target.to(device)
+
+
+def event_ms(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(rays, samples, threads):
+    """The oracle (CPU restatement of the reference, fp32 PyTorch) on a bounded sample of the step."""
+    from oracle import nerf_oracle as O
+    torch.set_num_threads(threads)
+    params = {k: v.clone().requires_grad_(True) for k, v in O.nerf_init_params(seed=0).items()}
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4)
+    o, d, target = synth_rays(rays, 1, "cpu")
+    field = lambda p, v: O.nerf_field(params, p, v)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        pred, _, _ = O.render_rays(field, o, d, 2.0, 6.0, samples, True)
+        loss = torch.nn.functional.mse_loss(pred, target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    step_s = min(times[1:])
+    return {"value": rays / step_s, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"train step on {rays} rays x {samples} samples (1 warm-up + 2 timed), oracle/nerf_oracle.py fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--render-samples", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-render", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import ops
+    from project_nerf_amd.engine import VanillaNerfEngine
+
+    eng = VanillaNerfEngine(seed=0, world_size=world, device=str(device))
+    R, S = args.rays, args.samples
+    o, d, target = synth_rays(R, 100 + rank, device)
+    sync = (lambda g: dist.all_reduce(g)) if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step(o, d, target, S, sync_grads=sync)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = eng.train_step(o, d, target, S, sync_grads=sync)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    rays_per_s = R * world * args.steps / dt
+
+    out = {
+        "metric": "train rays/sec + 800x800 render FPS, NeRF-Synthetic Lego; PSNR parity",
+        "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "Part 2 vanilla NeRF train step (L10/L4 Fourier, 8x256 skip-4 MLP, view 128)",
+                   "rays_per_gpu": R, "samples_per_ray": S, "global_rays": R * world,
+                   "parallelism": f"ray-dp{world}", "weights": "random init (seed 0)",
+                   "render": f"800x800 x {args.render_samples} samples/ray"},
+        "final_loss": float(loss.item()),
+    }
+
+    if rank == 0:
+        # ---- per-kernel timing with HIP events on the launch stream (torch's current stream) ----
+        n = R * S
+        u = torch.rand(R, S, device=device)
+        z = ops.sample_rays(o, d, 2.0, 6.0, S, u=u)
+        stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device=device)
+        rgb, sigma = ops.mlp_fwd(eng.packed, o, d, z, stash)
+        pred, _, _, _, _ = ops.composite_fwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg)
+        g_pred = (pred - target) * (2.0 / pred.numel())
+        d_rgb, d_sigma, _ = ops.composite_bwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg, None, g_pred, None, None, None)
+        ws = torch.empty(ops.mlp_bwd_workspace_bytes(n), dtype=torch.uint8, device=device)
+        grads = torch.empty_like(eng.params)
+        lib = ops._lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        P = lambda t: t.data_ptr()
+        k = {}
+        k["mlp_fwd_train"] = event_ms(lambda: ops.mlp_fwd(eng.packed, o, d, z, stash), 20)
+        k["mlp_fwd_infer"] = event_ms(lambda: ops.mlp_fwd(eng.packed, o, d, z), 20)
+        k["mlp_bwd_dgrad"] = event_ms(lambda: lib.nerf_mlp_bwd_dgrad(P(eng.packed), P(stash), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(ws), st), 20)
+        k["mlp_bwd_wgrad"] = event_ms(lambda: lib.nerf_mlp_bwd_wgrad(P(stash), P(ws), n, P(grads), st), 20)
+        k["composite_fwd"] = event_ms(lambda: ops.composite_fwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg), 20)
+        k["composite_bwd"] = event_ms(lambda: ops.composite_bwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg, None, g_pred, None, None, None), 20)
+        tp, tm, tv = eng.params.clone(), torch.zeros_like(grads), torch.zeros_like(grads)
+        k["adam+pack"] = event_ms(lambda: (ops.adam_step(tp, grads, tm, tv, 1, 5e-4), ops.mlp_pack(eng.params, eng.packed)), 20)
+        stash_b, ws_b = ops.mlp_stash_bytes(n), ops.mlp_bwd_workspace_bytes(n)
+        kern = {
+            "mlp_fwd_train": {"ms": k["mlp_fwd_train"], "tflops": n * FWD_FLOP / k["mlp_fwd_train"] * 1e-9},
+            "mlp_fwd_infer": {"ms": k["mlp_fwd_infer"], "tflops": n * FWD_FLOP / k["mlp_fwd_infer"] * 1e-9},
+            "mlp_bwd_dgrad": {"ms": k["mlp_bwd_dgrad"], "tflops": n * DGRAD_FLOP / k["mlp_bwd_dgrad"] * 1e-9},
+            "mlp_bwd_wgrad": {"ms": k["mlp_bwd_wgrad"], "tflops": n * WGRAD_FLOP / k["mlp_bwd_wgrad"] * 1e-9,
+                              "gbs": (stash_b + ws_b) / k["mlp_bwd_wgrad"] * 1e-6},
+            "composite_fwd": {"ms": k["composite_fwd"], "gbs": (n * 20 + R * 32) / k["composite_fwd"] * 1e-6},
+            "composite_bwd": {"ms": k["composite_bwd"], "gbs": (n * 36 + R * 32) / k["composite_bwd"] * 1e-6},
+            "adam+pack": {"ms": k["adam+pack"]},
+        }
+        out["kernels"] = kern
+        # dominant kernel of the step = the decoder chain (fwd + dgrad run the same MFMA structure);
+        # report the forward training launch: algorithmic FLOP per launch / measured launch time
+        dom = "mlp_fwd_train"
+        ach = n * FWD_FLOP / k[dom] * 1e-9
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                           "flop_per_launch": n * FWD_FLOP, "launch_ms": k[dom]}
+        step_ach = R * S * TRAIN_FLOP / (ms_per_step * 1e-3) * 1e-12
+        out["step_tflops"] = step_ach
+        out["step_frac_of_mfma_peak"] = step_ach / MFMA_PEAK_TFLOPS
+
+    # ---- render: 800x800 rays, 128 samples, rays split into row bands across ranks ----
+    if not args.no_render:
+        H = W = 800
+        rows = H // world
+        ro, rd, _ = synth_rays(rows * W, 7 + rank, device)
+        eng.render_image(ro, rd, args.render_samples)     # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        frames = 3
+        for _ in range(frames):
+            img = eng.render_image(ro, rd, args.render_samples)
+            if world > 1:
+                bands = [torch.empty_like(img) for _ in range(world)] if rank == 0 else None
+                dist.gather(img, bands, dst=0)
+        barrier()
+        rt = (time.perf_counter() - t0) / frames
+        if world > 1:
+            t = torch.tensor([rt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rt = float(t.item())
+        out["render_fps"] = 1.0 / rt
+        out["render_ms_per_frame"] = rt * 1e3
+        out["render_tflops"] = H * W * args.render_samples * FWD_FLOP / rt * 1e-12
+        out["render_frac_of_mfma_peak"] = out["render_tflops"] / MFMA_PEAK_TFLOPS
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        out["cpu_baseline"] = cpu_baseline(1024, S, min(cores, 16))   # the box's CPU share for one GPU is 16
+        out["gpu_over_cpu"] = rays_per_s / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

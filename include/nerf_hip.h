@@ -119,6 +119,23 @@ int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, c
                  int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
                  nerf_stream_t stream);
 
+/* Backward of nerf_mlp_fwd (autograd of src/decoders.py:68-87; the loss.backward() of
+ * run.py:337 for the decoder).  rgb/sigma are the forward outputs, d_rgb [n,3] / d_sigma [n]
+ * the upstream gradients; grads_f32 [595844] (same layout as the parameter vector) is
+ * OVERWRITTEN.  Two kernels: a dgrad chain (transposed weight stream, pre-activation
+ * gradients kept as bf16 in `workspace`) and a split-K weight-gradient pass over the stash.
+ * workspace: nerf_mlp_bwd_workspace_bytes(n), 256-byte aligned. */
+size_t nerf_mlp_bwd_workspace_bytes(int64_t n);
+int nerf_mlp_bwd(const void* packed, const void* stash, const float* rgb, const float* sigma,
+                 const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
+                 void* workspace, nerf_stream_t stream);
+/* the two halves of nerf_mlp_bwd, separately launchable (profiling, overlap with comms) */
+int nerf_mlp_bwd_dgrad(const void* packed, const void* stash, const float* rgb, const float* sigma,
+                       const float* d_rgb, const float* d_sigma, int64_t n, void* workspace,
+                       nerf_stream_t stream);
+int nerf_mlp_bwd_wgrad(const void* stash, const void* workspace, int64_t n, float* grads_f32,
+                       nerf_stream_t stream);
+
 /* ---- a14: optimiser ---------------------------------------------------------
  * replaces torch.optim.Adam / AdamW .step() (run.py:307,338; run.py:546,629) for
  * one flat fp32 parameter vector.  step counts from 1.  weight_decay is the

@@ -33,6 +33,10 @@ PROTOTYPES = {
     "nerf_mlp_pack": (i32, [c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_stash_bytes": (size_t, [i64]),
     "nerf_mlp_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_mlp_bwd_workspace_bytes": (size_t, [i64]),
+    "nerf_mlp_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
+    "nerf_mlp_bwd_dgrad": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
+    "nerf_mlp_bwd_wgrad": (i32, [c_ptr, c_ptr, i64, c_ptr, c_ptr]),
     "nerf_adam_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, c_ptr]),
 }
 

@@ -86,6 +86,19 @@ __device__ __forceinline__ float wave_inclusive_suffix_sum(float v) {
   return v + carry;
 }
 
+// exclusive suffix sum: lane i gets sum_{k>i} v_k (shifted scan: no `inclusive - own`
+// cancellation when a lane's own term dwarfs everything behind it)
+__device__ __forceinline__ float wave_exclusive_suffix_sum(float v) {
+  const float incl = wave_inclusive_suffix_sum(v);
+  float ex = dpp_row_shl<1>(incl, 0.0f);
+  const float n16 = lane_read(incl, 16), n32 = lane_read(incl, 32), n48 = lane_read(incl, 48);
+  const int lane = __lane_id();
+  if (lane == 15) ex = n16;
+  if (lane == 31) ex = n32;
+  if (lane == 47) ex = n48;
+  return ex;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

@@ -40,7 +40,7 @@ __device__ __forceinline__ void ray_setup(const float* __restrict__ sigma, const
     sig_out[k] = sg;
     float dl = (s < S - 1) ? (zn[k + 1] - zn[k]) : 1e10f;   // src/renderer.py:213-214
     dl = dl * dnorm;
-    const float e = valid ? __expf(-sg * dl) : 1.0f;
+    const float e = valid ? expf(-sg * dl) : 1.0f;
     c.z[k] = zn[k];
     c.delta[k] = dl;
     c.e[k] = e;
@@ -183,8 +183,7 @@ composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
       }
     }
     // suffix sum over later samples: lanes after this one, then within the lane
-    const float incl = wave_inclusive_suffix_sum(local);
-    float after = incl - local;  // sum over lanes > this lane
+    float after = wave_exclusive_suffix_sum(local);  // sum over lanes > this lane
 #pragma unroll
     for (int k = K - 1; k >= 0; --k) {
       const int s = lane * K + k;

@@ -2,6 +2,8 @@
 // global_load_lds_dwordx4, the per-m-tile MFMA loop, accumulator -> bf16 operand conversion,
 // and the in-register Fourier codes.  See mlp_plan.h for the data layout.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "common.h"
 #include "mlp_plan.h"
 
@@ -61,14 +63,23 @@ struct WeightRing {
       __builtin_amdgcn_global_load_lds((gptr_t)(sbase + i * 8192 + voff), (lptr_t)(dst + i * 8192), 16, 0, 0);
   }
   __device__ __forceinline__ void prologue() { issue<0>(0); }
-  // returns the LDS address lane `lane` reads its A fragments of the current chunk from
-  template <int C>
+  // Returns the LDS address this lane reads its A fragments of chunk C from.
+  // STORES = vector-memory instructions (stash stores) this wave issued since it issued the
+  // DMA of chunk C: vmcnt retires in issue order, so vmcnt(STORES) proves the DMA has landed
+  // without draining the (slow) stores.  Under-counting is safe, over-counting is not.
+  template <int C, int STORES>
   __device__ __forceinline__ const char* advance(bool more_passes) {
     constexpr int n = chunks().n_chunks;
-    __syncthreads();
+    static_assert(STORES >= 0 && STORES < 48, "vmcnt immediate");
+    __builtin_amdgcn_sched_barrier(0);   // also bounds the scheduler's regions (compile time)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     slot ^= 1;
     if constexpr (C + 1 < n) issue<C + 1>(slot ^ 1);
     else if (more_passes) issue<0>(slot ^ 1);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     return lds + slot * kRingSlotBytes + lane * 16;
   }
 };
@@ -115,6 +126,86 @@ __device__ __forceinline__ void acc_to_operand(const f32x16& acc, bf16x8& lo, bf
     lo[j] = (__bf16)acc[j];
     hi[j] = (__bf16)acc[8 + j];
   }
+}
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// stash stores (16-byte global stores) the epilogue of m-tile group g issues when training
+template <bool BWD>
+constexpr int group_stores(int g) {
+  int acc = 0;
+  for (int s = 0; s < plan::stream_steps(BWD); ++s) {
+    const int kind = plan::stream_first(BWD) + s;
+    const int mt = plan::step_of(kind).mt;
+    if (g < acc + mt) {
+      const int m = g - acc;
+      if (kind == plan::F_RGB) return 0;
+      if (kind == plan::F_HEAD && m == 8) return 0;
+      return 2;
+    }
+    acc += mt;
+  }
+  return 0;
+}
+// stash stores issued while the chunk BEFORE the one opened by group g was consumed
+template <bool BWD>
+constexpr int prev_chunk_stores(int g) {
+  const plan::Chunks& ch = WeightRing<BWD>::chunks();
+  const int c = ch.group_chunk[g];
+  if (c == 0) return 0;            // wraps across tile passes: drain everything
+  int n = 0;
+  for (int i = 0; i < ch.n_groups; ++i) n += ch.group_chunk[i] == c - 1 ? group_stores<BWD>(i) : 0;
+  return n;
+}
+
+// Runs one GEMM step; epi(mc, acc) consumes each finished 32-row tile.
+// STASH: the epilogues issue their stash stores (training); false for inference.
+template <bool BWD, int KIND, int KS, bool STASH, class Epi>
+__device__ __forceinline__ void run_step(WeightRing<BWD>& ring, const char*& a_base, bool more_passes,
+                                         const bf16x8 (&b)[KS], const float* bias_lds, int half, Epi&& epi) {
+  constexpr plan::Step st = plan::step_of(KIND);
+  static_assert(KS == st.ks_acc + st.ks_nat, "operand k-steps");
+  static_for<st.mt>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    constexpr int g = plan::group_of(KIND, m);
+    constexpr const plan::Chunks& ch = WeightRing<BWD>::chunks();
+    if constexpr (ch.group_first[g])
+      a_base = ring.template advance<ch.group_chunk[g], STASH ? prev_chunk_stores<BWD>(g) : 0>(more_passes);
+    f32x16 acc;
+    if constexpr (BWD) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    } else {
+      acc = bias_tile(bias_lds, plan::bias_off(KIND) + 32 * m, half);
+    }
+    acc = mtile_mfma<KS>(a_base, ch.group_off[g], b, acc);
+    epi(mc, acc);
+  });
+}
+
+// Blocked stash image of a [n, 32*MT] bf16 matrix: one 2-KiB block per (32-sample wave tile,
+// m-tile); lane (c, h) owns bytes [(2c+h)*32, +32) = its 16 accumulator rows as bf16 (the
+// two B fragments lo|hi).  Written with two 16-byte stores per lane; the wgrad kernel
+// DMAs blocks into LDS verbatim and transposes with ds_read_b64_tr_b16.
+__device__ __forceinline__ void stash_block(__bf16* base, int64_t wave_tile, int n_mtiles, int m, int col, int half,
+                                            const bf16x8& lo, const bf16x8& hi) {
+  char* p = reinterpret_cast<char*>(base) + ((wave_tile * n_mtiles + m) * 64 + 2 * col + half) * 32;
+  *reinterpret_cast<bf16x8*>(p) = lo;
+  *reinterpret_cast<bf16x8*>(p + 16) = hi;
+}
+// natural-order operand (Fourier codes, output gradients): 1-KiB block per (wave tile, k-step),
+// lane (c, h) owns bytes [(2c+h)*16, +16) = features 16ks + 8h + (0..7)
+__device__ __forceinline__ void stash_nat(__bf16* base, int64_t wave_tile, int n_ks, int ks, int col, int half,
+                                          const bf16x8& v) {
+  char* p = reinterpret_cast<char*>(base) + ((wave_tile * n_ks + ks) * 64 + 2 * col + half) * 16;
+  *reinterpret_cast<bf16x8*>(p) = v;
 }
 
 // ---------------------------------------------------------------------------

@@ -7,8 +7,6 @@
 // accumulators' initial values.  MFMA-bound: 1,186,816 FLOP per sample (+ padding).
 // TRAIN additionally stashes bf16 activations (row-major [n, width], the wgrad kernel's B
 // operands) and ReLU bitmasks for the backward chain.
-#include <type_traits>
-#include <utility>
 #include "mlp_chain.h"
 
 namespace nerf {
@@ -23,46 +21,15 @@ struct FwdArgs {
   int n_samples;        // 0: point mode (rays_o = pts[n,3], rays_d = dirs[n,3] used as given)
   float* rgb;
   float* sigma;
-  // training stash
-  __bf16* st_xenc;      // [n,64]
-  __bf16* st_h;         // 8 x [n,256], layer l at st_h + l*n*256
-  __bf16* st_feat;      // [n,256]
-  __bf16* st_hv;        // [n,128]
-  __bf16* st_denc;      // [n,32]
+  // training stash: blocked images (see stash_block / stash_nat), n rounded up to whole tiles
+  int64_t n_pad;        // ceil(n / 256) * 256
+  __bf16* st_xenc;      // nat  [n_pad, 64]
+  __bf16* st_h;         // 8 x blocked [n_pad, 256], layer l at st_h + l * n_pad * 256
+  __bf16* st_feat;      // blocked [n_pad, 256]
+  __bf16* st_hv;        // blocked [n_pad, 128]
+  __bf16* st_denc;      // nat  [n_pad, 32]
   uint4* st_mask;       // [tiles][9][512] relu bits: word (m>>1), bits 16*(m&1) + r
 };
-
-template <int N, class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
-// Runs one GEMM step; epi(mc, acc) consumes each finished 32-row tile.
-template <bool BWD, int KIND, int KS, class Epi>
-__device__ __forceinline__ void run_step(WeightRing<BWD>& ring, const char*& a_base, bool more_passes,
-                                         const bf16x8 (&b)[KS], const float* bias_lds, int half, Epi&& epi) {
-  constexpr Step st = step_of(KIND);
-  static_assert(KS == st.ks_acc + st.ks_nat, "operand k-steps");
-  static_for<st.mt>([&](auto mc) {
-    constexpr int m = decltype(mc)::value;
-    constexpr int g = group_of(KIND, m);
-    constexpr const Chunks& ch = WeightRing<BWD>::chunks();
-    if constexpr (ch.group_first[g]) a_base = ring.template advance<ch.group_chunk[g]>(more_passes);
-    f32x16 acc;
-    if constexpr (BWD) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    } else {
-      acc = bias_tile(bias_lds, bias_off(KIND) + 32 * m, half);
-    }
-    acc = mtile_mfma<KS>(a_base, ch.group_off[g], b, acc);
-    epi(mc, acc);
-  });
-}
 
 template <bool TRAIN>
 __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs a) {
@@ -108,15 +75,12 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
     bf16x8 xenc[4], denc[2];
     fourier_operand<4, kPosDim>(px, py, pz, half, xenc);
     fourier_operand<2, kDirDim>(vx, vy, vz, half, denc);
+    const int64_t wave_tile = tile * 8 + wave;
     if constexpr (TRAIN) {
-      if (live) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          *reinterpret_cast<bf16x8*>(a.st_xenc + n * 64 + 16 * ks + 8 * half) = xenc[ks];
+      for (int ks = 0; ks < 4; ++ks) stash_nat(a.st_xenc, wave_tile, 4, ks, col, half, xenc[ks]);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          *reinterpret_cast<bf16x8*>(a.st_denc + n * 32 + 16 * ks + 8 * half) = denc[ks];
-      }
+      for (int ks = 0; ks < 2; ++ks) stash_nat(a.st_denc, wave_tile, 2, ks, col, half, denc[ks]);
     }
 
     uint32_t mask_words[4];
@@ -137,19 +101,7 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
           }
         }
         acc_to_operand(acc, out[2 * m], out[2 * m + 1]);
-        if constexpr (TRAIN) {
-          if (live) {
-            __bf16* row = stash + n * width + 32 * m + 4 * half;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              bf16x4 v;
-              const bf16x8& src = out[2 * m + (g >> 1)];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = src[(g & 1) * 4 + e];
-              *reinterpret_cast<bf16x4*>(row + 8 * g) = v;
-            }
-          }
-        }
+        if constexpr (TRAIN) stash_block(stash, wave_tile, width / 32, m, col, half, out[2 * m], out[2 * m + 1]);
       };
     };
     auto flush_mask = [&](int layer) {
@@ -161,13 +113,13 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
 
     bf16x8 hA[16], hB[16];
     // ---- a6: pts_layers.0 .. 7 (src/decoders.py:70-74) ----
-    run_step<false, F_PTS0, 4>(ring, a_base, more, xenc, bias_lds, half, hidden(hA, a.st_h + 0 * a.n * 256, 256, true));
+    run_step<false, F_PTS0, 4, TRAIN>(ring, a_base, more, xenc, bias_lds, half, hidden(hA, a.st_h + 0 * a.n_pad * 256, 256, true));
     flush_mask(0);
-    run_step<false, F_PTS1, 16>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 1 * a.n * 256, 256, true));
+    run_step<false, F_PTS1, 16, TRAIN>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 1 * a.n_pad * 256, 256, true));
     flush_mask(1);
-    run_step<false, F_PTS2, 16>(ring, a_base, more, hB, bias_lds, half, hidden(hA, a.st_h + 2 * a.n * 256, 256, true));
+    run_step<false, F_PTS2, 16, TRAIN>(ring, a_base, more, hB, bias_lds, half, hidden(hA, a.st_h + 2 * a.n_pad * 256, 256, true));
     flush_mask(2);
-    run_step<false, F_PTS3, 16>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 3 * a.n * 256, 256, true));
+    run_step<false, F_PTS3, 16, TRAIN>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 3 * a.n_pad * 256, 256, true));
     flush_mask(3);
     {
       bf16x8 cat[20];   // skip connection: [h3 | xenc], hidden first (src/decoders.py:73)
@@ -175,20 +127,20 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
       for (int i = 0; i < 16; ++i) cat[i] = hB[i];
 #pragma unroll
       for (int i = 0; i < 4; ++i) cat[16 + i] = xenc[i];
-      run_step<false, F_PTS4, 20>(ring, a_base, more, cat, bias_lds, half, hidden(hA, a.st_h + 4 * a.n * 256, 256, true));
+      run_step<false, F_PTS4, 20, TRAIN>(ring, a_base, more, cat, bias_lds, half, hidden(hA, a.st_h + 4 * a.n_pad * 256, 256, true));
       flush_mask(4);
     }
-    run_step<false, F_PTS5, 16>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 5 * a.n * 256, 256, true));
+    run_step<false, F_PTS5, 16, TRAIN>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 5 * a.n_pad * 256, 256, true));
     flush_mask(5);
-    run_step<false, F_PTS6, 16>(ring, a_base, more, hB, bias_lds, half, hidden(hA, a.st_h + 6 * a.n * 256, 256, true));
+    run_step<false, F_PTS6, 16, TRAIN>(ring, a_base, more, hB, bias_lds, half, hidden(hA, a.st_h + 6 * a.n_pad * 256, 256, true));
     flush_mask(6);
-    run_step<false, F_PTS7, 16>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 7 * a.n * 256, 256, true));
+    run_step<false, F_PTS7, 16, TRAIN>(ring, a_base, more, hA, bias_lds, half, hidden(hB, a.st_h + 7 * a.n_pad * 256, 256, true));
     flush_mask(7);
 
     // ---- feature_layer (linear) + sigma_layer (relu) (src/decoders.py:77-80) ----
     {
       auto feat_epi = hidden(hA, a.st_feat, 256, false);
-      run_step<false, F_HEAD, 16>(ring, a_base, more, hB, bias_lds, half, [&](auto mc, f32x16 acc) {
+      run_step<false, F_HEAD, 16, TRAIN>(ring, a_base, more, hB, bias_lds, half, [&](auto mc, f32x16 acc) {
         constexpr int m = decltype(mc)::value;
         if constexpr (m < 8) feat_epi(mc, acc);
         else if (live && half == 0) a.sigma[n] = fmaxf(acc[0], 0.0f);
@@ -202,14 +154,14 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
       cat[16] = denc[0];
       cat[17] = denc[1];
       mask_words[0] = mask_words[1] = mask_words[2] = mask_words[3] = 0;
-      run_step<false, F_VIEW, 18>(ring, a_base, more, cat, bias_lds, half, hidden(hB, a.st_hv, 128, true));
+      run_step<false, F_VIEW, 18, TRAIN>(ring, a_base, more, cat, bias_lds, half, hidden(hB, a.st_hv, 128, true));
       flush_mask(8);
     }
     {
       bf16x8 hv[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) hv[i] = hB[i];
-      run_step<false, F_RGB, 8>(ring, a_base, more, hv, bias_lds, half, [&](auto, f32x16 acc) {
+      run_step<false, F_RGB, 8, TRAIN>(ring, a_base, more, hv, bias_lds, half, [&](auto, f32x16 acc) {
         if (live && half == 0) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) a.rgb[n * 3 + c] = 1.0f / (1.0f + __expf(-acc[c]));
@@ -221,28 +173,8 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
 
 }  // namespace nerf
 
+#include "mlp_stash.h"
 using namespace nerf;
-
-// stash layout (bytes), all offsets 256-B aligned for n % 128 == 0; computed for any n
-namespace {
-struct StashLayout {
-  size_t xenc, h, feat, hv, denc, mask, total;
-};
-StashLayout stash_layout(int64_t n) {
-  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-  StashLayout s{};
-  size_t o = 0;
-  s.xenc = o; o = up(o + (size_t)n * 64 * 2);
-  s.h = o;    o = up(o + (size_t)n * 256 * 2 * 8);
-  s.feat = o; o = up(o + (size_t)n * 256 * 2);
-  s.hv = o;   o = up(o + (size_t)n * 128 * 2);
-  s.denc = o; o = up(o + (size_t)n * 32 * 2);
-  const size_t tiles = (n + kTileSamples - 1) / kTileSamples;
-  s.mask = o; o = up(o + tiles * 9 * kChainThreads * 16);
-  s.total = o;
-  return s;
-}
-}  // namespace
 
 extern "C" size_t nerf_mlp_stash_bytes(int64_t n) { return n > 0 ? stash_layout(n).total : 0; }
 
@@ -264,6 +196,7 @@ extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float
   if (stash != nullptr) {
     const StashLayout s = stash_layout(n);
     char* b = static_cast<char*>(stash);
+    a.n_pad = s.n_pad;
     a.st_xenc = reinterpret_cast<__bf16*>(b + s.xenc);
     a.st_h = reinterpret_cast<__bf16*>(b + s.h);
     a.st_feat = reinterpret_cast<__bf16*>(b + s.feat);

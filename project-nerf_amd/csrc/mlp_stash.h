@@ -1,0 +1,53 @@
+// Byte layout of the training stash (written by nerf_mlp_fwd, read by nerf_mlp_bwd) and of
+// the backward workspace (dgrad chain -> wgrad).  All matrices are blocked images with the
+// sample count rounded up to whole 256-sample tiles; every offset is 256-byte aligned.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nerf {
+
+struct StashLayout {
+  int64_t n_pad;
+  size_t xenc, h, feat, hv, denc, mask, total;
+};
+
+inline StashLayout stash_layout(int64_t n) {
+  StashLayout s{};
+  s.n_pad = (n + 255) / 256 * 256;
+  const size_t np = (size_t)s.n_pad;
+  size_t o = 0;
+  s.xenc = o; o += np * 64 * 2;
+  s.h = o;    o += np * 256 * 2 * 8;
+  s.feat = o; o += np * 256 * 2;
+  s.hv = o;   o += np * 128 * 2;
+  s.denc = o; o += np * 32 * 2;
+  s.mask = o; o += (np / 256) * 9 * 512 * 16;
+  s.total = o;
+  return s;
+}
+
+// backward workspace: bf16 blocked gradients w.r.t. pre-activations
+struct BwdLayout {
+  int64_t n_pad;
+  size_t dsmall;   // nat [n_pad,16]: cols 0..2 d(rgb_pre), col 3 d(sigma_pre)
+  size_t dhv;      // blocked [n_pad,128]
+  size_t dfeat;    // blocked [n_pad,256]
+  size_t dh;       // 8 x blocked [n_pad,256], layer l at dh + l * n_pad * 512
+  size_t total;
+};
+
+inline BwdLayout bwd_layout(int64_t n) {
+  BwdLayout s{};
+  s.n_pad = (n + 255) / 256 * 256;
+  const size_t np = (size_t)s.n_pad;
+  size_t o = 0;
+  s.dsmall = o; o += np * 16 * 2;
+  s.dhv = o;    o += np * 128 * 2;
+  s.dfeat = o;  o += np * 256 * 2;
+  s.dh = o;     o += np * 256 * 2 * 8;
+  s.total = o;
+  return s;
+}
+
+}  // namespace nerf

@@ -98,10 +98,10 @@ extern "C" int nerf_sample_rays(const float* rays_o, const float* rays_d, const 
                                 float* z_out, float* pts_out, float* dirs_out, nerf_stream_t stream) {
   NERF_REQUIRE(n_rays >= 0 && n_samples >= 2, "nerf_sample_rays: n_rays=%lld n_samples=%d",
                (long long)n_rays, n_samples);
+  if (n_rays == 0) return NERF_OK;
   NERF_REQUIRE(z_out != nullptr, "nerf_sample_rays: z_out is NULL");
   NERF_REQUIRE((pts_out == nullptr && dirs_out == nullptr) || (rays_o && rays_d),
                "nerf_sample_rays: rays_o/rays_d required when pts/dirs are requested");
-  if (n_rays == 0) return NERF_OK;
   const float step = 1.0f / (float)(n_samples - 1);
   hipLaunchKernelGGL(sample_rays_kernel, dim3(grid_for(n_rays * n_samples, 256)), dim3(256), 0,
                      as_stream(stream), rays_o, rays_d, u, n_rays, n_samples, near_plane, far_plane,

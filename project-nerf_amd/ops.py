@@ -195,6 +195,51 @@ def mlp_fwd(packed: Tensor, rays_o: Tensor, rays_d: Tensor, z: Optional[Tensor],
     return rgb, sigma
 
 
+def mlp_bwd_workspace_bytes(n: int) -> int:
+    return _lib.load().nerf_mlp_bwd_workspace_bytes(n)
+
+
+def mlp_bwd(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Tensor, d_sigma: Tensor,
+            grads: Optional[Tensor] = None, workspace: Optional[Tensor] = None) -> Tensor:
+    """Parameter gradients [595844] (reference state_dict order) of the fused decoder."""
+    lib = _lib.load()
+    rgb, sigma = _dev(rgb, "rgb"), _dev(sigma, "sigma")
+    d_rgb, d_sigma = _dev(d_rgb, "d_rgb"), _dev(d_sigma, "d_sigma")
+    n = sigma.numel()
+    if grads is None:
+        grads = torch.empty(MLP_PARAM_COUNT, device=rgb.device, dtype=torch.float32)
+    if workspace is None:
+        workspace = torch.empty(lib.nerf_mlp_bwd_workspace_bytes(n), device=rgb.device, dtype=torch.uint8)
+    _lib.check(lib.nerf_mlp_bwd(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
+                                _p(grads), _p(workspace), _stream()), "nerf_mlp_bwd")
+    return grads
+
+
+class _Decoder(torch.autograd.Function):
+    """Fused Fourier-encode + 8x256 decoder: forward stashes, backward = dgrad chain + wgrad."""
+
+    @staticmethod
+    def forward(ctx, params, packed, rays_o, rays_d, z):
+        n = z.numel() if z is not None else rays_o.shape[0]
+        stash = torch.empty(mlp_stash_bytes(n), device=params.device, dtype=torch.uint8)
+        rgb, sigma = mlp_fwd(packed, rays_o, rays_d, z, stash)
+        ctx.save_for_backward(packed, stash, rgb, sigma)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        packed, stash, rgb, sigma = ctx.saved_tensors
+        grads = mlp_bwd(packed, stash, rgb, sigma, d_rgb.contiguous(), d_sigma.contiguous())
+        return grads, None, None, None, None
+
+
+def decoder(params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, z: Optional[Tensor]):
+    """rgb [n,3], sigma [n]; differentiable w.r.t. the flat parameter vector when it requires grad."""
+    if torch.is_grad_enabled() and params.requires_grad:
+        return _Decoder.apply(params, packed, rays_o, rays_d, z)
+    return mlp_fwd(packed, rays_o, rays_d, z)
+
+
 # --------------------------------------------------------------------------- a14
 def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0,

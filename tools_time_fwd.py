@@ -1,0 +1,32 @@
+"""Quick timing of the fused decoder kernels on one GPU (development aid)."""
+import sys, time, torch
+sys.path.insert(0, ".")
+import project_nerf_amd
+from project_nerf_amd import ops
+from oracle import nerf_oracle as O
+params = O.nerf_init_params(seed=0)
+flat = torch.cat([params[k].reshape(-1) for k, _ in O.nerf_param_shapes()]).cuda()
+packed = ops.mlp_pack(flat)
+def timeit(fn, it=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+for R, S in ((4096, 64), (65536, 128)):
+    o = torch.randn(R, 3, device="cuda"); d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=-1)
+    z = ops.sample_rays(o, d, 2.0, 6.0, S)
+    n = R * S
+    ms = timeit(lambda: ops.mlp_fwd(packed, o, d, z))
+    print(f"R={R} S={S}: fwd {ms:.3f} ms  {n*1186816/ms*1e-9:.1f} TFLOP/s (algorithmic)", flush=True)
+    if n > 1 << 20: continue
+    stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: ops.mlp_fwd(packed, o, d, z, stash))
+    print(f"   fwd+stash: {ms:.3f} ms  {n*1186816/ms*1e-9:.1f} TFLOP/s", flush=True)
+    rgb, sigma = ops.mlp_fwd(packed, o, d, z, stash)
+    d_rgb = torch.randn_like(rgb); d_sigma = torch.randn_like(sigma)
+    grads = torch.empty(ops.MLP_PARAM_COUNT, device="cuda"); ws = torch.empty(ops.mlp_bwd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    ms = timeit(lambda: ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb, d_sigma, grads, ws))
+    print(f"   bwd (dgrad+wgrad): {ms:.3f} ms  {n*(3489024-1186816)/ms*1e-9:.1f} TFLOP/s", flush=True)
