@@ -11,6 +11,7 @@
 // whole span), bias gradients fall out of an all-ones column.  Partial sums are flushed with
 // float atomics (two 128-byte segments per wave instruction).
 // HBM-bound: every stashed byte is read exactly once (about 10.4 KB per sample).
+#include <stdlib.h>
 #include "mlp_chain.h"
 #include "mlp_stash.h"
 
@@ -33,7 +34,8 @@ struct WgradJob {
   int a_nat;            // A is one 16-wide natural block (dsmall)
   int mt_a;             // 32-row tiles of A
   int nt_acc, nt_nat, ones;
-  int split_n;          // single-m-tile job: wave w owns n-tiles {w, w+8}
+  int split_n;          // single natural A block (dsmall): column tiles are split over the waves
+  int kind;             // template instantiation of run_job (see the switch in the kernel)
   int w_off, w_ld;      // dW[o][i] -> grads[w_off + (o - o_row0) * w_ld + col]
   int o_row0, o_valid;
   int acc_valid, acc_col0;
@@ -49,216 +51,197 @@ struct WgradArgs {
   int wave_tiles;
   long long total_cost;
   float* grads;
+  int debug;            // development aid (NERF_WGRAD_DEBUG): bit0 skip MFMA/LDS reads, bit1 skip DMA, bit2 skip flush
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
-// Transposing LDS reads as inline asm: hipcc orders every LDS read it can see behind ALL
-// pending LDS-DMA writes (s_waitcnt vmcnt(0)), which would drain the prefetch ring on every
-// fragment.  The DMA -> read ordering is done by hand instead (counted vmcnt + s_barrier in
-// the stage loop); the reads and their lgkmcnt wait live in one asm statement.
 __device__ __forceinline__ unsigned lds_addr(const char* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
-// N transposing reads + one wait in a single statement (outputs early-clobber)
-__device__ __forceinline__ void tr_read12(const unsigned (&ad)[12], s16x4 (&o)[12]) {
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %13\n\tds_read_b64_tr_b16 %2, %14\n\t"
-      "ds_read_b64_tr_b16 %3, %15\n\tds_read_b64_tr_b16 %4, %16\n\tds_read_b64_tr_b16 %5, %17\n\t"
-      "ds_read_b64_tr_b16 %6, %18\n\tds_read_b64_tr_b16 %7, %19\n\tds_read_b64_tr_b16 %8, %20\n\t"
-      "ds_read_b64_tr_b16 %9, %21\n\tds_read_b64_tr_b16 %10, %22\n\tds_read_b64_tr_b16 %11, %23\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
-        "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11])
-      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
-        "v"(ad[8]), "v"(ad[9]), "v"(ad[10]), "v"(ad[11])
-      : "memory");
+
+// LDS-DMA issued from inline asm: hipcc orders every LDS read it can see behind ALL pending
+// LDS-DMA writes it knows of (s_waitcnt vmcnt(0)), which would drain the prefetch ring at every
+// fragment read.  Hidden in asm, the DMA -> read ordering is ours (counted vmcnt + s_barrier in
+// the stage loop) and the transposing reads stay ordinary builtins the compiler can schedule.
+// M0 carries the wave-uniform LDS destination; it is saved/restored around the instruction.
+__device__ __forceinline__ void dma_1k(const char* gsrc_lane, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void tr_read10(const unsigned (&ad)[10], s16x4 (&o)[10]) {
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %10\n\tds_read_b64_tr_b16 %1, %11\n\tds_read_b64_tr_b16 %2, %12\n\t"
-      "ds_read_b64_tr_b16 %3, %13\n\tds_read_b64_tr_b16 %4, %14\n\tds_read_b64_tr_b16 %5, %15\n\t"
-      "ds_read_b64_tr_b16 %6, %16\n\tds_read_b64_tr_b16 %7, %17\n\tds_read_b64_tr_b16 %8, %18\n\t"
-      "ds_read_b64_tr_b16 %9, %19\n\ts_waitcnt lgkmcnt(0)"
-      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
-        "=&v"(o[8]), "=&v"(o[9])
-      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]),
-        "v"(ad[8]), "v"(ad[9])
-      : "memory");
-}
-__device__ __forceinline__ bf16x8 frag_of(const s16x4& lo, const s16x4& hi) {
+
+// A/B fragment of the contraction over samples: two transposing reads STRIDE bytes apart
+// (samples 4t + 0..3, t = 0, 1) of this lane's feature column
+template <int STRIDE>
+__device__ __forceinline__ bf16x8 tr_frag(const char* p) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(p + STRIDE));
   s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
 
+struct LaneGeo {
+  int lane, wave, fhalf, off_acc, off_nat;
+};
+
+// One job span [wt0, wt1) of one layer.  OWNER mode (SPLIT = false): wave w owns output rows
+// 32w.. x all NT = NT_ACC + NT_NAT + ONES column tiles.  SPLIT mode (single 16-row natural A
+// block, dsmall): wave w owns column tile w (w < NT_ACC) and wave NT_ACC % 8 the ones tile.
+template <int NT_ACC, int NT_NAT, bool ONES, bool SPLIT>
+__device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob job, int wt0, int wt1,
+                                        char* smem, const LaneGeo g) {
+  constexpr int NT = SPLIT ? 2 : NT_ACC + NT_NAT + (ONES ? 1 : 0);
+  const int wave = g.wave, lane = g.lane;
+  const bool active = SPLIT ? (wave <= NT_ACC) : (wave < job.mt_a);
+  f32x16 acc[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+  const int pieces_a = job.a_bytes >> 10, pieces_b = job.b_acc_bytes >> 10, pieces_n = job.b_nat_bytes >> 10;
+  const int pieces = pieces_a + pieces_b + pieces_n;
+  const int per_wave = (pieces + 7) >> 3;    // every wave issues exactly this many (tail duplicates)
+  const unsigned smem_lds = lds_addr(smem);
+  auto issue = [&](int wt) {
+    const unsigned stage = smem_lds + (wt & (kWgStages - 1)) * kWgStageBytes;
+    for (int i = 0; i < per_wave; ++i) {
+      int pc = wave + 8 * i;
+      pc = pc < pieces ? pc : pieces - 1;
+      const char* src;
+      unsigned dst;
+      if (pc < pieces_a) {
+        src = job.a + (size_t)wt * job.a_bytes + pc * 1024;
+        dst = stage + pc * 1024;
+      } else if (pc < pieces_a + pieces_b) {
+        const int o = pc - pieces_a;
+        src = job.b_acc + (size_t)wt * job.b_acc_bytes + o * 1024;
+        dst = stage + kWgStageA + o * 1024;
+      } else {
+        const int o = pc - pieces_a - pieces_b;
+        src = job.b_nat + (size_t)wt * job.b_nat_bytes + o * 1024;
+        dst = stage + kWgStageA + kWgStageB + o * 1024;
+      }
+      dma_1k(src + lane * 16, __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+  auto wait_in_flight = [&](int stages) {   // all but `stages` newest stages of this wave have landed
+    const int outstanding = stages * per_wave;
+    if (outstanding >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (outstanding >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (outstanding >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (outstanding >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (outstanding >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (outstanding >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  __builtin_amdgcn_s_barrier();   // previous span's readers are done with the ring
+  if (wt0 + 0 < wt1) issue(wt0 + 0);
+  if (wt0 + 1 < wt1) issue(wt0 + 1);
+  if (wt0 + 2 < wt1) issue(wt0 + 2);
+  for (int wt = wt0; wt < wt1; ++wt) {
+    wait_in_flight((wt + 1 < wt1) + (wt + 2 < wt1));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wt + 3 < wt1 && !(args.debug & 2)) issue(wt + 3);
+    if (!active || (args.debug & 1)) continue;
+    const char* stage = smem + (wt & (kWgStages - 1)) * kWgStageBytes;
+    const char* pa = SPLIT ? stage + g.off_nat - 1024 * g.fhalf : stage + wave * 2048 + g.off_acc;
+    const char* pb = stage + kWgStageA + g.off_acc + (SPLIT ? (wave < NT_ACC ? wave : 0) * 2048 : 0);
+    const char* pn = stage + kWgStageA + kWgStageB + g.off_nat;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af = SPLIT ? tr_frag<128>(pa + 512 * s) : tr_frag<256>(pa + 1024 * s);
+      if (SPLIT && g.fhalf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[e] = (__bf16)0.0f;
+      }
+      if constexpr (SPLIT) {
+        if (wave < NT_ACC) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tr_frag<256>(pb + 1024 * s), acc[0], 0, 0, 0);
+        if (wave == NT_ACC % 8) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, acc[1], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NT_ACC; ++k)
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tr_frag<256>(pb + k * 2048 + 1024 * s), acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NT_NAT; ++k)
+          acc[NT_ACC + k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tr_frag<128>(pn + k * 2048 + 512 * s), acc[NT_ACC + k], 0, 0, 0);
+        if constexpr (ONES)
+          acc[NT_ACC + NT_NAT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, acc[NT_ACC + NT_NAT], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- flush: row o = 32*m_tile + (r&3) + 8*(r>>2) + 4*hrow, column = 32*nt + (lane&31) ----
+  if (!active || (args.debug & 4)) return;
+  const int c32 = lane & 31, hrow = lane >> 5;
+  const int m_tile = SPLIT ? 0 : wave;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    int col = -1, bias_here = 0;
+    bool use = true;
+    if constexpr (SPLIT) {
+      if (k == 0) { use = wave < NT_ACC; const int i = wave * 32 + c32; if (i < job.acc_valid) col = job.acc_col0 + i; }
+      else { use = wave == NT_ACC % 8; bias_here = (c32 == 0); }
+    } else {
+      if (k < NT_ACC) { const int i = k * 32 + c32; if (i < job.acc_valid) col = job.acc_col0 + i; }
+      else if (k < NT_ACC + NT_NAT) {
+        const int i = (k - NT_ACC) * 32 + c32;
+        if (i < job.nat_valid) col = job.nat_col0 + i;
+        bias_here = (i == job.bias_nat_col);
+      } else bias_here = (c32 == 0);
+    }
+    if (!use) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 32 * m_tile + (r & 3) + 8 * (r >> 2) + 4 * hrow - job.o_row0;
+      if (o >= 0 && o < job.o_valid) {
+        if (col >= 0) atomicAdd(args.grads + job.w_off + o * job.w_ld + col, acc[k][r]);
+        if (bias_here) atomicAdd(args.grads + job.bias_off + o, acc[k][r]);
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // transposing-read lane geometry (see header comment of mlp_chain.h stash_block)
-  const int grp = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-  const int hh = grp >> 1, fhalf = grp & 1;
-  const int off_acc = 64 * (8 * hh + q) + 32 * (p & 1) + 16 * fhalf + 8 * (p >> 1);   // + 1024*s, block*2048
-  const int off_nat = 32 * (8 * hh + q) + 16 * (p >> 1) + 8 * (p & 1) + 1024 * fhalf;  // + 512*s, pair*2048
+  LaneGeo g;
+  g.lane = threadIdx.x & 63;
+  g.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // transposing-read lane geometry: 16-lane group grp covers features 16*fhalf.. of k-half hh;
+  // lane 4q+p supplies sample (8hh + q) [+4 for the second read], features 4p..4p+3
+  const int grp = g.lane >> 4, i16 = g.lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int hh = grp >> 1;
+  g.fhalf = grp & 1;
+  g.off_acc = 64 * (8 * hh + q) + 32 * (p & 1) + 16 * g.fhalf + 8 * (p >> 1);    // + 1024*s + 2048*block
+  g.off_nat = 32 * (8 * hh + q) + 16 * (p >> 1) + 8 * (p & 1) + 1024 * g.fhalf;  // + 512*s + 2048*pair
 
   // this workgroup's span of the cost line
   const long long lo = args.total_cost * blockIdx.x / gridDim.x;
   const long long hi = args.total_cost * (blockIdx.x + 1) / gridDim.x;
-
   for (int j = 0; j < args.n_jobs; ++j) {
-    const WgradJob& job = args.jobs[j];
+    const WgradJob job = args.jobs[j];   // by value: fields live in SGPRs, not re-read per use
     const long long j0 = job.cost0, j1 = job.cost0 + (long long)job.cost * args.wave_tiles;
     if (hi <= j0 || lo >= j1) continue;
     // wave tile t belongs to the workgroup whose span contains its first cost unit
     const long long a0 = lo > j0 ? lo - j0 : 0, a1 = (hi < j1 ? hi : j1) - j0;
     const int wt0 = (int)((a0 + job.cost - 1) / job.cost), wt1 = (int)((a1 + job.cost - 1) / job.cost);
     if (wt0 >= wt1) continue;
-
-    const int nt_total = job.nt_acc + job.nt_nat + job.ones;
-    int m_tile, n_first, n_step, n_count;
-    if (job.split_n) {
-      m_tile = 0; n_first = wave; n_step = 8; n_count = wave < nt_total ? (nt_total - wave + 7) / 8 : 0;
-    } else {
-      m_tile = wave; n_first = 0; n_step = 1; n_count = wave < job.mt_a ? nt_total : 0;
-    }
-
-    f32x16 acc[kMaxTiles];
-#pragma unroll
-    for (int k = 0; k < kMaxTiles; ++k)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-
-    const int pieces_a = job.a_bytes >> 10, pieces_b = job.b_acc_bytes >> 10, pieces_n = job.b_nat_bytes >> 10;
-    const int pieces = pieces_a + pieces_b + pieces_n;
-    const int per_wave = (pieces + 7) >> 3;    // every wave issues exactly this many (tail duplicates)
-    auto issue = [&](int wt) {
-      char* stage = smem + (wt & (kWgStages - 1)) * kWgStageBytes;
-      for (int i = 0; i < per_wave; ++i) {
-        int pc = wave + 8 * i;
-        pc = pc < pieces ? pc : pieces - 1;
-        const char* src;
-        char* dst;
-        if (pc < pieces_a) {
-          src = job.a + (size_t)wt * job.a_bytes + pc * 1024;
-          dst = stage + pc * 1024;
-        } else if (pc < pieces_a + pieces_b) {
-          const int o = pc - pieces_a;
-          src = job.b_acc + (size_t)wt * job.b_acc_bytes + o * 1024;
-          dst = stage + kWgStageA + o * 1024;
-        } else {
-          const int o = pc - pieces_a - pieces_b;
-          src = job.b_nat + (size_t)wt * job.b_nat_bytes + o * 1024;
-          dst = stage + kWgStageA + kWgStageB + o * 1024;
-        }
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + lane * 16), (lptr_t)dst, 16, 0, 0);
-      }
-    };
-    auto wait_in_flight = [&](int stages) {   // all but `stages` newest stages of this wave have landed
-      const int outstanding = stages * per_wave;
-      if (outstanding >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (outstanding >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (outstanding >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (outstanding >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (outstanding >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (outstanding >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-    __builtin_amdgcn_s_barrier();   // previous job's readers are done with the ring
-    if (wt0 + 0 < wt1) issue(wt0 + 0);
-    if (wt0 + 1 < wt1) issue(wt0 + 1);
-    if (wt0 + 2 < wt1) issue(wt0 + 2);
-    for (int wt = wt0; wt < wt1; ++wt) {
-      const int ahead = (wt + 1 < wt1) + (wt + 2 < wt1);
-      wait_in_flight(ahead);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (wt + 3 < wt1) issue(wt + 3);
-      const char* stage = smem + (wt & (kWgStages - 1)) * kWgStageBytes;
-      if (n_count > 0) {
-        const unsigned st = lds_addr(stage);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          // operand addresses: pair (first read, second read = +4 samples) per fragment
-          auto tile_addr = [&](int k, unsigned& a0, unsigned& a1) {
-            const int nt = n_first + k * n_step;
-            if (k < n_count && nt < job.nt_acc) {
-              a0 = st + kWgStageA + nt * 2048 + off_acc + 1024 * s; a1 = a0 + 256;
-            } else if (k < n_count && nt < job.nt_acc + job.nt_nat) {
-              a0 = st + kWgStageA + kWgStageB + (nt - job.nt_acc) * 2048 + off_nat + 512 * s; a1 = a0 + 128;
-            } else {
-              a0 = st; a1 = st;     // ones tile / unused slot: any valid address
-            }
-          };
-          unsigned ad0[12];
-          s16x4 r0[12];
-          if (job.a_nat) { ad0[0] = st + off_nat - 1024 * fhalf + 512 * s; ad0[1] = ad0[0] + 128; }
-          else { ad0[0] = st + m_tile * 2048 + off_acc + 1024 * s; ad0[1] = ad0[0] + 256; }
-#pragma unroll
-          for (int k = 0; k < 5; ++k) tile_addr(k, ad0[2 + 2 * k], ad0[3 + 2 * k]);
-          tr_read12(ad0, r0);
-          bf16x8 af = frag_of(r0[0], r0[1]);
-          if (job.a_nat && fhalf) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) af[e] = (__bf16)0.0f;
-          }
-          bf16x8 ones;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-#pragma unroll
-          for (int k = 0; k < 5; ++k) {
-            if (k < n_count) {
-              const int nt = n_first + k * n_step;
-              const bf16x8 bfrag = nt < job.nt_acc + job.nt_nat ? frag_of(r0[2 + 2 * k], r0[3 + 2 * k]) : ones;
-              acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc[k], 0, 0, 0);
-            }
-          }
-          if (n_count > 5) {
-            unsigned ad1[10];
-            s16x4 r1[10];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) tile_addr(5 + k, ad1[2 * k], ad1[2 * k + 1]);
-            tr_read10(ad1, r1);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-              if (5 + k < n_count) {
-                const int nt = n_first + (5 + k) * n_step;
-                const bf16x8 bfrag = nt < job.nt_acc + job.nt_nat ? frag_of(r1[2 * k], r1[2 * k + 1]) : ones;
-                acc[5 + k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag, acc[5 + k], 0, 0, 0);
-              }
-            }
-          }
-        }
-      }
-    }
-
-    // ---- flush: row o = 32*m_tile + (r&3) + 8*(r>>2) + 4*hh, column = 32*nt + (lane&31) ----
-    const int c32 = lane & 31, hrow = lane >> 5;
-#pragma unroll
-    for (int k = 0; k < kMaxTiles; ++k) {
-      if (k < n_count) {
-        const int nt = n_first + k * n_step;
-        int col = -1, bias_here = 0;
-        if (nt < job.nt_acc) {
-          const int i = nt * 32 + c32;
-          if (i < job.acc_valid) col = job.acc_col0 + i;
-        } else if (nt < job.nt_acc + job.nt_nat) {
-          const int i = (nt - job.nt_acc) * 32 + c32;
-          if (i < job.nat_valid) col = job.nat_col0 + i;
-          bias_here = (i == job.bias_nat_col);
-        } else {
-          bias_here = (c32 == 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = 32 * m_tile + (r & 3) + 8 * (r >> 2) + 4 * hrow - job.o_row0;
-          if (o >= 0 && o < job.o_valid) {
-            if (col >= 0) atomicAdd(args.grads + job.w_off + o * job.w_ld + col, acc[k][r]);
-            if (bias_here) atomicAdd(args.grads + job.bias_off + o, acc[k][r]);
-          }
-        }
-      }
+    switch (job.kind) {
+      case 0: run_job<8, 0, true, false>(args, job, wt0, wt1, smem, g); break;    // 256x256 (+bias)
+      case 1: run_job<8, 2, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.4
+      case 2: run_job<0, 2, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.0
+      case 3: run_job<8, 1, false, false>(args, job, wt0, wt1, smem, g); break;   // view_layer
+      case 4: run_job<8, 0, true, true>(args, job, wt0, wt1, smem, g); break;     // sigma_layer
+      default: run_job<4, 0, true, true>(args, job, wt0, wt1, smem, g); break;    // rgb_layer
     }
   }
 }
@@ -286,7 +269,7 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
     j.a = dh(0); j.a_bytes = 16384; j.mt_a = 8;
     j.b_nat = xenc; j.b_nat_bytes = 4096; j.nt_nat = 2;
     j.w_off = kW0; j.w_ld = 63; j.o_valid = 256; j.nat_valid = 63; j.nat_col0 = 0;
-    j.bias_off = kB0; j.bias_nat_col = 63;
+    j.bias_off = kB0; j.bias_nat_col = 63; j.kind = 2;
     add(j);
   }
   for (int l = 1; l < 8; ++l) {
@@ -297,8 +280,9 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
     j.bias_off = pts_bias_off(l);
     if (l == 4) {
       j.b_nat = xenc; j.b_nat_bytes = 4096; j.nt_nat = 2; j.nat_valid = 63; j.nat_col0 = 256; j.bias_nat_col = 63;
+      j.kind = 1;
     } else {
-      j.ones = 1; j.bias_nat_col = -1;
+      j.ones = 1; j.bias_nat_col = -1; j.kind = 0;
     }
     add(j);
   }
@@ -306,14 +290,14 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
     WgradJob j{};
     j.a = work + bl.dfeat; j.a_bytes = 16384; j.mt_a = 8;
     j.b_acc = st_h(7); j.b_acc_bytes = 16384; j.nt_acc = 8; j.ones = 1; j.bias_nat_col = -1;
-    j.w_off = kWFeat; j.w_ld = 256; j.o_valid = 256; j.acc_valid = 256; j.bias_off = kBFeat;
+    j.w_off = kWFeat; j.w_ld = 256; j.o_valid = 256; j.acc_valid = 256; j.bias_off = kBFeat; j.kind = 0;
     add(j);
   }
   {  // sigma_layer: dsmall[:,3] x h7
     WgradJob j{};
     j.a = work + bl.dsmall; j.a_bytes = 1024; j.a_nat = 1; j.mt_a = 1; j.split_n = 1;
     j.b_acc = st_h(7); j.b_acc_bytes = 16384; j.nt_acc = 8; j.ones = 1; j.bias_nat_col = -1;
-    j.w_off = kWSigma; j.w_ld = 256; j.o_row0 = 3; j.o_valid = 1; j.acc_valid = 256; j.bias_off = kBSigma;
+    j.w_off = kWSigma; j.w_ld = 256; j.o_row0 = 3; j.o_valid = 1; j.acc_valid = 256; j.bias_off = kBSigma; j.kind = 4;
     add(j);
   }
   {  // view_layer: dHv x [feat | denc] (bias from the direction code's constant-one column 27)
@@ -321,14 +305,14 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
     j.a = work + bl.dhv; j.a_bytes = 8192; j.mt_a = 4;
     j.b_acc = stash + sl.feat; j.b_acc_bytes = 16384; j.nt_acc = 8;
     j.b_nat = denc; j.b_nat_bytes = 2048; j.nt_nat = 1; j.nat_valid = 27; j.nat_col0 = 256; j.bias_nat_col = 27;
-    j.w_off = kWView; j.w_ld = 283; j.o_valid = 128; j.acc_valid = 256; j.bias_off = kBView;
+    j.w_off = kWView; j.w_ld = 283; j.o_valid = 128; j.acc_valid = 256; j.bias_off = kBView; j.kind = 3;
     add(j);
   }
   {  // rgb_layer: dsmall[:,0:3] x hv
     WgradJob j{};
     j.a = work + bl.dsmall; j.a_bytes = 1024; j.a_nat = 1; j.mt_a = 1; j.split_n = 1;
     j.b_acc = stash + sl.hv; j.b_acc_bytes = 8192; j.nt_acc = 4; j.ones = 1; j.bias_nat_col = -1;
-    j.w_off = kWRgb; j.w_ld = 128; j.o_row0 = 0; j.o_valid = 3; j.acc_valid = 128; j.bias_off = kBRgb;
+    j.w_off = kWRgb; j.w_ld = 128; j.o_row0 = 0; j.o_valid = 3; j.acc_valid = 128; j.bias_off = kBRgb; j.kind = 5;
     add(j);
   }
   args.n_jobs = nj;
@@ -340,6 +324,7 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
   }
   args.total_cost = c;
   args.grads = grads;
+  if (const char* dbg = getenv("NERF_WGRAD_DEBUG")) args.debug = atoi(dbg);
 
   static int n_cu = 0;
   if (n_cu == 0) {

@@ -1,0 +1,26 @@
+import sys, os, torch
+sys.path.insert(0, ".")
+import project_nerf_amd
+from project_nerf_amd import ops
+from project_nerf_amd.engine import default_init
+R, S = 4096, 64; n = R * S
+packed = ops.mlp_pack(default_init(0).cuda())
+o = torch.randn(R, 3, device="cuda"); d = torch.nn.functional.normalize(torch.randn(R, 3, device="cuda"), dim=-1)
+z = ops.sample_rays(o, d, 2.0, 6.0, S)
+stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
+rgb, sigma = ops.mlp_fwd(packed, o, d, z, stash)
+ws = torch.empty(ops.mlp_bwd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+grads = torch.empty(ops.MLP_PARAM_COUNT, device="cuda")
+lib = ops._lib.load(); st = torch.cuda.current_stream().cuda_stream
+lib.nerf_mlp_bwd_dgrad(packed.data_ptr(), stash.data_ptr(), rgb.data_ptr(), sigma.data_ptr(), torch.randn_like(rgb).data_ptr(), torch.randn_like(sigma).data_ptr(), n, ws.data_ptr(), st)
+def t(it=20):
+    for _ in range(3): lib.nerf_mlp_bwd_wgrad(stash.data_ptr(), ws.data_ptr(), n, grads.data_ptr(), st)
+    torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): lib.nerf_mlp_bwd_wgrad(stash.data_ptr(), ws.data_ptr(), n, grads.data_ptr(), st)
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
+gb = (stash.numel() + ws.numel()) * 1e-9
+for dbg in (0, 1, 2, 4, 5, 3):
+    os.environ["NERF_WGRAD_DEBUG"] = str(dbg)
+    ms = t()
+    print(f"debug={dbg}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s", flush=True)
