@@ -168,14 +168,19 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
         if (wave < NT_ACC) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tr_frag<256>(pb + 1024 * s), acc[0], 0, 0, 0);
         if (wave == NT_ACC % 8) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, acc[1], 0, 0, 0);
       } else {
+        // all fragment reads of the k-step first, then the MFMAs: hipcc otherwise recycles one
+        // fragment register (read -> wait -> mfma), exposing the LDS latency per MFMA
+        bf16x8 bf[NT_ACC + NT_NAT + 1];
 #pragma unroll
-        for (int k = 0; k < NT_ACC; ++k)
-          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tr_frag<256>(pb + k * 2048 + 1024 * s), acc[k], 0, 0, 0);
+        for (int k = 0; k < NT_ACC; ++k) bf[k] = tr_frag<256>(pb + k * 2048 + 1024 * s);
 #pragma unroll
-        for (int k = 0; k < NT_NAT; ++k)
-          acc[NT_ACC + k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tr_frag<128>(pn + k * 2048 + 512 * s), acc[NT_ACC + k], 0, 0, 0);
-        if constexpr (ONES)
-          acc[NT_ACC + NT_NAT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, acc[NT_ACC + NT_NAT], 0, 0, 0);
+        for (int k = 0; k < NT_NAT; ++k) bf[NT_ACC + k] = tr_frag<128>(pn + k * 2048 + 512 * s);
+        bf[NT_ACC + NT_NAT] = ones;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[k], acc[k], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (1 + NT_ACC + NT_NAT), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
