@@ -59,6 +59,19 @@ int nerf_sample_rays(const float* rays_o, const float* rays_d, const float* u,
 int nerf_active_mask(const float* pts, int64_t n, const uint8_t* binary_grid, int resolution,
                      float bound, uint8_t* mask_out, int64_t* idx_out, nerf_stream_t stream);
 
+/* ---- a12: occupancy-grid refresh -----------------------------------------------
+ * replaces the lattice construction and the grid / binary_grid update of
+ * DensityGrid.update (src/renderer.py:49-54, 118-132); the sigma query in between goes through
+ * the field kernels.
+ *   nerf_grid_lattice: pts_out [res^3,3], nodes of linspace(-bound, bound, res), 'ij' order.
+ *   nerf_grid_update : sigma [n_cells] freshly queried; grid [n_cells] in/out (overwritten, or
+ *                      max(grid*decay, sigma) when dynamic != 0); binary_grid [n_cells] bytes =
+ *                      grid > threshold; *active_count (device u64) = number of set cells. */
+int nerf_grid_lattice(float bound, int resolution, float* pts_out, nerf_stream_t stream);
+int nerf_grid_update(const float* sigma, float* grid, uint8_t* binary_grid, int64_t n_cells,
+                     float decay, int dynamic, float threshold, unsigned long long* active_count,
+                     nerf_stream_t stream);
+
 /* ---- a5: Fourier features ---------------------------------------------------
  * replaces FourierRepresentation.forward (src/embeddings.py:22-32).
  *   x [N,dim] -> out [N, dim + 2*dim*n_freq] laid out [x | sin f0 | cos f0 | sin f1 | ...]. */

@@ -68,6 +68,30 @@ def active_mask(pts: Tensor, binary_grid: Tensor, bound: float, want_index: bool
     return (mask, idx) if want_index else mask
 
 
+# --------------------------------------------------------------------------- a12
+def grid_lattice(bound: float, resolution: int, device) -> Tensor:
+    lib = _lib.load()
+    pts = torch.empty(resolution ** 3, 3, device=device, dtype=torch.float32)
+    if pts.device.type != "cuda":
+        raise _lib.NerfHipError("grid_lattice: the hot path only runs on a HIP device")
+    _lib.check(lib.nerf_grid_lattice(float(bound), resolution, _p(pts), _stream()), "nerf_grid_lattice")
+    return pts
+
+
+def grid_threshold(sigma_grid: Tensor, threshold: float, prev: Optional[Tensor] = None, decay: float = 1.0):
+    """binary = grid > threshold (+ running max against ``prev`` for dynamic fields); returns
+    (binary_grid bool, active ratio as a Python float -- the one host sync the reference also has)."""
+    lib = _lib.load()
+    cur = _dev(sigma_grid, "sigma_grid")
+    grid = cur if prev is None else _dev(prev, "prev")
+    binary = torch.empty(cur.shape, device=cur.device, dtype=torch.bool)
+    count = torch.zeros(1, device=cur.device, dtype=torch.int64)
+    _lib.check(lib.nerf_grid_update(_p(cur), _p(grid), _p(binary), cur.numel(), float(decay),
+                                    0 if prev is None else 1, float(threshold), _p(count), _stream()),
+               "nerf_grid_update")
+    return binary, float(count.item()) / cur.numel()
+
+
 # --------------------------------------------------------------------------- a5
 def fourier_encode(x: Tensor, n_freq: int) -> Tensor:
     lib = _lib.load()

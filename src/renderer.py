@@ -1,0 +1,3 @@
+"""Drop-in module path of the reference (src/renderer.py): re-exports the MI355X implementation."""
+import project_nerf_amd  # noqa: F401  (import shim for the hyphenated package directory)
+from project_nerf_amd.renderer import *  # noqa: F401,F403

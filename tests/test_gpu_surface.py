@@ -1,0 +1,159 @@
+"""The reference's module surface (src/*) on the MI355X kernels: checkpoint keys, render_rays /
+render_image / DensityGrid against the reference's golden outputs, a short training run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import ROOT, golden
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def field():
+    assert torch.cuda.is_available()
+    from src.core import NeuralField
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2.yaml.example")))
+    model = NeuralField(cfg).cuda()
+    g = golden("g4_decoder")
+    sd = model.state_dict()
+    for k, v in g.items():
+        if k.startswith("w:"):
+            assert "decoder." + k[2:] in sd, k          # reference checkpoint keys load unchanged
+            sd["decoder." + k[2:]] = T(v)
+    model.load_state_dict(sd)
+    return model
+
+
+def test_state_dict_keys_match_reference(field):
+    keys = [k for k in field.state_dict() if k.startswith("decoder.")]
+    assert keys == ["decoder." + k for k, _ in O.nerf_param_shapes()]
+    assert "representation.freq_bands" in field.state_dict() and "dir_representation.freq_bands" in field.state_dict()
+
+
+def test_neural_field_forward_and_errors(field):
+    g = golden("g4_decoder")
+    with torch.no_grad():
+        rgb, sigma = field(T(g["pts"]).cuda(), T(g["dirs"]).cuda())
+    assert rgb.shape == (512, 3) and sigma.shape == (512, 1)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb"], atol=2e-2)
+    with pytest.raises(ValueError):
+        field(T(g["pts"]).cuda())
+
+
+def test_render_rays_and_image_vs_reference_golden(field):
+    from src.renderer import render_image, render_rays
+    g = golden("g6_render")
+    o, d = T(g["rays_o"]).cuda(), T(g["rays_d"]).cuda()
+    with torch.no_grad():
+        c, dep, acc = render_rays(field, o, d, 2.0, 6.0, 64, False)
+    # stated tolerance for the bf16 decoder vs the reference's fp32 renderer
+    np.testing.assert_allclose(c.cpu().numpy(), g["rgb_plain"], atol=1e-2)
+    np.testing.assert_allclose(dep.cpu().numpy(), g["depth_plain"], rtol=2e-2)
+    np.testing.assert_allclose(acc.cpu().numpy(), g["acc_plain"], atol=1e-2)
+    gm = golden("g6_render_masked")
+    with torch.no_grad():
+        img = render_image(field, o[:64].reshape(8, 8, 3), d[:64].reshape(8, 8, 3), 2.0, 6.0, 64, 24, True)
+    np.testing.assert_allclose(img.cpu().numpy(), gm["image8x8"], atol=1e-2)
+
+
+def test_render_rays_with_density_grid_vs_reference_golden(field):
+    from src.renderer import DensityGrid, render_rays
+    gm = golden("g6_render_masked")
+    grid = DensityGrid(resolution=128, bound=1.5, threshold=0.01).cuda()
+    ax = torch.linspace(-1.5, 1.5, 128)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    grid.binary_grid = ((gx ** 2 + gy ** 2 + gz ** 2) < float(gm["radius"]) ** 2).cuda()
+    o, d = T(gm["rays_o"]).cuda(), T(gm["rays_d"]).cuda()
+    with torch.no_grad():
+        c, dep, acc = render_rays(field, o, d, 2.0, 6.0, 64, False, density_grid=grid, bg_color=T(gm["bg"]).cuda())
+    np.testing.assert_allclose(c.cpu().numpy(), gm["rgb"], atol=1e-2)
+    np.testing.assert_allclose(acc.cpu().numpy(), gm["acc"], atol=1e-2)
+
+
+class _Blob(torch.nn.Module):
+    mode = "part2_nerf"
+
+    def forward(self, x, d):
+        c = torch.tensor([0.2, -0.1, 0.3], device=x.device)
+        return torch.zeros(x.shape[0], 3, device=x.device), 5.0 * torch.exp(-((x - c) ** 2).sum(-1, keepdim=True) / 0.18)
+
+
+@pytest.mark.parametrize("res", [32, 64])
+def test_density_grid_update_vs_reference_golden(res):
+    from src.renderer import DensityGrid
+    g = golden(f"g7_grid_static_res{res}")
+    grid = DensityGrid(resolution=res, bound=1.5, threshold=0.12).cuda()
+    ratio = grid.update(_Blob(), device="cuda")
+    np.testing.assert_allclose(grid.grid.cpu().numpy(), g["grid"], rtol=1e-4, atol=1e-6)
+    flips = (grid.binary_grid.cpu().numpy() != g["binary"]).sum()
+    assert flips <= 2                                   # cells within 1 ulp of the threshold
+    assert abs(ratio - float(g["ratio"])) < 3.0 / res ** 3
+    table = golden("g7_should_update")["table"]
+    assert all(grid.should_update(int(s), int(i), int(w)) == bool(want) for s, i, w, want in table)
+
+
+def test_torch_optimizer_trains_through_module_surface(field):
+    """Drop-in: nn.Parameters + torch.optim.Adam + render_rays + MSE, as in the reference loop."""
+    import copy
+    from src.renderer import render_rays
+    model = copy.deepcopy(field)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    g = golden("g6_render")
+    o, d, tgt = T(g["rays_o"]).cuda(), T(g["rays_d"]).cuda(), T(g["target"]).cuda()
+    losses = []
+    for _ in range(12):
+        pred, _, _ = render_rays(model, o, d, 2.0, 6.0, 64, True)
+        loss = torch.nn.functional.mse_loss(pred, tgt)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    assert all(p.grad is not None for p in model.parameters())
+
+
+def test_engine_convergence_on_synthetic_scene(tmp_path):
+    """Flat-parameter fast path: PSNR on an analytic scene rises within a few hundred steps."""
+    from src.dataset import BlenderDataset, write_synthetic_scene
+    from project_nerf_amd.engine import VanillaNerfEngine
+    root = write_synthetic_scene(str(tmp_path / "scene"), n_train=12, n_test=2, size=64)
+    ds = BlenderDataset(root, "train", 1, True, 1.0).to("cuda")
+    eng = VanillaNerfEngine(seed=0, lr=5e-4)
+    torch.manual_seed(0)
+    first = last = None
+    for step in range(500):
+        o, d, rgba = ds.sample_random_rays(4096, "cuda")
+        target = rgba[:, :3] * rgba[:, 3:4] + (1 - rgba[:, 3:4])
+        loss = eng.train_step(o, d, target, 64)
+        if step == 0:
+            first = loss.item()
+    last = loss.item()
+    assert last < 0.5 * first, (first, last)
+    o, d, tgt = BlenderDataset(root, "test", 1, True, 1.0).get_image_rays(0, "cuda")
+    img = eng.render_image(o, d, 64, chunk=4096)
+    psnr = -10 * np.log10(float(((img - tgt) ** 2).mean()))
+    assert psnr > 17.0, psnr      # ~19-22 dB after 500 steps; 25+ dB after 1000
+
+
+def test_run_py_cli_trains_and_evaluates(tmp_path):
+    from src.dataset import write_synthetic_scene
+    root = write_synthetic_scene(str(tmp_path / "scene"), n_train=6, n_test=1, size=32)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2.yaml.example")))
+    cfg.update(train_iters=20, batch_size=512, log_every=10, save_every=0, downscale=1, log_dir=str(tmp_path / "out"))
+    cfg_path = tmp_path / "part2.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run.py"), "--config", str(cfg_path), "--data_dir", root,
+                        "--render_n", "1"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Test PSNR" in r.stdout
+    ckpt = torch.load(tmp_path / "out" / "checkpoints" / "model_final.pth", map_location="cpu")
+    assert set(ckpt) == {"model_state_dict", "config"}
+    assert "decoder.pts_layers.4.weight" in ckpt["model_state_dict"]
