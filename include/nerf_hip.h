@@ -149,6 +149,47 @@ int nerf_mlp_bwd_dgrad(const void* packed, const void* stash, const float* rgb, 
 int nerf_mlp_bwd_wgrad(const void* stash, const void* workspace, int64_t n, float* grads_f32,
                        nerf_stream_t stream);
 
+/* ---- a8: multiresolution hash grid ------------------------------------------------
+ * replaces tinycudann's Encoding("HashGrid") behind HashRepresentation.forward
+ * (src/embeddings.py:60-89), incl. its (x + bound) / (2 bound) clamp pre-step.  The library is
+ * third party, unpinned and absent: the level table is this build's definition (see
+ * oracle/nerf_oracle.py::hash_grid_levels) and is passed in by the host, one entry per level:
+ *   scale (fp32), res, size (entries), offset (first entry), dense (1: x + y*res + z*res^2,
+ *   0: xor-prime spatial hash), all HOST arrays of n_levels (<= 16) elements.
+ * table: fp32 [entries, 2] (the flat `encoding.params` vector).
+ * fwd: pts [n,3] world coordinates -> out_f32 [n, 2*n_levels] and/or out_nat_bf16, the bf16
+ *      operand image nerf_imlp_fwd consumes (n rounded up to 128 rows); idx_out [n, n_levels, 8]
+ *      absolute entry indices or NULL.
+ * bwd: d_feat [n, 2*n_levels] -> d_table [entries, 2] += trilinear scatter (float atomics;
+ *      the caller zeroes d_table). */
+int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* table, int n_levels,
+                         const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                         const unsigned* offset_host, const unsigned* dense_host, float bound,
+                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream);
+int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                         const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                         const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                         nerf_stream_t stream);
+
+/* ---- a7: Instant decoder (two bias-free tiny MLPs, bf16 MFMA) -----------------------
+ * replaces the two tinycudann FullyFusedMLP networks of InstantNeRFDecoder
+ * (src/decoders.py:111-134, forward 136-162).  Parameter vector (fp32, [out,in] row-major):
+ *   sigma_net W1 [64,32] | W2 [16,64] | color_net W1 [64,48] | W2 [64,64] | W3 [16,64] = 11264
+ * (input 16 geometry channels + 27 direction-code channels, padded to 48; 3 rgb rows of 16).
+ * workspace (nerf_imlp_workspace_bytes(n), 256-B aligned) starts with the hash operand image
+ * (offset nerf_imlp_hash_operand_offset(n) = 0) and holds the training stash.
+ * fwd: dirs [n,3] unit view directions -> rgb [n,3], sigma [n] = softplus(h0 - 5).
+ * bwd: grads_f32 [11264] OVERWRITTEN; d_feat [n,32] = gradient w.r.t. the hash features. */
+size_t nerf_imlp_packed_bytes(void);
+size_t nerf_imlp_workspace_bytes(int64_t n);
+size_t nerf_imlp_hash_operand_offset(int64_t n);
+int nerf_imlp_pack(const float* params_f32, void* packed, nerf_stream_t stream);
+int nerf_imlp_fwd(const void* packed, void* workspace, const float* dirs, int64_t n, float* rgb,
+                  float* sigma, int train, nerf_stream_t stream);
+int nerf_imlp_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma,
+                  const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
+                  float* d_feat, nerf_stream_t stream);
+
 /* ---- a14: optimiser ---------------------------------------------------------
  * replaces torch.optim.Adam / AdamW .step() (run.py:307,338; run.py:546,629) for
  * one flat fp32 parameter vector.  step counts from 1.  weight_decay is the

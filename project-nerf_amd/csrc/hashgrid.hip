@@ -1,0 +1,171 @@
+// Multiresolution hash-grid encoding, forward gather and backward scatter-add.
+// Replaces tinycudann's HashGrid encoding behind HashRepresentation (reference
+// src/embeddings.py:39-93).  The third-party source is absent, so this follows the published
+// Instant-NGP algorithm (Mueller et al. 2022, section 3) with the level table defined in
+// oracle/nerf_oracle.py::hash_grid_levels -- PARITY UNPINNED against tinycudann itself; bit-exact
+// indices and fp32-accurate features against the build's own CPU restatement.
+//
+// One thread per (point, level): normalise + clamp the point, 8 corner indices (dense below the
+// hash-map budget, xor-prime hash above), trilinear blend of F = 2 features.  Gather-bound:
+// 16 levels x 8 corners x 8 B (fp32 table) per point; the 52 MB table lives in the 256 MB
+// Infinity Cache.  Backward: 16 float atomics per (point, level).
+#include "common.h"
+
+namespace nerf {
+
+constexpr int kMaxLevels = 16;
+
+struct HashLevels {
+  float scale[kMaxLevels];
+  unsigned res[kMaxLevels];
+  unsigned size[kMaxLevels];
+  unsigned offset[kMaxLevels];
+  unsigned dense[kMaxLevels];
+  int n_levels;
+  float bound;
+};
+
+struct Corner {
+  unsigned idx[8];
+  float w[8];
+};
+
+__device__ __forceinline__ Corner corners_of(const HashLevels& L, int lvl, float px, float py, float pz) {
+  // HashRepresentation.forward: (x + bound) / (2 bound), clamp to [0, 1]  (embeddings.py:86-87)
+  const float two_b = 2.0f * L.bound;
+  float x01[3] = {add_rn(px, L.bound) / two_b, add_rn(py, L.bound) / two_b, add_rn(pz, L.bound) / two_b};
+  unsigned cell[3];
+  float frac[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float c = fminf(fmaxf(x01[a], 0.0f), 1.0f);
+    const float pos = add_rn(mul_rn(c, L.scale[lvl]), 0.5f);
+    const float fl = floorf(pos);
+    frac[a] = sub_rn(pos, fl);
+    cell[a] = (unsigned)fl;
+  }
+  Corner out;
+  const unsigned res = L.res[lvl], size = L.size[lvl];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned gx = cell[0] + (c & 1), gy = cell[1] + ((c >> 1) & 1), gz = cell[2] + ((c >> 2) & 1);
+    const float wx = (c & 1) ? frac[0] : sub_rn(1.0f, frac[0]);
+    const float wy = (c & 2) ? frac[1] : sub_rn(1.0f, frac[1]);
+    const float wz = (c & 4) ? frac[2] : sub_rn(1.0f, frac[2]);
+    out.w[c] = mul_rn(mul_rn(wx, wy), wz);
+    unsigned e;
+    if (L.dense[lvl]) e = (gx + gy * res + gz * res * res) % size;
+    else e = ((gx * 1u) ^ (gy * 2654435761u) ^ (gz * 805459861u)) % size;
+    out.idx[c] = e + L.offset[lvl];
+  }
+  return out;
+}
+
+// out_f32 [n, 2L] row-major (optional), out_nat: bf16 natural-order operand blocks (optional):
+// [wave tile of 32 points][k-step ks = level/8][lane (c, h)][8] with feature 16ks + 8h + j
+__global__ void __launch_bounds__(256)
+hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const float2* __restrict__ table, HashLevels L,
+                float* __restrict__ out_f32, __bf16* __restrict__ out_nat, unsigned* __restrict__ idx_out) {
+  // the operand image is padded to whole 128-point tiles: pad rows repeat the last point so that
+  // every stashed value is finite (their gradients are zero downstream)
+  const int64_t total = (out_nat != nullptr ? n_pad : n) * L.n_levels;
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = g / L.n_levels;
+    const int lvl = (int)(g - p * L.n_levels);
+    const int64_t ps = p < n ? p : n - 1;
+    const Corner c = corners_of(L, lvl, pts[ps * 3 + 0], pts[ps * 3 + 1], pts[ps * 3 + 2]);
+    float f0 = 0.0f, f1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float2 v = table[c.idx[k]];
+      f0 += c.w[k] * v.x;
+      f1 += c.w[k] * v.y;
+      if (idx_out != nullptr && p < n) idx_out[g * 8 + k] = c.idx[k];
+    }
+    if (out_f32 != nullptr && p < n) {
+      out_f32[p * (2 * L.n_levels) + 2 * lvl + 0] = f0;
+      out_f32[p * (2 * L.n_levels) + 2 * lvl + 1] = f1;
+    }
+    if (out_nat != nullptr) {
+      const int f = 2 * lvl, ks = f >> 4, h = (f >> 3) & 1, j = f & 7;
+      const int64_t wt = p >> 5;
+      const int col = (int)(p & 31);
+      const int n_ks = (2 * L.n_levels + 15) / 16;
+      __bf16* dst = out_nat + ((wt * n_ks + ks) * 64 + 2 * col + h) * 8 + j;
+      dst[0] = (__bf16)f0;
+      dst[1] = (__bf16)f1;
+    }
+  }
+}
+
+// d_feat [n, 2L] fp32 -> atomic scatter into d_table [E, 2]
+__global__ void __launch_bounds__(256)
+hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, const float* __restrict__ d_feat,
+                float* __restrict__ d_table) {
+  const int64_t total = n * L.n_levels;
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = g / L.n_levels;
+    const int lvl = (int)(g - p * L.n_levels);
+    const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0], g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1];
+    if (g0 == 0.0f && g1 == 0.0f) continue;
+    const Corner c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      atomicAdd(d_table + 2 * (size_t)c.idx[k] + 0, c.w[k] * g0);
+      atomicAdd(d_table + 2 * (size_t)c.idx[k] + 1, c.w[k] * g1);
+    }
+  }
+}
+
+static int fill_levels(HashLevels& L, int n_levels, const float* scale, const unsigned* res, const unsigned* size,
+                       const unsigned* offset, const unsigned* dense, float bound) {
+  if (n_levels < 1 || n_levels > kMaxLevels) return fail(NERF_EINVAL, "hash grid: n_levels=%d (1..16)", n_levels);
+  L.n_levels = n_levels;
+  L.bound = bound;
+  for (int i = 0; i < n_levels; ++i) {
+    L.scale[i] = scale[i]; L.res[i] = res[i]; L.size[i] = size[i]; L.offset[i] = offset[i]; L.dense[i] = dense[i];
+    if (size[i] == 0) return fail(NERF_EINVAL, "hash grid: level %d has size 0", i);
+  }
+  return NERF_OK;
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* table, int n_levels,
+                                    const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                    const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                    float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0, "nerf_hash_encode_fwd: n=%lld", (long long)n);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(pts && table && scale_host && res_host && size_host && offset_host && dense_host,
+               "nerf_hash_encode_fwd: NULL pointer");
+  NERF_REQUIRE(out_f32 || out_nat_bf16, "nerf_hash_encode_fwd: no output requested");
+  HashLevels L;
+  int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
+  if (rc != NERF_OK) return rc;
+  const int64_t n_pad = (n + 127) / 128 * 128;
+  int64_t blocks = (n_pad * n_levels + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(hash_fwd_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), pts, n, n_pad,
+                     reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out);
+  return check_launch("nerf_hash_encode_fwd");
+}
+
+extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                    const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                    const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                                    nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd: n=%lld", (long long)n);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(pts && d_feat && d_table && scale_host && res_host && size_host && offset_host && dense_host,
+               "nerf_hash_encode_bwd: NULL pointer");
+  HashLevels L;
+  int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
+  if (rc != NERF_OK) return rc;
+  int64_t blocks = (n * n_levels + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(hash_bwd_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), pts, n, L, d_feat, d_table);
+  return check_launch("nerf_hash_encode_bwd");
+}

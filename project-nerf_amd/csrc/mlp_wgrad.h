@@ -1,0 +1,49 @@
+// Job table of the split-K weight-gradient kernel (mlp_wgrad.hip), shared by the vanilla decoder
+// and the Instant tiny-MLP backward passes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nerf {
+
+constexpr int kMaxJobs = 12;
+constexpr int kWgStages = 4;
+constexpr int kWgStageA = 16 * 1024, kWgStageB = 16 * 1024, kWgStageN = 4 * 1024;
+constexpr int kWgStageBytes = kWgStageA + kWgStageB + kWgStageN;   // 36 KiB
+constexpr int kWgLds = kWgStages * kWgStageBytes;                 // 144 KiB
+constexpr int kMaxTiles = 10;                                      // n-tiles a wave accumulates
+
+struct WgradJob {
+  const char* a;        // A image
+  const char* b_acc;    // blocked activations (or null)
+  const char* b_nat;    // Fourier-code blocks (or null)
+  int a_bytes;          // A bytes per wave tile
+  int b_acc_bytes, b_nat_bytes;
+  int a_nat;            // A is one 16-wide natural block (dsmall)
+  int mt_a;             // 32-row tiles of A
+  int nt_acc, nt_nat, ones;
+  int split_n;          // single natural A block (dsmall): column tiles are split over the waves
+  int kind;             // template instantiation of run_job (see the switch in the kernel)
+  int w_off, w_ld;      // dW[o][i] -> grads[w_off + (o - o_row0) * w_ld + col]
+  int o_row0, o_valid;
+  int acc_valid, acc_col0;
+  int nat_valid, nat_col0;
+  int bias_off, bias_nat_col;   // bias_nat_col < 0: bias comes from the ones tile
+  long long cost0;      // prefix sum of cost (bytes per wave tile * wave tiles) before this job
+  int cost;             // bytes per wave tile
+};
+
+struct WgradArgs {
+  WgradJob jobs[kMaxJobs];
+  int n_jobs;
+  int wave_tiles;
+  long long total_cost;
+  float* grads;
+  int debug;            // development aid (NERF_WGRAD_DEBUG): bit0 skip MFMA/LDS reads, bit1 skip DMA, bit2 skip flush
+};
+
+
+// fills cost0 / total_cost / wave_tiles / grads and launches; jobs[0..n_jobs) must be set
+int wgrad_launch(WgradArgs& args, int64_t n_samples, float* grads, hipStream_t stream);
+
+}  // namespace nerf

@@ -14,45 +14,10 @@
 #include <stdlib.h>
 #include "mlp_chain.h"
 #include "mlp_stash.h"
+#include "mlp_wgrad.h"
 
 namespace nerf {
 using namespace plan;
-
-constexpr int kMaxJobs = 12;
-constexpr int kWgStages = 4;
-constexpr int kWgStageA = 16 * 1024, kWgStageB = 16 * 1024, kWgStageN = 4 * 1024;
-constexpr int kWgStageBytes = kWgStageA + kWgStageB + kWgStageN;   // 36 KiB
-constexpr int kWgLds = kWgStages * kWgStageBytes;                 // 144 KiB
-constexpr int kMaxTiles = 10;                                      // n-tiles a wave accumulates
-
-struct WgradJob {
-  const char* a;        // A image
-  const char* b_acc;    // blocked activations (or null)
-  const char* b_nat;    // Fourier-code blocks (or null)
-  int a_bytes;          // A bytes per wave tile
-  int b_acc_bytes, b_nat_bytes;
-  int a_nat;            // A is one 16-wide natural block (dsmall)
-  int mt_a;             // 32-row tiles of A
-  int nt_acc, nt_nat, ones;
-  int split_n;          // single natural A block (dsmall): column tiles are split over the waves
-  int kind;             // template instantiation of run_job (see the switch in the kernel)
-  int w_off, w_ld;      // dW[o][i] -> grads[w_off + (o - o_row0) * w_ld + col]
-  int o_row0, o_valid;
-  int acc_valid, acc_col0;
-  int nat_valid, nat_col0;
-  int bias_off, bias_nat_col;   // bias_nat_col < 0: bias comes from the ones tile
-  long long cost0;      // prefix sum of cost (bytes per wave tile * wave tiles) before this job
-  int cost;             // bytes per wave tile
-};
-
-struct WgradArgs {
-  WgradJob jobs[kMaxJobs];
-  int n_jobs;
-  int wave_tiles;
-  long long total_cost;
-  float* grads;
-  int debug;            // development aid (NERF_WGRAD_DEBUG): bit0 skip MFMA/LDS reads, bit1 skip DMA, bit2 skip flush
-};
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -166,7 +131,7 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
       }
       if constexpr (SPLIT) {
         if (wave < NT_ACC) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tr_frag<256>(pb + 1024 * s), acc[0], 0, 0, 0);
-        if (wave == NT_ACC % 8) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, acc[1], 0, 0, 0);
+        if (ONES && wave == NT_ACC % 8) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, acc[1], 0, 0, 0);
       } else {
         // all fragment reads of the k-step first, then the MFMAs: hipcc otherwise recycles one
         // fragment register (read -> wait -> mfma), exposing the LDS latency per MFMA
@@ -195,7 +160,7 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
     bool use = true;
     if constexpr (SPLIT) {
       if (k == 0) { use = wave < NT_ACC; const int i = wave * 32 + c32; if (i < job.acc_valid) col = job.acc_col0 + i; }
-      else { use = wave == NT_ACC % 8; bias_here = (c32 == 0); }
+      else { use = ONES && wave == NT_ACC % 8; bias_here = (c32 == 0); }
     } else {
       if (k < NT_ACC) { const int i = k * 32 + c32; if (i < job.acc_valid) col = job.acc_col0 + i; }
       else if (k < NT_ACC + NT_NAT) {
@@ -246,7 +211,11 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
       case 2: run_job<0, 2, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.0
       case 3: run_job<8, 1, false, false>(args, job, wt0, wt1, smem, g); break;   // view_layer
       case 4: run_job<8, 0, true, true>(args, job, wt0, wt1, smem, g); break;     // sigma_layer
-      default: run_job<4, 0, true, true>(args, job, wt0, wt1, smem, g); break;    // rgb_layer
+      case 5: run_job<4, 0, true, true>(args, job, wt0, wt1, smem, g); break;     // rgb_layer
+      case 6: run_job<0, 1, false, false>(args, job, wt0, wt1, smem, g); break;   // instant sigma-net layer 1
+      case 7: run_job<2, 0, false, false>(args, job, wt0, wt1, smem, g); break;   // instant 64-wide layers
+      case 8: run_job<1, 1, false, false>(args, job, wt0, wt1, smem, g); break;   // instant colour-net layer 1
+      default: run_job<2, 0, false, true>(args, job, wt0, wt1, smem, g); break;   // instant rgb layer
     }
   }
 }
@@ -321,6 +290,12 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
     add(j);
   }
   args.n_jobs = nj;
+  return wgrad_launch(args, n, grads, stream);
+}
+
+int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t stream) {
+  const int nj = args.n_jobs;
+  for (int j = 0; j < nj; ++j) args.jobs[j].cost = args.jobs[j].a_bytes + args.jobs[j].b_acc_bytes + args.jobs[j].b_nat_bytes;
   args.wave_tiles = (int)((n + 31) / 32);
   long long c = 0;
   for (int j = 0; j < nj; ++j) {

@@ -1,0 +1,204 @@
+"""Instant-NGP variant (mode part2_instant): hash-grid representation, tiny-MLP decoder and the
+training loop of reference run.py:396-900, on the HIP kernels.
+
+The reference delegates both operators to tinycudann (absent, unpinned); the classes below keep
+its attribute surface -- ``representation.encoding.params`` (flat fp32, read by the TV
+regulariser, run.py:614), ``decoder.sigma_net.params``, ``decoder.color_net.params`` -- so that
+state_dict keys match, while sizes/layouts are this build's definition (see include/nerf_hip.h)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .abstract import BaseDecoder, BaseRepresentation
+from .embeddings import FourierRepresentation
+
+
+class _ParamHolder(nn.Module):
+    """Stands in for a tcnn module: one flat fp32 ``params`` vector."""
+
+    def __init__(self, init, n_output_dims=None):
+        super().__init__()
+        self.params = nn.Parameter(init)
+        self.n_output_dims = n_output_dims
+
+
+class HashRepresentation(BaseRepresentation):
+    """reference src/embeddings.py:39-93."""
+
+    def __init__(self, n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+                 per_level_scale=1.5, bound=1.0):
+        super().__init__()
+        if n_features_per_level != 2 or n_levels != 16:
+            raise NotImplementedError("libnerf_hip is compiled for 16 levels x 2 features (32 hash channels)")
+        self.bound = bound
+        self.levels = ops.HashLevelTable(n_levels, log2_hashmap_size, base_resolution, per_level_scale)
+        init = (torch.rand(self.levels.entries * 2) * 2 - 1) * 1e-4
+        self.encoding = _ParamHolder(init, n_output_dims=n_levels * n_features_per_level)
+        self._out_dim = self.encoding.n_output_dims
+
+    def table(self):
+        return self.encoding.params.view(-1, 2)
+
+    def forward(self, x):
+        if x.requires_grad or self.encoding.params.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("differentiate through NeuralField (fused hash + decoder), not the bare encoding")
+        return ops.hash_encode_fwd(x, self.table(), self.levels, self.bound)[0]
+
+    @property
+    def out_dim(self):
+        return self._out_dim
+
+
+class InstantNeRFDecoder(BaseDecoder):
+    """reference src/decoders.py:90-162: sigma-net 32->64->16, colour-net (16+27)->64->64->3."""
+
+    def __init__(self, pos_dim, dir_dim, hidden_dim=64):
+        super().__init__()
+        if (pos_dim, dir_dim, hidden_dim) != (32, 27, 64):
+            raise NotImplementedError("libnerf_hip is compiled for pos 32 / dir 27 / hidden 64")
+
+        def xavier(rows, cols, fan_in, fan_out):
+            return (torch.rand(rows, cols) * 2 - 1) * (6.0 / (fan_in + fan_out)) ** 0.5
+        s = torch.cat([xavier(64, 32, 32, 64).reshape(-1), xavier(16, 64, 64, 16).reshape(-1)])
+        w1 = xavier(64, 48, 43, 64)
+        w1[:, 43:] = 0
+        w3 = xavier(16, 64, 64, 3)
+        w3[3:] = 0
+        c = torch.cat([w1.reshape(-1), xavier(64, 64, 64, 64).reshape(-1), w3.reshape(-1)])
+        self.sigma_net = _ParamHolder(s)
+        self.color_net = _ParamHolder(c)
+        self._packed, self._version = None, None
+
+    def flat_parameters(self):
+        return torch.cat([self.sigma_net.params, self.color_net.params])
+
+    def packed_weights(self):
+        v = (self.sigma_net.params._version, self.color_net.params._version)
+        if self._packed is None or v != self._version or self._packed.device != self.sigma_net.params.device:
+            with torch.no_grad():
+                self._packed = ops.imlp_pack(self.flat_parameters())
+            self._version = v
+        return self._packed
+
+    def forward(self, x_enc, d_enc):
+        raise NotImplementedError("the Instant decoder runs fused with the hash encoding: call NeuralField(x, d)")
+
+
+def build_instant_field(field, config):
+    """NeuralField.__init__ for mode part2_instant (reference src/core.py:57-77)."""
+    field.representation = HashRepresentation(
+        n_levels=config.get("n_levels", 16), n_features_per_level=config.get("n_features_per_level", 2),
+        log2_hashmap_size=config.get("log2_hashmap_size", 19), base_resolution=config.get("base_resolution", 16),
+        per_level_scale=config.get("per_level_scale", 1.5), bound=config.get("scene_bound", 1.0))
+    field.dir_representation = FourierRepresentation(input_dim=3, L=config.get("L_embed_dir", 4), use_encoding=True)
+    field.decoder = InstantNeRFDecoder(pos_dim=field.representation.out_dim, dir_dim=field.dir_representation.out_dim,
+                                       hidden_dim=config.get("hidden_dim", 64))
+
+    def _instant_forward(x, d):
+        rep, dec = field.representation, field.decoder
+        rgb, sigma = ops.instant_field(rep.table(), dec.flat_parameters(), dec.packed_weights(), x, d, rep.levels, rep.bound)
+        return rgb, sigma.unsqueeze(-1)
+    field._instant_forward = _instant_forward
+
+
+def run_instant(cfg, args):
+    """Training / evaluation loop of reference run_part2_instant (run.py:396-900): AdamW + cosine LR,
+    TV-L1 on the flat hash table, per-group grad clipping, occupancy grid refreshed every
+    32 / 128 / 512 steps after the warm-up, best-on-validation checkpoints."""
+    import random
+    from .core import NeuralField
+    from .dataset import BlenderDataset
+    from .renderer import DensityGrid, render_rays
+    from .utils import compute_psnr, compute_psnr_torch
+    if not args.data_dir:
+        raise ValueError("Part 2 Instant requires --data_dir pointing to a NeRF dataset root.")
+    if not torch.cuda.is_available():
+        raise RuntimeError("the NeRF hot path runs on a HIP device only (no CPU fallback)")
+    device = torch.device("cuda")
+    downscale, white_bkgd = cfg.get("downscale", 2), cfg.get("white_bkgd", True)
+    near, far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
+    n_samples = cfg.get("n_samples", 32)
+    render_n = cfg.get("render_n_samples", n_samples)
+    batch, iters, lr = cfg.get("batch_size", 8192), cfg.get("train_iters", 5000), cfg.get("learning_rate", 0.01)
+    log_every, chunk = cfg.get("log_every", 50), args.render_chunk or cfg.get("chunk", 16384)
+    log_dir = os.path.join(cfg.get("log_dir", "output/part2_instant"), os.path.basename(args.data_dir.rstrip("/")))
+    os.makedirs(log_dir, exist_ok=True)
+    train_set = BlenderDataset(args.data_dir, "train", downscale, white_bkgd, cfg.get("scene_scale", 1.0)).to(device)
+    split = "test" if os.path.exists(os.path.join(args.data_dir, "transforms_test.json")) else "val"
+    test_set = BlenderDataset(args.data_dir, split, downscale, white_bkgd, cfg.get("scene_scale", 1.0))
+    model = NeuralField(cfg).to(device)
+    grid = None
+    if cfg.get("use_density_grid", True):
+        grid = DensityGrid(cfg.get("grid_resolution", 128), cfg.get("scene_bound", 1.5), cfg.get("grid_threshold", 0.01)).to(device)
+    if args.checkpoint:
+        ckpt = torch.load(args.checkpoint, map_location=device)
+        model.load_state_dict(ckpt["model_state_dict"])
+        if grid is not None and "density_grid" in ckpt:
+            grid.load_state_dict(ckpt["density_grid"])
+
+    def evaluate(ds, indices):
+        model.eval()
+        out = []
+        with torch.no_grad():
+            for idx in indices:
+                o, d, tgt = ds.get_image_rays(idx, device)
+                o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+                pred = torch.cat([render_rays(model, o[i:i + chunk], d[i:i + chunk], near, far, render_n, False,
+                                              white_bkgd=white_bkgd, density_grid=grid)[0]
+                                  for i in range(0, o.shape[0], chunk)], 0)
+                out.append(compute_psnr_torch(pred.clamp(0, 1), tgt.reshape(-1, 3)))
+        model.train()
+        return float(np.mean(out)) if out else 0.0
+
+    best = 0.0
+    if not args.eval_only:
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=cfg.get("weight_decay", 1e-5))
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=cfg.get("eta_min", 1e-4))
+        use_tv, tv_w = cfg.get("use_tv_loss", True), float(cfg.get("tv_loss_weight", 1e-6))
+        warm, stop = cfg.get("grid_warmup_iters", 256), cfg.get("grid_stop_ratio", 0.9)
+        n_val = max(1, int(len(test_set) * 0.3))
+        val_idx = random.sample(range(len(test_set)), n_val)
+        active = 1.0
+        model.train()
+        for step in range(1, iters + 1):
+            o, d, rgba = train_set.sample_random_rays(batch, device)
+            bg = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)
+            target = rgba[:, :3] * rgba[:, 3:4] + bg * (1 - rgba[:, 3:4])
+            pred, _, _ = render_rays(model, o, d, near, far, n_samples, True, white_bkgd=white_bkgd,
+                                     density_grid=grid, bg_color=bg)
+            loss_rgb = torch.nn.functional.mse_loss(pred, target)
+            loss = loss_rgb
+            if use_tv:
+                p = model.representation.encoding.params
+                loss = loss + torch.mean(torch.abs(p[1:] - p[:-1])) * tv_w
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.representation.parameters(), max_norm=1.0)
+            torch.nn.utils.clip_grad_norm_(model.decoder.parameters(), max_norm=1.0)
+            opt.step()
+            sched.step()
+            if grid is not None and step < iters * stop:
+                interval = 32 if step < iters * 0.1 else (128 if step < iters * 0.5 else 512)
+                if grid.should_update(step, interval, warm):
+                    model.eval()
+                    active = grid.update(model, device=device, time=None)
+                    model.train()
+            if step % log_every == 0:
+                print(f">>> Step {step}/{iters} | Loss {loss.item():.6f} | PSNR {compute_psnr(loss_rgb.item()):.2f} dB"
+                      f" | Skip: {(1 - active) * 100:.1f}%")
+            if step % cfg.get("val_every", 500) == 0:
+                v = evaluate(test_set, val_idx)
+                print(f"    [Validation] PSNR: {v:.2f} dB")
+                if v > best:
+                    best = v
+                    save = {"model_state_dict": model.state_dict(), "config": cfg, "step": step, "val_psnr": best}
+                    if grid is not None:
+                        save["density_grid"] = grid.state_dict()
+                    torch.save(save, os.path.join(log_dir, "best_model.pth"))
+    n_eval = len(test_set) if args.render_n in (None, -1) else min(args.render_n, len(test_set))
+    avg = evaluate(test_set, range(n_eval))
+    print(f">>> Test PSNR: {avg:.2f} dB (best validation {best:.2f} dB)")
+    return avg

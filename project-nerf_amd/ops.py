@@ -264,6 +264,116 @@ def decoder(params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, z: O
     return mlp_fwd(packed, rays_o, rays_d, z)
 
 
+# --------------------------------------------------------------------------- a7 / a8
+import ctypes as _ct
+import math as _math
+
+import numpy as _np
+
+
+class HashLevelTable:
+    """Per-level table of the multiresolution grid (this build's definition; the third-party
+    library is absent): scale_l = base * s^l - 1 evaluated in float64 and rounded once to fp32,
+    res_l = ceil(scale_l) + 1, dense storage when res^3 fits the hash-map budget (sizes padded to
+    8 entries).  Identical to oracle/nerf_oracle.py::hash_grid_levels."""
+
+    def __init__(self, n_levels=16, log2_hashmap_size=19, base_resolution=16, per_level_scale=1.5):
+        budget = 1 << log2_hashmap_size
+        scale, res, size, offset, dense, off = [], [], [], [], [], 0
+        for l in range(n_levels):
+            s64 = base_resolution * (per_level_scale ** l) - 1.0
+            r = int(_math.ceil(round(s64, 9))) + 1
+            is_dense = r ** 3 <= budget
+            sz = ((r ** 3 + 7) // 8) * 8 if is_dense else budget
+            scale.append(s64); res.append(r); size.append(sz); offset.append(off); dense.append(int(is_dense))
+            off += sz
+        self.n_levels, self.entries = n_levels, off
+        self.scale = _np.asarray(scale, dtype=_np.float32)
+        self.res = _np.asarray(res, dtype=_np.uint32)
+        self.size = _np.asarray(size, dtype=_np.uint32)
+        self.offset = _np.asarray(offset, dtype=_np.uint32)
+        self.dense = _np.asarray(dense, dtype=_np.uint32)
+
+    def host_args(self):
+        return tuple(a.ctypes.data_as(_ct.c_void_p) for a in (self.scale, self.res, self.size, self.offset, self.dense))
+
+
+def hash_encode_fwd(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: float,
+                    want_f32: bool = True, out_nat: Optional[Tensor] = None, want_index: bool = False):
+    lib = _lib.load()
+    pts, table = _dev(pts, "pts"), _dev(table, "table")
+    n = pts.shape[0]
+    out = torch.empty(n, 2 * levels.n_levels, device=pts.device) if want_f32 else None
+    idx = torch.empty(n, levels.n_levels, 8, device=pts.device, dtype=torch.int32) if want_index else None
+    _lib.check(lib.nerf_hash_encode_fwd(_p(pts), n, _p(table), levels.n_levels, *levels.host_args(), float(bound),
+                                        _p(out), _p(out_nat), _p(idx), _stream()), "nerf_hash_encode_fwd")
+    return out, idx
+
+
+def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor, d_table: Tensor) -> None:
+    lib = _lib.load()
+    pts, d_feat = _dev(pts, "pts"), _dev(d_feat, "d_feat")
+    _lib.check(lib.nerf_hash_encode_bwd(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
+                                        _p(d_feat), _p(d_table), _stream()), "nerf_hash_encode_bwd")
+
+
+IMLP_PARAM_COUNT = 11264
+IMLP_SIGMA_PARAMS = 3072
+
+
+def imlp_pack(params: Tensor, packed: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    params = _dev(params, "params")
+    if params.numel() != IMLP_PARAM_COUNT:
+        raise ValueError(f"instant decoder expects {IMLP_PARAM_COUNT} parameters, got {params.numel()}")
+    if packed is None:
+        packed = torch.empty(lib.nerf_imlp_packed_bytes(), device=params.device, dtype=torch.uint8)
+    _lib.check(lib.nerf_imlp_pack(_p(params), _p(packed), _stream()), "nerf_imlp_pack")
+    return packed
+
+
+class _InstantField(torch.autograd.Function):
+    """hash encode -> tiny MLPs (reference core.py:354-359 for part2_instant), fwd and bwd in HIP."""
+
+    @staticmethod
+    def forward(ctx, table, net_params, packed, pts, dirs, levels, bound, train):
+        lib = _lib.load()
+        n = pts.shape[0]
+        ws = torch.empty(lib.nerf_imlp_workspace_bytes(n), device=pts.device, dtype=torch.uint8)
+        hash_encode_fwd(pts, table, levels, bound, want_f32=False, out_nat=ws)
+        rgb = torch.empty(n, 3, device=pts.device)
+        sigma = torch.empty(n, device=pts.device)
+        _lib.check(lib.nerf_imlp_fwd(_p(packed), _p(ws), _p(dirs), n, _p(rgb), _p(sigma), 1 if train else 0, _stream()),
+                   "nerf_imlp_fwd")
+        if train:
+            ctx.save_for_backward(packed, ws, rgb, sigma, pts)
+            ctx.levels, ctx.bound, ctx.table_shape = levels, bound, table.shape
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        lib = _lib.load()
+        packed, ws, rgb, sigma, pts = ctx.saved_tensors
+        n = pts.shape[0]
+        g_net = torch.empty(IMLP_PARAM_COUNT, device=pts.device)
+        d_feat = torch.empty(n, 2 * ctx.levels.n_levels, device=pts.device)
+        _lib.check(lib.nerf_imlp_bwd(_p(packed), _p(ws), _p(rgb), _p(sigma), _p(d_rgb.contiguous()),
+                                     _p(d_sigma.contiguous()), n, _p(g_net), _p(d_feat), _stream()), "nerf_imlp_bwd")
+        g_table = torch.zeros(ctx.table_shape, device=pts.device)
+        hash_encode_bwd(pts, ctx.levels, ctx.bound, d_feat, g_table)
+        return g_table, g_net, None, None, None, None, None, None
+
+
+def instant_field(table: Tensor, net_params: Tensor, packed: Tensor, pts: Tensor, dirs: Tensor,
+                  levels: HashLevelTable, bound: float):
+    """rgb [n,3], sigma [n] for world-space points and unit view directions."""
+    pts, dirs = _dev(pts, "pts"), _dev(dirs, "dirs")
+    if pts.shape[0] == 0:
+        return pts.new_zeros(0, 3), pts.new_zeros(0)
+    train = torch.is_grad_enabled() and (table.requires_grad or net_params.requires_grad)
+    return _InstantField.apply(table, net_params, packed, pts, dirs, levels, bound, train)
+
+
 # --------------------------------------------------------------------------- a14
 def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0,
