@@ -100,20 +100,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import ops, parallel
+    from project_nerf_amd.engine import VanillaNerfEngine
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-
-    import project_nerf_amd  # noqa: F401
-    from project_nerf_amd import ops
-    from project_nerf_amd.engine import VanillaNerfEngine
+        parallel.init_distributed("cuda")       # backend nccl == RCCL over xGMI
 
     eng = VanillaNerfEngine(seed=0, world_size=world, device=str(device))
     R, S = args.rays, args.samples
     o, d, target = synth_rays(R, 100 + rank, device)
-    sync = (lambda g: dist.all_reduce(g)) if world > 1 else None
+    sync = parallel.allreduce_sum_ if world > 1 else None   # ONE collective per step: flat 2.38 MB gradient
 
     def barrier():
         if world > 1:

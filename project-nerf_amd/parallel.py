@@ -1,0 +1,62 @@
+"""Ray data-parallelism over the GPUs of one node.
+
+One process per GPU; rays are independent, so the only exchange in a training step is ONE
+all-reduce (sum) of the flat fp32 gradient vector -- 2.38 MB for the vanilla decoder -- over
+RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm; "gloo" on CPU for the tests).  The mean
+over the global batch is taken by scaling with 1/world inside the Adam kernel.  Evaluation
+splits an image into contiguous row bands and gathers them on rank 0.  The reference has no
+distributed code at all (grep: no ``distributed`` / ``all_reduce``), this is the build's own.
+"""
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(device_type: Optional[str] = None) -> Tuple[int, int, int]:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE (torchrun contract); returns (rank, local_rank, world)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        use_gpu = (device_type or ("cuda" if torch.cuda.is_available() else "cpu")) == "cuda"
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    return rank, local_rank, world
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n items; the union over ranks is exactly range(n)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place sum over ranks of one flat buffer (a single collective per step)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def gather_row_bands(band: torch.Tensor, rows_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """Each rank holds rows shard_range(rows_total, rank, world) of an image [rows, W, C]; returns
+    the assembled image on ``dst`` (None elsewhere)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return band
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(rows_total, r, world) for r in range(world)]
+    max_rows = max(hi - lo for lo, hi in sizes)
+    pad = band.new_zeros((max_rows,) + tuple(band.shape[1:]))
+    pad[: band.shape[0]] = band
+    bufs: Optional[List[torch.Tensor]] = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
