@@ -76,6 +76,9 @@ struct WeightRing {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     slot ^= 1;
+    // (ablation on MI355X, 65536x128 samples: skipping these DMA issues -> 1476 TFLOP/s vs 1253;
+    //  skipping the wait changes nothing: the ~77-cycle issue cost of each 1-KiB LDS-DMA piece,
+    //  64 pieces per 4096-cycle chunk per CU, is what the ring costs, not its latency)
     if constexpr (C + 1 < n) issue<C + 1>(slot ^ 1);
     else if (more_passes) issue<0>(slot ^ 1);
     asm volatile("" ::: "memory");
@@ -90,23 +93,30 @@ struct WeightRing {
 // A fragments are read kAhead k-steps ahead of the MFMA that consumes them; the
 // sched_group_barrier sequence pins that software pipeline (hipcc otherwise serialises
 // ds_read -> wait -> mfma on one fragment register when VGPRs are tight).
-constexpr int kAhead = 6;
+constexpr int kAhead = 3;
 template <int KS>
 __device__ __forceinline__ f32x16 mtile_mfma(const char* a_base, int frag_off, const bf16x8 (&b)[KS], f32x16 acc) {
-  bf16x8 a[KS];
+  // explicit rotating window of kAhead fragments, in program order: read k+kAhead, then MFMA k
+  constexpr int D = KS < kAhead ? KS : kAhead;
+  bf16x8 win[D];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(a_base + (frag_off + ks) * 1024);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks], acc, 0, 0, 0);
-  constexpr int pre = KS < kAhead ? KS : kAhead;
-  __builtin_amdgcn_sched_group_barrier(0x100, pre, 0);
+  for (int i = 0; i < D; ++i) win[i] = *reinterpret_cast<const bf16x8*>(a_base + (frag_off + i) * 1024);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (ks + pre < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    const bf16x8 cur = win[ks % D];
+    if (ks + D < KS) win[ks % D] = *reinterpret_cast<const bf16x8*>(a_base + (frag_off + ks + D) * 1024);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, b[ks], acc, 0, 0, 0);
   }
   return acc;
 }
+
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+}  // namespace nerf
+#include "mlp_mtile_asm.h"
+namespace nerf {
 
 // accumulator rows of register r in lane-half h: (r&3) + 8*(r>>2) + 4h  -> bias as 4 x float4
 __device__ __forceinline__ f32x16 bias_tile(const float* bias_lds, int row0, int half) {
@@ -117,6 +127,22 @@ __device__ __forceinline__ f32x16 bias_tile(const float* bias_lds, int row0, int
     acc[4 * g + 0] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
   }
   return acc;
+}
+
+// ReLU as a signed integer max on the fp32 bit pattern (negative floats are negative integers,
+// -0.0 -> +0): one v_max_i32 per element where fmaxf costs two v_max_f32 (hipcc canonicalises
+// MFMA results before fmaxf).  NaNs pass through unchanged if positive-signed.
+__device__ __forceinline__ float relu_bits(float x) {
+  const int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+template <bool RELU>
+__device__ __forceinline__ void acc_to_operand_relu(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    lo[j] = (__bf16)(RELU ? relu_bits(acc[j]) : acc[j]);
+    hi[j] = (__bf16)(RELU ? relu_bits(acc[8 + j]) : acc[8 + j]);
+  }
 }
 
 // fp32 accumulator tile -> the two bf16 B fragments (k-steps 2m, 2m+1) of the next step
@@ -185,7 +211,7 @@ __device__ __forceinline__ void run_step(WeightRing<BWD>& ring, const char*& a_b
     } else {
       acc = bias_tile(bias_lds, plan::bias_off(KIND) + 32 * m, half);
     }
-    acc = mtile_mfma<KS>(a_base, ch.group_off[g], b, acc);
+    acc = mtile_asm<KS>(lds_addr(a_base) + ch.group_off[g] * 1024, b, acc);
     epi(mc, acc);
   });
 }

@@ -7,6 +7,7 @@
 // accumulators' initial values.  MFMA-bound: 1,186,816 FLOP per sample (+ padding).
 // TRAIN additionally stashes bf16 activations (row-major [n, width], the wgrad kernel's B
 // operands) and ReLU bitmasks for the backward chain.
+#include <stdlib.h>
 #include "mlp_chain.h"
 
 namespace nerf {
@@ -88,19 +89,17 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
     auto hidden = [&](bf16x8* out, __bf16* stash, int width, bool relu) {
       return [=, &mask_words](auto mc, f32x16 acc) {
         constexpr int m = decltype(mc)::value;
-        if (relu) {
-          uint32_t bits = 0;
+        if constexpr (TRAIN) {
+          if (relu) {
+            uint32_t bits = 0;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
-            acc[r] = fmaxf(acc[r], 0.0f);
-          }
-          if constexpr (TRAIN) {
+            for (int r = 0; r < 16; ++r) bits |= (acc[r] > 0.0f ? 1u : 0u) << r;
             if constexpr ((m & 1) == 0) mask_words[m >> 1] = bits;
             else mask_words[m >> 1] |= bits << 16;
           }
         }
-        acc_to_operand(acc, out[2 * m], out[2 * m + 1]);
+        if (relu) acc_to_operand_relu<true>(acc, out[2 * m], out[2 * m + 1]);
+        else acc_to_operand_relu<false>(acc, out[2 * m], out[2 * m + 1]);
         if constexpr (TRAIN) stash_block(stash, wave_tile, width / 32, m, col, half, out[2 * m], out[2 * m + 1]);
       };
     };

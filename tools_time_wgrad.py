@@ -20,7 +20,16 @@ def t(it=20):
     for _ in range(it): lib.nerf_mlp_bwd_wgrad(stash.data_ptr(), ws.data_ptr(), n, grads.data_ptr(), st)
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
 gb = (stash.numel() + ws.numel()) * 1e-9
-for dbg in (0, 1, 2, 4, 5, 3):
+for dbg in (0, 1, 2, 3):
     os.environ["NERF_WGRAD_DEBUG"] = str(dbg)
     ms = t()
     print(f"debug={dbg}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s", flush=True)
+os.environ["NERF_WGRAD_DEBUG"] = "0"
+for ovh in (49152, 65536, 98304, 131072, 262144, 1048576):
+    os.environ['NERF_WGRAD_OVH'] = str(ovh); print('ovh', ovh, f'{t():.3f} ms', flush=True)
+for kind, nb in ():
+    os.environ["NERF_WGRAD_ONLY"] = str(kind)
+    for dbg in (0, 1, 2):
+        os.environ["NERF_WGRAD_DEBUG"] = str(dbg)
+        ms = t()
+        print(f"kind {kind} debug={dbg}: {ms:.3f} ms  {nb*1024*8192e-9/ms*1e3:.0f} GB/s", flush=True)
