@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--render-samples", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--render-frames", type=int, default=3)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,6 +99,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("NERF_BENCH_SINGLE_DEVICE"):      # rehearsal of the N>1 control flow on a 1-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import project_nerf_amd  # noqa: F401
@@ -181,13 +184,31 @@ def main():
             "adam+pack": {"ms": k["adam+pack"]},
         }
         out["kernels"] = kern
-        # dominant kernel of the step = the decoder chain (fwd + dgrad run the same MFMA structure);
-        # report the forward training launch: algorithmic FLOP per launch / measured launch time
-        dom = "mlp_fwd_train"
-        ach = n * FWD_FLOP / k[dom] * 1e-9
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
-                           "flop_per_launch": n * FWD_FLOP, "launch_ms": k[dom]}
+        # ---- rooflines: algorithmic work per launch / live launch time; PMC traffic from the committed
+        # rocprofv3 --pmc summary of this same command (profiles/, FETCH_SIZE doubled as the gfx950
+        # guide prescribes); the step's dominant kernel (largest launch time) is reported as `roofline`
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                pmc = json.load(f)
+        except OSError:
+            pass
+        traffic = lambda name: (pmc.get(name, {}).get("hbm_bytes_per_launch_corrected") if (R, S) == (4096, 64) else None)
+        wgrad_bytes = stash_b + ws_b          # every stashed byte is read exactly once
+        roofs = {
+            "mlp_fwd_train": {"bound": "mfma", "kernel": "mlp_fwd_kernel<true>", "achieved": kern["mlp_fwd_train"]["tflops"],
+                              "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kern["mlp_fwd_train"]["tflops"] / MFMA_PEAK_TFLOPS,
+                              "traffic": traffic("mlp_fwd_kernel<true>"), "work_per_launch": n * FWD_FLOP, "launch_ms": k["mlp_fwd_train"]},
+            "mlp_bwd_dgrad": {"bound": "mfma", "kernel": "mlp_bwd_kernel", "achieved": kern["mlp_bwd_dgrad"]["tflops"],
+                              "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kern["mlp_bwd_dgrad"]["tflops"] / MFMA_PEAK_TFLOPS,
+                              "traffic": traffic("mlp_bwd_kernel"), "work_per_launch": n * DGRAD_FLOP, "launch_ms": k["mlp_bwd_dgrad"]},
+            "mlp_bwd_wgrad": {"bound": "hbm", "kernel": "mlp_wgrad_kernel", "achieved": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6 / HBM_PEAK_GBS,
+                              "traffic": traffic("mlp_wgrad_kernel"), "work_per_launch": wgrad_bytes, "launch_ms": k["mlp_bwd_wgrad"]},
+        }
+        dom = max(roofs, key=lambda name: k[name])
+        out["roofline"] = roofs[dom]
+        out["rooflines"] = roofs
         step_ach = R * S * TRAIN_FLOP / (ms_per_step * 1e-3) * 1e-12
         out["step_tflops"] = step_ach
         out["step_frac_of_mfma_peak"] = step_ach / MFMA_PEAK_TFLOPS
@@ -200,7 +221,7 @@ def main():
         eng.render_image(ro, rd, args.render_samples)     # warm-up
         barrier()
         t0 = time.perf_counter()
-        frames = 3
+        frames = args.render_frames
         for _ in range(frames):
             img = eng.render_image(ro, rd, args.render_samples)
             if world > 1:

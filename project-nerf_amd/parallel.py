@@ -23,11 +23,12 @@ def init_distributed(device_type: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         use_gpu = (device_type or ("cuda" if torch.cuda.is_available() else "cpu")) == "cuda"
-        if use_gpu:
+        backend = os.environ.get("NERF_DIST_BACKEND", "nccl" if use_gpu else "gloo")   # override: tests only
+        if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group(backend)
     return rank, local_rank, world
 
 
