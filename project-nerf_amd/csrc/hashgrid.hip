@@ -98,21 +98,44 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const f
   }
 }
 
-// d_feat [n, 2L] fp32 -> atomic scatter into d_table [E, 2]
-__global__ void __launch_bounds__(256)
-hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, const float* __restrict__ d_feat,
+// d_feat [n, 2L] fp32 -> scatter into d_table [E, 2].  Level-major work split (blockIdx.y = level,
+// consecutive lanes = consecutive points, i.e. neighbouring samples of a ray): a wave's 64 x 16
+// float atomics then fall into ONE level's table, mostly into neighbouring cells, instead of 16
+// unrelated regions.  Levels whose whole table fits in LDS (<= kLdsEntries entries: the dense
+// 16^3 and 24^3 levels, where thousands of samples hit each cell) are reduced in LDS first and
+// flushed with one well-shaped (contiguous) global atomic per entry per workgroup.
+constexpr int kLdsEntries = 16384;      // 128 KiB of float2
+template <bool in_lds>
+__global__ void __launch_bounds__(512)
+hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0, const float* __restrict__ d_feat,
                 float* __restrict__ d_table) {
-  const int64_t total = n * L.n_levels;
-  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = g / L.n_levels;
-    const int lvl = (int)(g - p * L.n_levels);
+  extern __shared__ __attribute__((aligned(16))) float lds_acc[];
+  const int lvl = lvl0 + blockIdx.y;
+  const unsigned size = L.size[lvl], offset = L.offset[lvl];
+  if (in_lds) {
+    for (unsigned i = threadIdx.x; i < 2 * size; i += blockDim.x) lds_acc[i] = 0.0f;
+    __syncthreads();
+  }
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
     const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0], g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1];
     if (g0 == 0.0f && g1 == 0.0f) continue;
     const Corner c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      atomicAdd(d_table + 2 * (size_t)c.idx[k] + 0, c.w[k] * g0);
-      atomicAdd(d_table + 2 * (size_t)c.idx[k] + 1, c.w[k] * g1);
+      if (in_lds) {
+        atomicAdd(lds_acc + 2 * (c.idx[k] - offset) + 0, c.w[k] * g0);
+        atomicAdd(lds_acc + 2 * (c.idx[k] - offset) + 1, c.w[k] * g1);
+      } else {
+        atomicAdd(d_table + 2 * (size_t)c.idx[k] + 0, c.w[k] * g0);
+        atomicAdd(d_table + 2 * (size_t)c.idx[k] + 1, c.w[k] * g1);
+      }
+    }
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < 2 * size; i += blockDim.x) {
+      const float v = lds_acc[i];
+      if (v != 0.0f) atomicAdd(d_table + 2 * (size_t)offset + i, v);
     }
   }
 }
@@ -164,8 +187,25 @@ extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, c
   HashLevels L;
   int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
   if (rc != NERF_OK) return rc;
-  int64_t blocks = (n * n_levels + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(hash_bwd_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), pts, n, L, d_feat, d_table);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)hash_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEntries * 8) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  int n_small = 0;                      // leading levels whose table fits in LDS
+  while (n_small < n_levels && size_host[n_small] <= (unsigned)kLdsEntries) ++n_small;
+  if (n_small > 0) {
+    int64_t bx = (n + 511) / 512;
+    if (bx > 128) bx = 128;             // each workgroup flushes its whole LDS table once
+    hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((int)bx, n_small), dim3(512), kLdsEntries * 8, as_stream(stream), pts, n, L, 0,
+                       d_feat, d_table);
+  }
+  if (n_small < n_levels) {
+    int64_t bx = (n + 511) / 512;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((int)bx, n_levels - n_small), dim3(512), 0, as_stream(stream), pts, n, L,
+                       n_small, d_feat, d_table);
+  }
   return check_launch("nerf_hash_encode_bwd");
 }
