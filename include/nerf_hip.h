@@ -59,6 +59,19 @@ int nerf_sample_rays(const float* rays_o, const float* rays_d, const float* u,
 int nerf_active_mask(const float* pts, int64_t n, const uint8_t* binary_grid, int resolution,
                      float bound, uint8_t* mask_out, int64_t* idx_out, nerf_stream_t stream);
 
+/* ---- a1-a4: occupancy-masked sampling with in-kernel compaction ---------------------
+ * replaces the density-grid branch of render_rays (src/renderer.py:303-343): sample_stratified
+ * + pts + get_active_mask + boolean-index gather (+ the zero-filled scatter, which the *_indexed
+ * compositing entry points make unnecessary).
+ *   z_out [R,S]; slot_of_sample [R*S] int32: row of the sample in the compact arrays, -1 = skipped;
+ *   pts_compact / dirs_compact [capacity >= R*S rows, 3] (only the first *active_count rows are
+ *   written; dirs are unit view directions); active_count: device u32.
+ * z and the voxel test are bit-exact w.r.t. nerf_sample_rays + nerf_active_mask. */
+int nerf_sample_compact(const float* rays_o, const float* rays_d, const float* u, int64_t n_rays,
+                        int n_samples, float near_plane, float far_plane, const uint8_t* binary_grid,
+                        int resolution, float bound, float* z_out, int* slot_of_sample, float* pts_compact,
+                        float* dirs_compact, unsigned* active_count, nerf_stream_t stream);
+
 /* ---- a12: occupancy-grid refresh -----------------------------------------------
  * replaces the lattice construction and the grid / binary_grid update of
  * DensityGrid.update (src/renderer.py:49-54, 118-132); the sigma query in between goes through
@@ -99,6 +112,19 @@ int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z, con
                        const float* g_rgb, const float* g_depth, const float* g_acc,
                        const float* g_extra, int64_t n_rays, int n_samples,
                        float* d_rgb, float* d_sigma, float* d_extra, nerf_stream_t stream);
+
+/* compositing straight from compact field outputs: sample (r,s) reads row slot_of_sample[r*S+s] of
+ * rgb_compact [n_active,3] / sigma_compact [n_active]; skipped samples count as sigma = 0, rgb = 0
+ * (src/renderer.py:328-333).  The backward writes d_rgb_compact / d_sigma_compact rows only. */
+int nerf_composite_fwd_indexed(const float* rgb_compact, const float* sigma_compact, const int* slot_of_sample,
+                               const float* z, const float* rays_d, const float* bg, int64_t bg_rows,
+                               int64_t n_rays, int n_samples, float* out_rgb, float* out_depth,
+                               float* out_acc, nerf_stream_t stream);
+int nerf_composite_bwd_indexed(const float* rgb_compact, const float* sigma_compact, const int* slot_of_sample,
+                               const float* z, const float* rays_d, const float* bg, int64_t bg_rows,
+                               const float* g_rgb, const float* g_depth, const float* g_acc, int64_t n_rays,
+                               int n_samples, float* d_rgb_compact, float* d_sigma_compact,
+                               nerf_stream_t stream);
 
 /* ---- a6: fused Fourier-encode + 8x256 density/colour decoder (bf16 MFMA) ----
  * replaces NeuralField.forward for mode part2_nerf (src/core.py:354-359) =

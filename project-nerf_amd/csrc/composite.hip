@@ -18,10 +18,16 @@ struct RayCtx {
 };
 
 // loads sigma/z for the lane's K samples of ray r and builds alpha / transmittance
+// slot map: sample (r, s) lives at row slots[r*S+s] of the compact rgb/sigma arrays, or is skipped
+// (slot < 0: sigma = 0, rgb = 0); without a map the arrays are dense [R,S]
+__device__ __forceinline__ int64_t row_of(const int* __restrict__ slots, int64_t dense_index) {
+  return slots == nullptr ? dense_index : (int64_t)slots[dense_index];
+}
+
 template <int K>
 __device__ __forceinline__ void ray_setup(const float* __restrict__ sigma, const float* __restrict__ z,
-                                          const float* __restrict__ rays_d, int64_t r, int S, int lane,
-                                          RayCtx& c, float* sig_out) {
+                                          const float* __restrict__ rays_d, const int* __restrict__ slots,
+                                          int64_t r, int S, int lane, RayCtx& c, float* sig_out, int64_t* row_out) {
   const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
   const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
   const int s0 = lane * K;
@@ -36,7 +42,9 @@ __device__ __forceinline__ void ray_setup(const float* __restrict__ sigma, const
   for (int k = 0; k < K; ++k) {
     const int s = s0 + k;
     const bool valid = s < S;
-    const float sg = valid ? sigma[r * S + s] : 0.0f;
+    const int64_t row = valid ? row_of(slots, r * S + s) : -1;
+    row_out[k] = row;
+    const float sg = row >= 0 ? sigma[row] : 0.0f;
     sig_out[k] = sg;
     float dl = (s < S - 1) ? (zn[k + 1] - zn[k]) : 1e10f;   // src/renderer.py:213-214
     dl = dl * dnorm;
@@ -71,8 +79,8 @@ __global__ void __launch_bounds__(256)
 composite_fwd_kernel(const float* __restrict__ rgb, const float* __restrict__ sigma,
                      const float* __restrict__ z, const float* __restrict__ rays_d,
                      const float* __restrict__ bg, int64_t bg_rows, const float* __restrict__ extra,
-                     int64_t R, int S, float* __restrict__ out_rgb, float* __restrict__ out_depth,
-                     float* __restrict__ out_acc, float* __restrict__ extra_map,
+                     const int* __restrict__ slots, int64_t R, int S, float* __restrict__ out_rgb,
+                     float* __restrict__ out_depth, float* __restrict__ out_acc, float* __restrict__ extra_map,
                      float* __restrict__ weights_out) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
@@ -80,21 +88,24 @@ composite_fwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
   for (int64_t r = wave; r < R; r += nwave) {
     RayCtx c;
     float sg[K];
-    ray_setup<K>(sigma, z, rays_d, r, S, lane, c, sg);
+    int64_t row[K];
+    ray_setup<K>(sigma, z, rays_d, slots, r, S, lane, c, sg, row);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f, aw = 0.f, x0 = 0.f, x1 = 0.f, x2 = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int s = lane * K + k;
       if (s < S) {
         const float w = c.alpha[k] * c.T[k];
-        const float* p = rgb + (r * S + s) * 3;
-        a0 += w * p[0];
-        a1 += w * p[1];
-        a2 += w * p[2];
+        if (row[k] >= 0) {
+          const float* p = rgb + row[k] * 3;
+          a0 += w * p[0];
+          a1 += w * p[1];
+          a2 += w * p[2];
+        }
         ad += w * c.z[k];
         aw += w;
-        if (extra != nullptr) {
-          const float* q = extra + (r * S + s) * 3;
+        if (extra != nullptr && row[k] >= 0) {
+          const float* q = extra + row[k] * 3;
           x0 += w * q[0];
           x1 += w * q[1];
           x2 += w * q[2];
@@ -135,7 +146,8 @@ composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
                      const float* __restrict__ z, const float* __restrict__ rays_d,
                      const float* __restrict__ bg, int64_t bg_rows, const float* __restrict__ extra,
                      const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
-                     const float* __restrict__ g_acc, const float* __restrict__ g_extra, int64_t R, int S,
+                     const float* __restrict__ g_acc, const float* __restrict__ g_extra,
+                     const int* __restrict__ slots, int64_t R, int S,
                      float* __restrict__ d_rgb, float* __restrict__ d_sigma, float* __restrict__ d_extra) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
@@ -143,7 +155,8 @@ composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
   for (int64_t r = wave; r < R; r += nwave) {
     RayCtx c;
     float sg[K];
-    ray_setup<K>(sigma, z, rays_d, r, S, lane, c, sg);
+    int64_t row[K];
+    ray_setup<K>(sigma, z, rays_d, slots, r, S, lane, c, sg, row);
     const float gr0 = g_rgb[r * 3 + 0], gr1 = g_rgb[r * 3 + 1], gr2 = g_rgb[r * 3 + 2];
     const float gd = g_depth ? g_depth[r] : 0.0f;
     float ga = g_acc ? g_acc[r] : 0.0f;
@@ -161,18 +174,21 @@ composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
       G[k] = 0.0f;
       w[k] = 0.0f;
       if (s < S) {
-        const float* p = rgb + (r * S + s) * 3;
         w[k] = c.alpha[k] * c.T[k];
-        float g = gr0 * p[0] + gr1 * p[1] + gr2 * p[2] + gd * c.z[k] + ga;
-        float* o = d_rgb + (r * S + s) * 3;
-        o[0] = w[k] * gr0;
-        o[1] = w[k] * gr1;
-        o[2] = w[k] * gr2;
-        if (extra != nullptr && g_extra != nullptr) {
-          const float* q = extra + (r * S + s) * 3;
+        float g = gd * c.z[k] + ga;
+        if (row[k] >= 0) {
+          const float* p = rgb + row[k] * 3;
+          g += gr0 * p[0] + gr1 * p[1] + gr2 * p[2];
+          float* o = d_rgb + row[k] * 3;
+          o[0] = w[k] * gr0;
+          o[1] = w[k] * gr1;
+          o[2] = w[k] * gr2;
+        }
+        if (extra != nullptr && g_extra != nullptr && row[k] >= 0) {
+          const float* q = extra + row[k] * 3;
           g += gx0 * q[0] + gx1 * q[1] + gx2 * q[2];
           if (d_extra != nullptr) {
-            float* oe = d_extra + (r * S + s) * 3;
+            float* oe = d_extra + row[k] * 3;
             oe[0] = w[k] * gx0;
             oe[1] = w[k] * gx1;
             oe[2] = w[k] * gx2;
@@ -187,9 +203,9 @@ composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
 #pragma unroll
     for (int k = K - 1; k >= 0; --k) {
       const int s = lane * K + k;
-      if (s < S) {
+      if (s < S && row[k] >= 0) {
         const float dalpha = G[k] * c.T[k] - after / c.q[k];
-        d_sigma[r * S + s] = dalpha * c.delta[k] * c.e[k];
+        d_sigma[row[k]] = dalpha * c.delta[k] * c.e[k];
       }
       after += G[k] * w[k];
     }
@@ -210,11 +226,10 @@ using namespace nerf;
     default: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
   }
 
-extern "C" int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z,
-                                  const float* rays_d, const float* bg, int64_t bg_rows,
-                                  const float* extra, int64_t n_rays, int n_samples, float* out_rgb,
-                                  float* out_depth, float* out_acc, float* extra_map,
-                                  float* weights_out, nerf_stream_t stream) {
+static int composite_fwd_impl(const float* rgb, const float* sigma, const float* z, const float* rays_d,
+                              const float* bg, int64_t bg_rows, const float* extra, const int* slots,
+                              int64_t n_rays, int n_samples, float* out_rgb, float* out_depth, float* out_acc,
+                              float* extra_map, float* weights_out, nerf_stream_t stream) {
   NERF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 64 * kMaxPerLane,
                "nerf_composite_fwd: n_rays=%lld n_samples=%d (max %d)", (long long)n_rays, n_samples,
                64 * kMaxPerLane);
@@ -227,17 +242,34 @@ extern "C" int nerf_composite_fwd(const float* rgb, const float* sigma, const fl
   int64_t blocks = (n_rays + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
   const dim3 grid((int)blocks);
-  DISPATCH_K(per_lane(n_samples), composite_fwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, extra, n_rays,
+  DISPATCH_K(per_lane(n_samples), composite_fwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, extra, slots, n_rays,
              n_samples, out_rgb, out_depth, out_acc, extra_map, weights_out);
   return check_launch("nerf_composite_fwd");
 }
 
-extern "C" int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z,
+extern "C" int nerf_composite_fwd(const float* rgb, const float* sigma, const float* z,
                                   const float* rays_d, const float* bg, int64_t bg_rows,
-                                  const float* extra, const float* g_rgb, const float* g_depth,
-                                  const float* g_acc, const float* g_extra, int64_t n_rays,
-                                  int n_samples, float* d_rgb, float* d_sigma, float* d_extra,
-                                  nerf_stream_t stream) {
+                                  const float* extra, int64_t n_rays, int n_samples, float* out_rgb,
+                                  float* out_depth, float* out_acc, float* extra_map,
+                                  float* weights_out, nerf_stream_t stream) {
+  return composite_fwd_impl(rgb, sigma, z, rays_d, bg, bg_rows, extra, nullptr, n_rays, n_samples, out_rgb, out_depth,
+                            out_acc, extra_map, weights_out, stream);
+}
+
+extern "C" int nerf_composite_fwd_indexed(const float* rgb_compact, const float* sigma_compact, const int* slot_of_sample,
+                                          const float* z, const float* rays_d, const float* bg, int64_t bg_rows,
+                                          int64_t n_rays, int n_samples, float* out_rgb, float* out_depth,
+                                          float* out_acc, nerf_stream_t stream) {
+  NERF_REQUIRE(n_rays == 0 || slot_of_sample != nullptr, "nerf_composite_fwd_indexed: slot map is NULL");
+  return composite_fwd_impl(rgb_compact, sigma_compact, z, rays_d, bg, bg_rows, nullptr, slot_of_sample, n_rays, n_samples,
+                            out_rgb, out_depth, out_acc, nullptr, nullptr, stream);
+}
+
+static int composite_bwd_impl(const float* rgb, const float* sigma, const float* z, const float* rays_d,
+                              const float* bg, int64_t bg_rows, const float* extra, const float* g_rgb,
+                              const float* g_depth, const float* g_acc, const float* g_extra, const int* slots,
+                              int64_t n_rays, int n_samples, float* d_rgb, float* d_sigma, float* d_extra,
+                              nerf_stream_t stream) {
   NERF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 64 * kMaxPerLane,
                "nerf_composite_bwd: n_rays=%lld n_samples=%d", (long long)n_rays, n_samples);
   if (n_rays == 0) return NERF_OK;
@@ -248,6 +280,26 @@ extern "C" int nerf_composite_bwd(const float* rgb, const float* sigma, const fl
   if (blocks > 256 * 8) blocks = 256 * 8;
   const dim3 grid((int)blocks);
   DISPATCH_K(per_lane(n_samples), composite_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, extra, g_rgb,
-             g_depth, g_acc, g_extra, n_rays, n_samples, d_rgb, d_sigma, d_extra);
+             g_depth, g_acc, g_extra, slots, n_rays, n_samples, d_rgb, d_sigma, d_extra);
   return check_launch("nerf_composite_bwd");
+}
+
+extern "C" int nerf_composite_bwd(const float* rgb, const float* sigma, const float* z,
+                                  const float* rays_d, const float* bg, int64_t bg_rows,
+                                  const float* extra, const float* g_rgb, const float* g_depth,
+                                  const float* g_acc, const float* g_extra, int64_t n_rays,
+                                  int n_samples, float* d_rgb, float* d_sigma, float* d_extra,
+                                  nerf_stream_t stream) {
+  return composite_bwd_impl(rgb, sigma, z, rays_d, bg, bg_rows, extra, g_rgb, g_depth, g_acc, g_extra, nullptr, n_rays,
+                            n_samples, d_rgb, d_sigma, d_extra, stream);
+}
+
+extern "C" int nerf_composite_bwd_indexed(const float* rgb_compact, const float* sigma_compact, const int* slot_of_sample,
+                                          const float* z, const float* rays_d, const float* bg, int64_t bg_rows,
+                                          const float* g_rgb, const float* g_depth, const float* g_acc, int64_t n_rays,
+                                          int n_samples, float* d_rgb_compact, float* d_sigma_compact,
+                                          nerf_stream_t stream) {
+  NERF_REQUIRE(n_rays == 0 || slot_of_sample != nullptr, "nerf_composite_bwd_indexed: slot map is NULL");
+  return composite_bwd_impl(rgb_compact, sigma_compact, z, rays_d, bg, bg_rows, nullptr, g_rgb, g_depth, g_acc, nullptr,
+                            slot_of_sample, n_rays, n_samples, d_rgb_compact, d_sigma_compact, nullptr, stream);
 }

@@ -68,6 +68,66 @@ def active_mask(pts: Tensor, binary_grid: Tensor, bound: float, want_index: bool
     return (mask, idx) if want_index else mask
 
 
+# --------------------------------------------------------------------------- a1-a4 fused
+def sample_compact(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_samples: int,
+                   binary_grid: Tensor, bound: float, u: Optional[Tensor] = None):
+    """z [R,S], slot_of_sample [R*S] (int32, -1 = skipped), pts [n_act,3], dirs [n_act,3].
+    One host read of the active count (the reference syncs at the same place: ``.any()`` and the
+    boolean-index gathers, renderer.py:309-323)."""
+    lib = _lib.load()
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    grid = _dev(binary_grid, "binary_grid", torch.bool)
+    R = rays_o.shape[0]
+    n = R * n_samples
+    if u is not None:
+        u = _dev(u, "u")
+    z = torch.empty(R, n_samples, device=rays_o.device)
+    slots = torch.empty(n, device=rays_o.device, dtype=torch.int32)
+    pts = torch.empty(max(n, 1), 3, device=rays_o.device)
+    dirs = torch.empty(max(n, 1), 3, device=rays_o.device)
+    count = torch.zeros(1, device=rays_o.device, dtype=torch.int32)
+    _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
+                                       float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),
+               "nerf_sample_compact")
+    n_act = int(count.item())
+    return z, slots, pts[:n_act], dirs[:n_act]
+
+
+class _CompositeIndexed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_c, sigma_c, slots, z, rays_d, bg):
+        lib = _lib.load()
+        R, S = z.shape
+        rgb_c, sigma_c = _dev(rgb_c, "rgb_c"), _dev(sigma_c, "sigma_c")
+        out_rgb = torch.empty(R, 3, device=z.device)
+        depth = torch.empty(R, device=z.device)
+        acc = torch.empty(R, device=z.device)
+        bg_rows = 0 if bg is None else (1 if bg.dim() == 1 else bg.shape[0])
+        _lib.check(lib.nerf_composite_fwd_indexed(_p(rgb_c), _p(sigma_c), _p(slots), _p(z), _p(rays_d), _p(bg), bg_rows,
+                                                  R, S, _p(out_rgb), _p(depth), _p(acc), _stream()),
+                   "nerf_composite_fwd_indexed")
+        ctx.save_for_backward(rgb_c, sigma_c, slots, z, rays_d, bg)
+        return out_rgb, depth, acc
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc):
+        lib = _lib.load()
+        rgb_c, sigma_c, slots, z, rays_d, bg = ctx.saved_tensors
+        R, S = z.shape
+        d_rgb, d_sigma = torch.empty_like(rgb_c), torch.empty_like(sigma_c)
+        bg_rows = 0 if bg is None else (1 if bg.dim() == 1 else bg.shape[0])
+        _lib.check(lib.nerf_composite_bwd_indexed(_p(rgb_c), _p(sigma_c), _p(slots), _p(z), _p(rays_d), _p(bg), bg_rows,
+                                                  _p(g_rgb.contiguous()), _p(g_depth.contiguous()), _p(g_acc.contiguous()),
+                                                  R, S, _p(d_rgb), _p(d_sigma), _stream()), "nerf_composite_bwd_indexed")
+        return d_rgb, d_sigma, None, None, None, None
+
+
+def composite_indexed(rgb_c: Tensor, sigma_c: Tensor, slots: Tensor, z: Tensor, rays_d: Tensor,
+                      bg: Optional[Tensor] = None):
+    """volume_render over compact field outputs; skipped samples contribute sigma = 0."""
+    return _CompositeIndexed.apply(rgb_c, sigma_c.reshape(-1), slots, z, rays_d, bg)
+
+
 # --------------------------------------------------------------------------- a12
 def grid_lattice(bound: float, resolution: int, device) -> Tensor:
     lib = _lib.load()

@@ -76,19 +76,22 @@ def render_rays(model, rays_o, rays_d, near, far, n_samples, perturb, density_gr
         z = ops.sample_rays(rays_o, rays_d, near, far, n_samples, u=u)
         rgb, sigma = model.field_from_rays(rays_o, rays_d, z)
     else:
-        z, pts, dirs = ops.sample_rays(rays_o, rays_d, near, far, n_samples, u=u, want_points=True)
         if density_grid is not None:
-            mask = density_grid.get_active_mask(pts)
-            if not bool(mask.any()):
-                mask = mask.clone()
-                mask[0] = True              # keep the autograd graph connected (renderer.py:309-311)
-            c_rgb, c_sigma = model(pts[mask], dirs[mask])
-            rgb = c_rgb.new_zeros(pts.shape[0], 3, dtype=torch.float32)
-            sigma = c_sigma.new_zeros(pts.shape[0], 1, dtype=torch.float32)
-            rgb[mask] = c_rgb.float()
-            sigma[mask] = c_sigma.float().reshape(-1, 1)
-        else:
-            rgb, sigma = model(pts, dirs)
+            # a1-a4 in one kernel: depths, points, occupancy test, compaction of the active samples
+            z, slots, pts, dirs = ops.sample_compact(rays_o, rays_d, near, far, n_samples, density_grid.binary_grid,
+                                                     density_grid.bound, u=u)
+            if pts.shape[0] == 0:
+                # nothing active: query sample 0 anyway so the autograd graph stays connected
+                # (reference renderer.py:309-311)
+                _, p_all, d_all = ops.sample_rays(rays_o[:1], rays_d[:1], near, far, n_samples,
+                                                  u=None if u is None else u[:1].contiguous(), want_points=True)
+                pts, dirs = p_all[:1].contiguous(), d_all[:1].contiguous()
+                slots = slots.clone()
+                slots[0] = 0
+            c_rgb, c_sigma = model(pts, dirs)
+            return ops.composite_indexed(c_rgb.float(), c_sigma.float(), slots, z, rays_d, bg_color)
+        z, pts, dirs = ops.sample_rays(rays_o, rays_d, near, far, n_samples, u=u, want_points=True)
+        rgb, sigma = model(pts, dirs)
     rgb = rgb.float().view(n_rays, n_samples, 3)
     sigma = sigma.float().view(n_rays, n_samples)
     return volume_render(rgb, sigma, z, rays_d, bg_color=bg_color)

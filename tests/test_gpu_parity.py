@@ -335,3 +335,58 @@ def test_adam_and_adamw_vs_reference_golden(ops):
                 lr = lr0 if name == "adam" else O.cosine_lr(1e-2, 1e-4, step, 2000)
                 ops.adam_step(p, dev(g[f"grads_p{k}"][step]).reshape(-1), m, v, step + 1, lr, weight_decay=wd)
             np.testing.assert_allclose(p.cpu().numpy(), g[f"{name}_p{k}"].reshape(-1), rtol=3e-6, atol=2e-7)
+
+
+# ------------------------------------------------------------------ a1-a4 fused
+@pytest.mark.parametrize("perturb", [False, True])
+def test_sample_compact_matches_separate_kernels(ops, perturb):
+    R, S = 77, 64
+    o, d = synth_rays(R, 23)
+    gen = torch.Generator().manual_seed(3)
+    bits = torch.rand(128, 128, 128, generator=gen) < 0.2
+    u = torch.rand(R, S, generator=gen) if perturb else None
+    ud = None if u is None else dev(u)
+    z_ref, pts, dirs = ops.sample_rays(dev(o), dev(d), 2.0, 6.0, S, u=ud, want_points=True)
+    mask = ops.active_mask(pts, dev(bits), 1.5)
+    z, slots, pts_c, dirs_c = ops.sample_compact(dev(o), dev(d), 2.0, 6.0, S, dev(bits), 1.5, u=ud)
+    assert torch.equal(z, z_ref)                                   # depths: bit-exact
+    assert torch.equal(slots >= 0, mask)                           # same voxel test, bit-exact
+    n_act = int(mask.sum())
+    assert pts_c.shape == (n_act, 3) and n_act > 0
+    act = slots[mask].long()
+    assert torch.equal(torch.sort(act).values, torch.arange(n_act, device="cuda"))   # a permutation
+    assert torch.equal(pts_c[act], pts[mask])                      # every active sample landed in its slot
+    np.testing.assert_allclose(dirs_c[act].cpu().numpy(), dirs[mask].cpu().numpy(), rtol=2e-7)
+
+
+def test_composite_indexed_equals_zero_filled_scatter(ops):
+    """reference renderer.py:328-343: scatter into zeros then volume_render == compositing through the slot map."""
+    R, S = 41, 64
+    gen = torch.Generator().manual_seed(8)
+    z = dev(O.stratified_depths(2.0, 6.0, S, R, True, u=torch.rand(R, S, generator=gen)).contiguous())
+    _, d = synth_rays(R, 9)
+    mask = torch.rand(R * S, generator=gen) < 0.3
+    mask[:S] = False                                               # one ray with nothing active
+    n_act = int(mask.sum())
+    perm = torch.randperm(n_act, generator=gen)
+    slots = torch.full((R * S,), -1, dtype=torch.int32)
+    slots[mask] = perm.int()
+    rgb_c = torch.rand(n_act, 3, generator=gen)
+    sig_c = torch.rand(n_act, generator=gen) * 5
+    bg = torch.tensor([0.3, 0.6, 0.9])
+    # dense reference through the oracle
+    rgb_d = torch.zeros(R * S, 3); sig_d = torch.zeros(R * S)
+    rc, sc = rgb_c.clone().requires_grad_(True), sig_c.clone().requires_grad_(True)
+    rgb_d = rgb_d.index_put((torch.nonzero(mask)[:, 0],), rc[perm])
+    sig_d = sig_d.index_put((torch.nonzero(mask)[:, 0],), sc[perm])
+    c_ref, dep_ref, acc_ref = O.composite(rgb_d.view(R, S, 3), sig_d.view(R, S), z.cpu(), d, bg)
+    g1, g2, g3 = torch.rand(R, 3, generator=gen), torch.rand(R, generator=gen) * .1, torch.rand(R, generator=gen) * .1
+    ((c_ref * g1).sum() + (dep_ref * g2).sum() + (acc_ref * g3).sum()).backward()
+    rg, sg = dev(rgb_c).requires_grad_(True), dev(sig_c).requires_grad_(True)
+    c, dep, acc = ops.composite_indexed(rg, sg, dev(slots), z, dev(d), dev(bg))
+    np.testing.assert_allclose(c.detach().cpu().numpy(), c_ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(acc.detach().cpu().numpy(), acc_ref.detach().numpy(), rtol=2e-5, atol=2e-6)
+    ((c * dev(g1)).sum() + (dep * dev(g2)).sum() + (acc * dev(g3)).sum()).backward()
+    np.testing.assert_allclose(rg.grad.cpu().numpy(), rc.grad.numpy(), rtol=3e-5, atol=1e-7)
+    ref = sc.grad.numpy()
+    assert np.max(np.abs(sg.grad.cpu().numpy() - ref)) < 5e-5 * max(1.0, np.abs(ref).max())
