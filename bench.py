@@ -82,62 +82,44 @@ def cpu_baseline(rays, samples, threads):
 
 
 def bench_instant(args, device):
-    """Secondary line: Instant-NGP variant (BASELINE.json configs[2]) through the module surface
-    (NeuralField + DensityGrid + render_rays + AdamW), on the synthetic Blender-format scene:
+    """Secondary line: Instant-NGP variant (BASELINE.json configs[2]) on the flat-parameter engine
+    (same kernels as NeuralField + DensityGrid + render_rays + AdamW), synthetic Blender-format scene:
     wall time to PSNR, train rays/s in steady state (occupancy grid active), 800x800 render FPS."""
     import tempfile
     import numpy as np
     import yaml
-    from src.core import NeuralField
     from src.dataset import BlenderDataset, look_at_pose, write_synthetic_scene
-    from src.renderer import DensityGrid, render_rays
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
     root = write_synthetic_scene(tempfile.mkdtemp() + "/scene", n_train=40, n_test=4, size=200)
     ds = BlenderDataset(root, "train", 1, True, 1.0).to(device)
     test = BlenderDataset(root, "test", 1, True, 1.0)
-    torch.manual_seed(0)
-    model = NeuralField(cfg).to(device)
-    grid = DensityGrid(128, 1.5, 0.12).to(device)
+    from project_nerf_amd.engine import InstantNgpEngine
     iters, batch, S = 1000, 16384, 128
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=1e-5)
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=1e-4)
-    bg = torch.ones(3, device=device)
+    cfg["train_iters"] = iters
+    torch.manual_seed(0)
+    eng = InstantNgpEngine(cfg, device=str(device), seed=0)
 
     def psnr():
-        model.eval()
         vals = []
-        with torch.no_grad():
-            for i in range(len(test)):
-                o, d, tgt = test.get_image_rays(i, device)
-                img = render_rays(model, o.reshape(-1, 3), d.reshape(-1, 3), 2.0, 6.0, S, False, density_grid=grid)[0]
-                vals.append(-10 * np.log10(float(((img.clamp(0, 1) - tgt.reshape(-1, 3)) ** 2).mean())))
-        model.train()
+        for i in range(len(test)):
+            o, d, tgt = test.get_image_rays(i, device)
+            img = eng.render_image(o, d, S)
+            vals.append(-10 * np.log10(float(((img.clamp(0, 1) - tgt) ** 2).mean())))
         return float(np.mean(vals))
 
     def step():
         o, d, rgba = ds.sample_random_rays(batch, device)
         target = rgba[:, :3] * rgba[:, 3:4] + (1 - rgba[:, 3:4])
-        pred, _, _ = render_rays(model, o, d, 2.0, 6.0, S, True, density_grid=grid, bg_color=bg)
-        loss = torch.nn.functional.mse_loss(pred, target)
-        p = model.representation.encoding.params
-        loss = loss + torch.mean(torch.abs(p[1:] - p[:-1])) * 1e-6
-        opt.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.representation.parameters(), 1.0)
-        torch.nn.utils.clip_grad_norm_(model.decoder.parameters(), 1.0)
-        opt.step()
-        sched.step()
+        return eng.train_step(o, d, target, S)
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     curve, active = [], 1.0
     for it in range(1, iters + 1):
         step()
-        interval = 32 if it < iters * 0.1 else (128 if it < iters * 0.5 else 512)
-        if it < iters * 0.9 and grid.should_update(it, interval, 256):
-            model.eval()
-            active = grid.update(model, device=device)
-            model.train()
+        interval = 32 if it < iters * 0.1 else (128 if it < iters * 0.5 else 512)      # run.py:636-641
+        if it < iters * 0.9 and it >= 256 and it % interval == 0:
+            active = eng.update_grid()
         if it in (300, 600, 1000):
             torch.cuda.synchronize()
             curve.append({"step": it, "train_seconds": time.perf_counter() - t0, "test_psnr_db": psnr()})
@@ -154,17 +136,13 @@ def bench_instant(args, device):
     dd = torch.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -torch.ones_like(i)], -1).reshape(-1, 3).float() @ c2w[:3, :3].T
     dd = (dd / dd.norm(dim=-1, keepdim=True)).to(device)
     oo = c2w[:3, 3].expand_as(dd).contiguous().to(device)
-    model.eval()
-    with torch.no_grad():
-        frame = lambda: torch.cat([render_rays(model, oo[k:k + 200000], dd[k:k + 200000], 2.0, 6.0, S, False, density_grid=grid)[0]
-                                   for k in range(0, H * W, 200000)])
-        frame()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.render_frames):
-            frame()
-        torch.cuda.synchronize()
-        rt = (time.perf_counter() - t1) / args.render_frames
+    eng.render_image(oo, dd, S)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.render_frames):
+        eng.render_image(oo, dd, S)
+    torch.cuda.synchronize()
+    rt = (time.perf_counter() - t1) / args.render_frames
     print(json.dumps({
         "metric": "train rays/sec + 800x800 render FPS, NeRF-Synthetic Lego; PSNR parity", "value": batch * args.steps / dt,
         "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": iters, "ms_per_step": dt / args.steps * 1e3,

@@ -225,6 +225,19 @@ int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp
                    int64_t n, int step, float lr, float beta1, float beta2, float eps,
                    float weight_decay, const float* grad_scale_dev, nerf_stream_t stream);
 
+/* Fused regulariser + global-norm clip + AdamW for one flat parameter group:
+ * replaces, per group, the TV-L1 term on `representation.encoding.params` and its backward
+ * (run.py:611-618), clip_grad_norm_(group, max_norm) (run.py:624-627) and AdamW.step() (run.py:629).
+ *   nerf_tv_normsq      : grads += tv_weight * d/dp mean|p[1:] - p[:-1]|  (tv_weight 0: skip), then
+ *                         *normsq_dev = sum(grads^2)                       (device fp32 scalar)
+ *   nerf_adamw_clip_step: AdamW with grads scaled by grad_scale * min(1, max_norm / (norm + 1e-6)),
+ *                         norm = grad_scale * sqrt(*normsq_dev); normsq_dev NULL or max_norm <= 0: no clip. */
+int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float* normsq_dev,
+                   nerf_stream_t stream);
+int nerf_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         const float* normsq_dev, float max_norm, float grad_scale, nerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ PROTOTYPES = {
     "nerf_imlp_fwd": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
     "nerf_imlp_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_adam_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, c_ptr]),
+    "nerf_tv_normsq": (i32, [c_ptr, c_ptr, i64, f32, c_ptr, c_ptr]),
+    "nerf_adamw_clip_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr]),
 }
 
 _lib = None

@@ -144,3 +144,141 @@ class VanillaNerfEngine:
         for i in range(0, o.shape[0], chunk):
             out[i:i + chunk] = self.render_rays(o[i:i + chunk], d[i:i + chunk], n_samples)[0]
         return out.view(*shape, 3)
+
+
+class InstantNgpEngine:
+    """Flat-parameter training / rendering engine for mode part2_instant: the per-step work of
+    reference run_part2_instant (run.py:579-646) as one kernel sequence with no torch autograd or
+    optimiser objects in the loop:
+
+        sample+mask+compact -> hash encode -> tiny MLPs (+stash) -> indexed composite -> MSE grad
+        -> indexed composite bwd -> tiny-MLP dgrad/wgrad -> hash scatter -> [all-reduce]
+        -> TV + clip + AdamW (table) , clip + AdamW (nets) -> repack ; cosine LR on the host.
+    """
+
+    def __init__(self, cfg: Optional[dict] = None, device: str = "cuda", seed: int = 0, world_size: int = 1):
+        cfg = dict(cfg or {})
+        self.device = torch.device(device)
+        self.bound = float(cfg.get("scene_bound", 1.5))
+        self.levels = ops.HashLevelTable(cfg.get("n_levels", 16), cfg.get("log2_hashmap_size", 19),
+                                         cfg.get("base_resolution", 16), cfg.get("per_level_scale", 1.5))
+        g = torch.Generator().manual_seed(seed)
+        self.table = ((torch.rand(self.levels.entries * 2, generator=g) * 2 - 1) * 1e-4).to(self.device)
+
+        def xavier(rows, cols, fi, fo):
+            return (torch.rand(rows, cols, generator=g) * 2 - 1) * (6.0 / (fi + fo)) ** 0.5
+        w1 = xavier(64, 48, 43, 64)
+        w1[:, 43:] = 0
+        w3 = xavier(16, 64, 64, 3)
+        w3[3:] = 0
+        self.net = torch.cat([xavier(64, 32, 32, 64).reshape(-1), xavier(16, 64, 64, 16).reshape(-1), w1.reshape(-1),
+                              xavier(64, 64, 64, 64).reshape(-1), w3.reshape(-1)]).to(self.device)
+        self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in (("table", self.table), ("net", self.net))}
+        self.g_table = torch.zeros_like(self.table)
+        self.g_net = torch.empty_like(self.net)
+        self.packed = ops.imlp_pack(self.net)
+        self.near, self.far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
+        self.lr0, self.eta_min = float(cfg.get("learning_rate", 1e-2)), float(cfg.get("eta_min", 1e-4))
+        self.t_max = int(cfg.get("train_iters", 2000))
+        self.wd = float(cfg.get("weight_decay", 1e-5))
+        self.tv_weight = float(cfg.get("tv_loss_weight", 1e-6)) if cfg.get("use_tv_loss", True) else 0.0
+        self.bg = (torch.ones(3) if cfg.get("white_bkgd", True) else torch.zeros(3)).to(self.device)
+        res = int(cfg.get("grid_resolution", 128))
+        self.grid_threshold = float(cfg.get("grid_threshold", 0.12))
+        self.grid = torch.zeros(res, res, res, device=self.device)
+        self.binary_grid = torch.ones(res, res, res, dtype=torch.bool, device=self.device)
+        self.step_count, self.world_size = 0, world_size
+        self._scratch = torch.empty(1, device=self.device)
+
+    def lr(self) -> float:
+        import math
+        return self.eta_min + (self.lr0 - self.eta_min) * (1 + math.cos(math.pi * self.step_count / self.t_max)) / 2
+
+    def _field(self, pts: Tensor, dirs: Tensor, train: bool):
+        lib = ops._lib.load()
+        n = pts.shape[0]
+        ws = torch.empty(lib.nerf_imlp_workspace_bytes(n), device=self.device, dtype=torch.uint8)
+        ops.hash_encode_fwd(pts, self.table.view(-1, 2), self.levels, self.bound, want_f32=False, out_nat=ws)
+        rgb, sigma = torch.empty(n, 3, device=self.device), torch.empty(n, device=self.device)
+        ops._lib.check(lib.nerf_imlp_fwd(self.packed.data_ptr(), ws.data_ptr(), dirs.data_ptr(), n, rgb.data_ptr(),
+                                         sigma.data_ptr(), 1 if train else 0, ops._stream()), "nerf_imlp_fwd")
+        return rgb, sigma, ws
+
+    def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
+                   u: Optional[Tensor] = None, sync_grads=None) -> Tensor:
+        lib = ops._lib.load()
+        R = rays_o.shape[0]
+        if u is None:
+            u = torch.rand(R, n_samples, device=self.device)
+        z, slots, pts, dirs = ops.sample_compact(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid,
+                                                 self.bound, u=u)
+        n = pts.shape[0]
+        self.g_table.zero_()
+        if n == 0:
+            self.g_net.zero_()
+            pred = self.bg.expand(R, 3)
+            loss = ((pred - target) ** 2).mean()
+        else:
+            rgb, sigma, ws = self._field(pts, dirs, True)
+            bg_rows = 1
+            pred, depth, acc = (torch.empty(R, 3, device=self.device), torch.empty(R, device=self.device),
+                                torch.empty(R, device=self.device))
+            P = lambda t: t.data_ptr()
+            ops._lib.check(lib.nerf_composite_fwd_indexed(P(rgb), P(sigma), P(slots), P(z), P(rays_d), P(self.bg), bg_rows,
+                                                          R, n_samples, P(pred), P(depth), P(acc), ops._stream()),
+                           "nerf_composite_fwd_indexed")
+            diff = pred - target
+            loss = (diff * diff).mean()
+            g_pred = (diff * (2.0 / diff.numel())).contiguous()
+            d_rgb, d_sigma = torch.empty_like(rgb), torch.empty_like(sigma)
+            ops._lib.check(lib.nerf_composite_bwd_indexed(P(rgb), P(sigma), P(slots), P(z), P(rays_d), P(self.bg), bg_rows,
+                                                          P(g_pred), None, None, R, n_samples, P(d_rgb), P(d_sigma),
+                                                          ops._stream()), "nerf_composite_bwd_indexed")
+            d_feat = torch.empty(n, 2 * self.levels.n_levels, device=self.device)
+            ops._lib.check(lib.nerf_imlp_bwd(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
+                                             P(self.g_net), P(d_feat), ops._stream()), "nerf_imlp_bwd")
+            ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table)
+        if sync_grads is not None:
+            sync_grads(self.g_table)
+            sync_grads(self.g_net)
+        lr = self.lr()
+        self.step_count += 1
+        scale = 1.0 / self.world_size
+        ops.tv_clip_adamw_step(self.table, self.g_table, *self.state["table"], self.step_count, lr, tv_weight=self.tv_weight,
+                               max_norm=1.0, weight_decay=self.wd, grad_scale=scale, scratch=self._scratch)
+        ops.tv_clip_adamw_step(self.net, self.g_net, *self.state["net"], self.step_count, lr, max_norm=1.0,
+                               weight_decay=self.wd, grad_scale=scale, scratch=self._scratch)
+        ops.imlp_pack(self.net, self.packed)
+        return loss
+
+    @torch.no_grad()
+    def update_grid(self) -> float:
+        """DensityGrid.update for a static field (reference src/renderer.py:35-132)."""
+        res = self.grid.shape[0]
+        pts = ops.grid_lattice(self.bound, res, self.device)
+        sig = torch.empty(res ** 3, device=self.device)
+        zeros = torch.zeros(2 ** 18, 3, device=self.device)
+        for i in range(0, pts.shape[0], 2 ** 18):
+            p = pts[i:i + 2 ** 18]
+            sig[i:i + 2 ** 18] = self._field(p, zeros[:p.shape[0]], False)[1]
+        self.grid = sig.view(res, res, res)
+        self.binary_grid, ratio = ops.grid_threshold(self.grid, self.grid_threshold)
+        return ratio
+
+    @torch.no_grad()
+    def render_rays(self, rays_o: Tensor, rays_d: Tensor, n_samples: int):
+        z, slots, pts, dirs = ops.sample_compact(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid, self.bound)
+        R = rays_o.shape[0]
+        if pts.shape[0] == 0:
+            return self.bg.expand(R, 3).clone(), torch.zeros(R, device=self.device), torch.zeros(R, device=self.device)
+        rgb, sigma, _ = self._field(pts, dirs, False)
+        return ops.composite_indexed(rgb, sigma, slots, z, rays_d, self.bg)
+
+    @torch.no_grad()
+    def render_image(self, rays_o: Tensor, rays_d: Tensor, n_samples: int, chunk: int = 200000) -> Tensor:
+        shape = rays_o.shape[:-1]
+        o, d = rays_o.reshape(-1, 3).contiguous(), rays_d.reshape(-1, 3).contiguous()
+        out = torch.empty(o.shape[0], 3, device=self.device)
+        for i in range(0, o.shape[0], chunk):
+            out[i:i + chunk] = self.render_rays(o[i:i + chunk], d[i:i + chunk], n_samples)[0]
+        return out.view(*shape, 3)

@@ -68,3 +68,20 @@ def test_ops_refuse_cpu_tensors(lib):
         ops.fourier_encode(torch.zeros(4, 3), 10)
     with pytest.raises(lib.NerfHipError):
         ops.sample_rays(torch.zeros(4, 3), torch.zeros(4, 3), 2.0, 6.0, 64)
+
+
+def test_argument_validation_returns_error_codes(lib):
+    """Bad arguments are rejected on the host side with a negative code and a message; nothing is launched."""
+    h = lib.load()
+    assert h.nerf_sample_rays(None, None, None, -1, 64, 2.0, 6.0, None, None, None, None) == -22
+    assert b"n_rays" in h.nerf_last_error()
+    assert h.nerf_sample_rays(None, None, None, 4, 1, 2.0, 6.0, None, None, None, None) == -22     # n_samples < 2
+    assert h.nerf_composite_fwd(None, None, None, None, None, 0, None, 5, 1000, None, None, None, None, None, None) == -22
+    assert b"n_samples" in h.nerf_last_error()
+    assert h.nerf_fourier_encode(None, 10, 3, 99, None, None) == -22                               # n_freq out of range
+    assert h.nerf_mlp_pack(None, None, None) == -22
+    assert h.nerf_mlp_fwd(None, None, None, None, -5, 0, None, None, None, None) == -22
+    # zero-sized work is a successful no-op
+    assert h.nerf_sample_rays(None, None, None, 0, 64, 2.0, 6.0, None, None, None, None) == 0
+    assert h.nerf_fourier_encode(None, 0, 3, 10, None, None) == 0
+    assert h.nerf_active_mask(None, 0, None, 128, 1.5, None, None, None) == 0

@@ -170,3 +170,48 @@ def test_instant_neural_field_and_training(tmp_path):
         img = render_rays(model, o.reshape(-1, 3), d.reshape(-1, 3), 2.0, 6.0, 64, False, density_grid=grid)[0]
     psnr = -10 * np.log10(float(((img - tgt.reshape(-1, 3)) ** 2).mean()))
     assert psnr > 17.0, psnr       # ~19.5 dB after 300 steps of 4096 rays on the 64x64 synthetic scene
+
+
+def test_tv_clip_adamw_vs_torch_sequence(ops):
+    """nerf_tv_normsq + nerf_adamw_clip_step == TV-L1 backward + clip_grad_norm_ + AdamW of reference run.py:611-630."""
+    g = torch.Generator().manual_seed(21)
+    n = 10007
+    p0 = torch.randn(n, generator=g) * 0.1
+    grads = [torch.randn(n, generator=g) * s for s in (0.05, 3e-3, 1e-4)]     # first one gets clipped
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=1e-2, weight_decay=1e-5)
+    p = p0.cuda().clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step, g_data in enumerate(grads, 1):
+        tv = torch.mean(torch.abs(p_ref[1:] - p_ref[:-1])) * 1e-3
+        opt.zero_grad()
+        tv.backward()
+        p_ref.grad.add_(g_data)
+        torch.nn.utils.clip_grad_norm_([p_ref], max_norm=1.0)
+        opt.step()
+        ops.tv_clip_adamw_step(p, g_data.cuda().clone(), m, v, step, 1e-2, tv_weight=1e-3, max_norm=1.0, weight_decay=1e-5)
+        np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), rtol=2e-5, atol=2e-7)
+
+
+def test_instant_engine_trains_and_renders(tmp_path):
+    from src.dataset import BlenderDataset, write_synthetic_scene
+    from project_nerf_amd.engine import InstantNgpEngine
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    cfg["train_iters"] = 400
+    root = write_synthetic_scene(str(tmp_path / "scene"), n_train=12, n_test=2, size=64)
+    ds = BlenderDataset(root, "train", 1, True, 1.0).to("cuda")
+    eng = InstantNgpEngine(cfg, seed=0)
+    torch.manual_seed(0)
+    first = None
+    for step in range(1, 401):
+        o, d, rgba = ds.sample_random_rays(4096, "cuda")
+        target = rgba[:, :3] * rgba[:, 3:4] + (1 - rgba[:, 3:4])
+        loss = eng.train_step(o, d, target, 64)
+        first = first if first is not None else loss.item()
+        if step in (128, 256):
+            assert 0.0 < eng.update_grid() < 1.0
+    assert loss.item() < 0.2 * first, (first, loss.item())
+    o, d, tgt = BlenderDataset(root, "test", 1, True, 1.0).get_image_rays(0, "cuda")
+    img = eng.render_image(o, d, 64)
+    psnr = -10 * np.log10(float(((img - tgt) ** 2).mean()))
+    assert psnr > 18.0, psnr
