@@ -1,7 +1,7 @@
 """NeuralField (reference src/core.py:9-363): mode dispatch around the HIP operators."""
 import torch.nn as nn
 
-from .decoders import NeRFDecoder
+from .decoders import NeRFDecoder, StandardMLP
 from .embeddings import FourierRepresentation
 
 
@@ -14,7 +14,12 @@ class NeuralField(nn.Module):
         self.mode = config["mode"]
         use_pe = config.get("use_positional_encoding", True)
         L = config.get("L_embed", 0) if use_pe else 0
-        if self.mode == "part2_nerf":
+        if self.mode == "part1_fourier":
+            # 2-D image fit (reference core.py:25-34): HIP Fourier features + a library-GEMM MLP
+            self.representation = FourierRepresentation(input_dim=2, L=L, use_encoding=use_pe)
+            self.decoder = StandardMLP(input_dim=self.representation.out_dim, hidden_dim=config["hidden_dim"],
+                                       output_dim=config["output_dim"], num_layers=config.get("num_layers", 3))
+        elif self.mode == "part2_nerf":
             self.representation = FourierRepresentation(input_dim=3, L=L, use_encoding=use_pe)
             use_dir = config.get("use_viewdirs", True)
             L_dir = config.get("L_embed_dir", 4) if use_dir else 0
@@ -28,10 +33,12 @@ class NeuralField(nn.Module):
             build_instant_field(self, config)
         else:
             raise NotImplementedError(
-                f"mode {self.mode!r}: only the static hot path (part2_nerf, part2_instant) is built; "
-                "part1/part3/part4 are listed as next rows in DESIGN.md")
+                f"mode {self.mode!r}: only part1_fourier and the static hot path (part2_nerf, part2_instant) are "
+                "built; part3/part4 are listed as next rows in DESIGN.md")
 
     def forward(self, x, d=None, t=None):
+        if self.mode == "part1_fourier":
+            return self.decoder(self.representation(x))
         if self.mode in ("part2_nerf", "part2_instant"):
             if d is None:
                 raise ValueError(f"{self.mode} requires view directions.")

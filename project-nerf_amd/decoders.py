@@ -7,6 +7,23 @@ from . import ops
 from .abstract import BaseDecoder
 
 
+class StandardMLP(BaseDecoder):
+    """Part 1 image-fit MLP (reference src/decoders.py:6-26): Linear/ReLU x num_layers, Linear, Sigmoid.
+    Outside the volumetric hot path (SURVEY 8 scope): plain library GEMMs through torch.nn on the
+    device; only its Fourier features go through the HIP kernel."""
+
+    def __init__(self, input_dim, hidden_dim=256, output_dim=3, num_layers=3):
+        super().__init__()
+        layers = [nn.Linear(input_dim, hidden_dim), nn.ReLU()]
+        for _ in range(num_layers - 1):
+            layers += [nn.Linear(hidden_dim, hidden_dim), nn.ReLU()]
+        layers += [nn.Linear(hidden_dim, output_dim), nn.Sigmoid()]
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.net(x)
+
+
 class NeRFDecoder(BaseDecoder):
     """8x256 MLP with skip at layer 4, sigma / feature heads, 128-wide view branch
     (reference src/decoders.py:29-87).  The HIP kernels are specialised for the reference

@@ -100,6 +100,50 @@ def run_part2(cfg, args):
     return avg
 
 
+def run_part1(cfg, args):
+    """2-D image fit (reference run.py:30-237), single configuration: HIP Fourier features + MLP."""
+    from PIL import Image
+    if not args.image:
+        raise ValueError("Part 1 requires --image")
+    if not torch.cuda.is_available():
+        raise RuntimeError("a HIP device is required")
+    device = torch.device("cuda")
+    size = cfg.get("image_size", 400)
+    img = Image.open(args.image).convert("RGB")
+    scale = min(size / img.width, size / img.height)
+    img = img.resize((int(img.width * scale), int(img.height * scale)), Image.LANCZOS)
+    arr = np.array(img) / 255.0
+    h, w, _ = arr.shape
+    coords = torch.stack(torch.meshgrid(torch.linspace(0, 1, h), torch.linspace(0, 1, w), indexing="ij"), -1).reshape(-1, 2).to(device)
+    gt = torch.tensor(arr.reshape(-1, 3), dtype=torch.float32, device=device)
+    pick = lambda v: v[0] if isinstance(v, (list, tuple)) else v
+    cfg = dict(cfg, L_embed=pick(cfg["L_embed"]), hidden_dim=pick(cfg["hidden_dim"]), num_layers=pick(cfg.get("num_layers", 3)),
+               use_positional_encoding=pick(cfg.get("use_positional_encoding", True)))
+    model = NeuralField(cfg).to(device)
+    if args.checkpoint:
+        model.load_state_dict(torch.load(args.checkpoint, map_location=device)["model_state_dict"], strict=False)
+    log_dir = os.path.join(cfg.get("log_dir", "output/"), "part1", os.path.splitext(os.path.basename(args.image))[0])
+    os.makedirs(log_dir, exist_ok=True)
+    if not args.eval_only:
+        opt = torch.optim.Adam(model.parameters(), lr=cfg["learning_rate"])
+        bs = cfg.get("batch_size")
+        for epoch in range(1, cfg["epochs"] + 1):
+            idx = slice(None) if bs is None else torch.randint(0, coords.shape[0], (bs,), device=device)
+            loss = torch.nn.functional.mse_loss(model(coords[idx]), gt[idx])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if epoch % cfg.get("log_every", 100) == 0:
+                print(f">>> Epoch {epoch}/{cfg['epochs']} | Loss {loss.item():.6f} | PSNR {compute_psnr(loss.item()):.2f} dB")
+        torch.save({"model_state_dict": model.state_dict(), "config": cfg}, os.path.join(log_dir, "model_final.pth"))
+    with torch.no_grad():
+        pred = model(coords).clamp(0, 1)
+    psnr = compute_psnr(torch.nn.functional.mse_loss(pred, gt).item())
+    Image.fromarray((pred.cpu().numpy().reshape(h, w, 3) * 255 + 0.5).astype(np.uint8)).save(os.path.join(log_dir, "final.png"))
+    print(f">>> Final PSNR: {psnr:.2f} dB")
+    return psnr
+
+
 def run_part2_instant(cfg, args):
     """Instant-NGP style training (reference run.py:396-900)."""
     from project_nerf_amd.instant import run_instant
@@ -119,12 +163,14 @@ def main():
     with open(args.config, "r", encoding="utf-8") as f:
         cfg = yaml.safe_load(f)
     mode = cfg.get("mode")
-    if mode == "part2_nerf":
+    if mode == "part1_fourier":
+        run_part1(cfg, args)
+    elif mode == "part2_nerf":
         run_part2(cfg, args)
     elif mode == "part2_instant":
         run_part2_instant(cfg, args)
     else:
-        raise ValueError(f"mode {mode!r} is outside the built hot path (part2_nerf, part2_instant); see DESIGN.md")
+        raise ValueError(f"mode {mode!r} is not built (part1_fourier, part2_nerf, part2_instant are); see DESIGN.md")
 
 
 if __name__ == "__main__":

@@ -17,7 +17,12 @@ import torch
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.dont_write_bytecode = True
+# only the reference may provide `src`: this repository ships a regular package of the same name
+# (src/__init__.py), which would shadow the reference's namespace package if it were importable
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) not in (ROOT, HERE)]
 sys.path.insert(0, REF)
+os.chdir(REF)
 
 import yaml  # noqa: E402
 from src.core import NeuralField  # noqa: E402
@@ -236,6 +241,18 @@ def g10_optim():
     save("g10_optim", **out)
 
 
+def g12_part1():
+    """configs[0]: 2-D image fit field (Fourier L=15 + StandardMLP), the reference's CPU-runnable case."""
+    cfg = {"mode": "part1_fourier", "use_positional_encoding": True, "L_embed": 15, "hidden_dim": 64,
+           "num_layers": 3, "output_dim": 3}
+    torch.manual_seed(12)
+    model = NeuralField(cfg)
+    coords = torch.stack(torch.meshgrid(torch.linspace(0, 1, 17), torch.linspace(0, 1, 19), indexing="ij"), -1).reshape(-1, 2)
+    with torch.no_grad():
+        rgb = model(coords)
+    save("g12_part1", coords=coords, rgb=rgb, **{"w:" + k: v for k, v in model.state_dict().items()})
+
+
 def g11_psnr():
     mse = np.array([1e-4, 3.3e-3, 0.02, 0.25])
     save("g11_psnr", mse=mse, psnr=np.array([compute_psnr(m) for m in mse]))
@@ -243,7 +260,13 @@ def g11_psnr():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    import src.core as _probe
+    assert _probe.__file__.startswith(REF), _probe.__file__
     print("writing golden vectors from", REF)
+    if len(sys.argv) > 1:            # regenerate selected groups only, e.g. `make_golden.py g12_part1`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        raise SystemExit(0)
     g1_fourier()
     g2_sampling()
     g3_mask()
@@ -254,3 +277,4 @@ if __name__ == "__main__":
     g8_rays()
     g10_optim()
     g11_psnr()
+    g12_part1()
