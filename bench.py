@@ -309,6 +309,15 @@ def main():
             t = torch.tensor([rt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rt = float(t.item())
+        if world == 1:
+            # opt-in extension: "64 coarse + 128 fine" of BASELINE.json (no reference counterpart):
+            # 64-sample coarse pass, inverse-CDF resampling, 192-sample fine pass with the same field
+            eng.render_image(ro, rd, 64, n_fine=128)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            eng.render_image(ro, rd, 64, n_fine=128)
+            torch.cuda.synchronize()
+            out["render_fps_64coarse_128fine"] = 1.0 / (time.perf_counter() - th)
         out["render_fps"] = 1.0 / rt
         out["render_ms_per_frame"] = rt * 1e3
         out["render_tflops"] = H * W * args.render_samples * FWD_FLOP / rt * 1e-12

@@ -72,6 +72,15 @@ int nerf_sample_compact(const float* rays_o, const float* rays_d, const float* u
                         int resolution, float bound, float* z_out, int* slot_of_sample, float* pts_compact,
                         float* dirs_compact, unsigned* active_count, nerf_stream_t stream);
 
+/* ---- hierarchical (inverse-CDF) fine sampling, opt-in extension --------------------
+ * No reference counterpart (the reference has one stratified pass only); follows Mildenhall et al.
+ * 2020 sec. 5.2 as restated in oracle/nerf_oracle.py::sample_pdf (parity unpinned).
+ *   z_coarse [R,S] sorted depths, weights [R,S] compositing weights of the coarse pass,
+ *   u [R,n_fine] uniform draws or NULL (deterministic linspace(0,1,n_fine));
+ *   z_out [R, S + n_fine]: coarse and fine depths merged and sorted. */
+int nerf_sample_pdf(const float* z_coarse, const float* weights, const float* u, int64_t n_rays,
+                    int n_coarse, int n_fine, float* z_out, nerf_stream_t stream);
+
 /* ---- a12: occupancy-grid refresh -----------------------------------------------
  * replaces the lattice construction and the grid / binary_grid update of
  * DensityGrid.update (src/renderer.py:49-54, 118-132); the sigma query in between goes through

@@ -283,6 +283,32 @@ def should_update(step: int, interval: int = 16, warmup: int = 0) -> bool:
 
 
 # ----------------------------------------------------------------------------
+# hierarchical fine sampling -- NOT in the reference (no sample_pdf / searchsorted anywhere in the
+# tree); opt-in extension named by BASELINE.json.  Restates Mildenhall et al. 2020, section 5.2.
+# PARITY UNPINNED.
+# ----------------------------------------------------------------------------
+
+def sample_pdf(z: Tensor, weights: Tensor, n_fine: int, u: Optional[Tensor] = None) -> Tensor:
+    """z [R,S] coarse depths, weights [R,S] -> merged, sorted depths [R, S+n_fine]."""
+    bins = 0.5 * (z[:, 1:] + z[:, :-1])
+    w = weights[:, 1:-1] + 1e-5
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)          # [R, S-1]
+    if u is None:
+        u = torch.linspace(0.0, 1.0, n_fine).expand(z.shape[0], n_fine)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf.contiguous(), u, right=True)
+    below = (inds - 1).clamp(min=0)
+    above = inds.clamp(max=cdf.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    b0, b1 = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+    denom = c1 - c0
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    fine = b0 + (u - c0) / denom * (b1 - b0)
+    return torch.sort(torch.cat([z, fine], -1), -1).values
+
+
+# ----------------------------------------------------------------------------
 # a8  multiresolution hash grid  (tinycudann -- PARITY UNPINNED)
 #     call site reference src/embeddings.py:60-89; algorithm Instant-NGP sec. 3
 # ----------------------------------------------------------------------------

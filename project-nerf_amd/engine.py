@@ -137,12 +137,29 @@ class VanillaNerfEngine:
         return c, depth, acc
 
     @torch.no_grad()
-    def render_image(self, rays_o: Tensor, rays_d: Tensor, n_samples: int, chunk: int = 65536) -> Tensor:
+    def render_rays_hierarchical(self, rays_o: Tensor, rays_d: Tensor, n_coarse: int, n_fine: int):
+        """Opt-in coarse -> inverse-CDF fine rendering with the single field ("64 coarse + 128 fine" of
+        BASELINE.json; the reference itself has one stratified pass only)."""
+        R = rays_o.shape[0]
+        z = ops.sample_rays(rays_o, rays_d, self.near, self.far, n_coarse)
+        rgb, sigma = ops.mlp_fwd(self.packed, rays_o, rays_d, z)
+        w = ops.composite_fwd(rgb.view(R, n_coarse, 3), sigma.view(R, n_coarse), z, rays_d, self.bg, want_weights=True)[4]
+        z_all = ops.sample_pdf(z, w, n_fine)
+        S = n_coarse + n_fine
+        rgb, sigma = ops.mlp_fwd(self.packed, rays_o, rays_d, z_all)
+        c, depth, acc, _, _ = ops.composite_fwd(rgb.view(R, S, 3), sigma.view(R, S), z_all, rays_d, self.bg)
+        return c, depth, acc
+
+    @torch.no_grad()
+    def render_image(self, rays_o: Tensor, rays_d: Tensor, n_samples: int, chunk: int = 65536, n_fine: int = 0) -> Tensor:
         shape = rays_o.shape[:-1]
         o, d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
         out = torch.empty(o.shape[0], 3, device=self.device)
         for i in range(0, o.shape[0], chunk):
-            out[i:i + chunk] = self.render_rays(o[i:i + chunk], d[i:i + chunk], n_samples)[0]
+            if n_fine > 0:
+                out[i:i + chunk] = self.render_rays_hierarchical(o[i:i + chunk], d[i:i + chunk], n_samples, n_fine)[0]
+            else:
+                out[i:i + chunk] = self.render_rays(o[i:i + chunk], d[i:i + chunk], n_samples)[0]
         return out.view(*shape, 3)
 
 

@@ -128,6 +128,18 @@ def composite_indexed(rgb_c: Tensor, sigma_c: Tensor, slots: Tensor, z: Tensor, 
     return _CompositeIndexed.apply(rgb_c, sigma_c.reshape(-1), slots, z, rays_d, bg)
 
 
+def sample_pdf(z_coarse: Tensor, weights: Tensor, n_fine: int, u: Optional[Tensor] = None) -> Tensor:
+    """Inverse-CDF fine depths merged with the coarse ones: [R, S + n_fine], sorted (opt-in extension)."""
+    lib = _lib.load()
+    z_coarse, weights = _dev(z_coarse, "z_coarse"), _dev(weights, "weights")
+    R, S = z_coarse.shape
+    if u is not None:
+        u = _dev(u, "u")
+    out = torch.empty(R, S + n_fine, device=z_coarse.device)
+    _lib.check(lib.nerf_sample_pdf(_p(z_coarse), _p(weights), _p(u), R, S, n_fine, _p(out), _stream()), "nerf_sample_pdf")
+    return out
+
+
 # --------------------------------------------------------------------------- a12
 def grid_lattice(bound: float, resolution: int, device) -> Tensor:
     lib = _lib.load()

@@ -390,3 +390,25 @@ def test_composite_indexed_equals_zero_filled_scatter(ops):
     np.testing.assert_allclose(rg.grad.cpu().numpy(), rc.grad.numpy(), rtol=3e-5, atol=1e-7)
     ref = sc.grad.numpy()
     assert np.max(np.abs(sg.grad.cpu().numpy() - ref)) < 5e-5 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------ hierarchical sampling (extension)
+@pytest.mark.parametrize("S,NF,rand", [(64, 128, False), (64, 128, True), (32, 64, True), (128, 128, False)])
+def test_sample_pdf_vs_oracle(ops, S, NF, rand):
+    R = 50
+    gen = torch.Generator().manual_seed(S + NF)
+    z = O.stratified_depths(2.0, 6.0, S, R, True, u=torch.rand(R, S, generator=gen)).contiguous()
+    w = torch.rand(R, S, generator=gen) ** 4                       # peaky weights
+    w[:3] = 0.0                                                    # empty rays: uniform pdf from the 1e-5 floor
+    u = torch.rand(R, NF, generator=gen) if rand else None
+    out = ops.sample_pdf(dev(z), dev(w), NF, None if u is None else dev(u)).cpu()
+    ref = O.sample_pdf(z, w, NF, u)
+    assert out.shape == (R, S + NF)
+    assert bool((out[:, 1:] >= out[:, :-1]).all())                 # sorted
+    assert float(out.min()) >= float(z.min()) - 1e-6 and float(out.max()) <= float(z.max()) + 1e-6
+    err = (out - ref).abs()
+    # the cdf is a parallel prefix sum here and a sequential cumsum in the oracle: a draw that lands
+    # within 1e-7 of a cdf entry may pick the neighbouring bin, so bound the bulk tightly and the
+    # rare flips loosely
+    assert float(torch.quantile(err.flatten(), 0.999)) < 1e-4, float(torch.quantile(err.flatten(), 0.999))
+    assert float(err.max()) < 0.1
