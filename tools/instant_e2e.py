@@ -1,6 +1,7 @@
 """Instant-NGP path end to end on the synthetic scene: wall time to PSNR, train rays/s, 800x800 FPS."""
+import os
 import sys, time, tempfile, numpy as np, torch, yaml
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from src.core import NeuralField
 from src.dataset import BlenderDataset, write_synthetic_scene, look_at_pose
 from src.renderer import DensityGrid, render_rays

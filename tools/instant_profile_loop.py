@@ -1,5 +1,6 @@
+import os
 import sys, time, tempfile, numpy as np, torch, yaml
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from src.core import NeuralField
 from src.dataset import BlenderDataset, write_synthetic_scene
 from src.renderer import DensityGrid, render_rays

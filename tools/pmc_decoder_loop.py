@@ -1,5 +1,6 @@
+import os
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import project_nerf_amd
 from project_nerf_amd import ops
 from project_nerf_amd.engine import default_init

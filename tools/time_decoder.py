@@ -1,6 +1,7 @@
 """Quick timing of the fused decoder kernels on one GPU (development aid)."""
+import os
 import sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import project_nerf_amd
 from project_nerf_amd import ops
 from oracle import nerf_oracle as O

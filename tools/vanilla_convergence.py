@@ -1,5 +1,6 @@
+import os
 import sys, numpy as np, torch, tempfile, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from src.dataset import BlenderDataset, write_synthetic_scene
 from project_nerf_amd.engine import VanillaNerfEngine
 root = write_synthetic_scene(tempfile.mkdtemp() + "/scene", n_train=20, n_test=2, size=100)
