@@ -15,7 +15,9 @@ LIB = os.path.join(HERE, "libnerf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
-PER_FILE = {"sample.hip": ["-ffp-contract=off"]}
+PER_FILE = {"sample.hip": ["-ffp-contract=off"],
+            # the stream asm clobbers a0..a159; hipcc calls AGPRs past its default split "reserved"
+            "mlp_fwd.hip": ["-Wno-inline-asm"]}
 
 
 def _sources():

@@ -7,6 +7,7 @@
 // accumulators' initial values.  MFMA-bound: 1,186,816 FLOP per sample (+ padding).
 // TRAIN additionally stashes bf16 activations (row-major [n, width], the wgrad kernel's B
 // operands) and ReLU bitmasks for the backward chain.
+#include <stdio.h>
 #include <stdlib.h>
 #include "mlp_chain.h"
 
@@ -30,6 +31,7 @@ struct FwdArgs {
   __bf16* st_hv;        // blocked [n_pad, 128]
   __bf16* st_denc;      // nat  [n_pad, 32]
   uint4* st_mask;       // [tiles][9][512] relu bits: word (m>>1), bits 16*(m&1) + r
+  unsigned long long* dbg_cycles;   // development aid (NERF_FWD_CYCLES): [0] += shader cycles in passes, [1] += passes
 };
 
 template <bool TRAIN>
@@ -172,6 +174,81 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
 
 }  // namespace nerf
 
+#include "mlp_fwd_stream_asm.h"
+
+namespace nerf {
+using namespace plan;
+
+// Inference: the whole 11-step chain of a 256-sample tile is ONE hand-scheduled asm statement per
+// wave (gen_fwd_stream_asm.py); this kernel supplies the sample geometry and Fourier codes, the
+// cold start of the ring, and the sigma / rgb heads' activations.
+__global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+
+  const float* bias_g = reinterpret_cast<const float*>(a.packed + kPackBiasOff);
+  for (int i = tid; i < kBiasFloats; i += kChainThreads) bias_lds[i] = bias_g[i];
+
+  WeightRing<false> ring;
+  ring.init(a.packed + kPackFwdOff, smem + kBiasLdsBytes, wave, lane);
+  ring.template issue<0>(0);
+  ring.template issue<1>(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned bb = lds_addr(smem) + 16u * half;
+  const unsigned ab0 = lds_addr(smem + kBiasLdsBytes) + 16u * lane, ab1 = ab0 + kRingSlotBytes;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds_addr(smem + kBiasLdsBytes) + 1024u * wave);
+  const unsigned voff = 1024u * wave + 16u * lane;
+  const char* src = a.packed + kPackFwdOff;
+
+  const int64_t n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  unsigned passes = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, ++passes) {
+    const int64_t n = tile * kTileSamples + wave * kWaveSamples + col;
+    const bool live = n < a.n;
+    const int64_t nc = live ? n : a.n - 1;
+    float px, py, pz, vx, vy, vz;
+    if (a.n_samples > 0) {
+      const int64_t ray = (uint32_t)nc / (uint32_t)a.n_samples;
+      const float zz = a.z[nc];
+      const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
+      const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+      px = add_rn(ox, mul_rn(dx, zz));
+      py = add_rn(oy, mul_rn(dy, zz));
+      pz = add_rn(oz, mul_rn(dz, zz));
+      const float nrm = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
+      vx = (dx / nrm); vy = (dy / nrm); vz = (dz / nrm);
+    } else {
+      px = a.rays_o[nc * 3 + 0]; py = a.rays_o[nc * 3 + 1]; pz = a.rays_o[nc * 3 + 2];
+      vx = a.rays_d[nc * 3 + 0]; vy = a.rays_d[nc * 3 + 1]; vz = a.rays_d[nc * 3 + 2];
+    }
+    bf16x8 xenc[4], denc[2];
+    fourier_operand<4, kPosDim>(px, py, pz, half, xenc);
+    fourier_operand<2, kDirDim>(vx, vy, vz, half, denc);
+
+    float sg, cr, cg, cb;
+    fwd_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, sg, cr, cg, cb);
+    if (live && half == 0) {
+      a.sigma[n] = fmaxf(sg, 0.0f);
+      a.rgb[n * 3 + 0] = 1.0f / (1.0f + __expf(-cr));
+      a.rgb[n * 3 + 1] = 1.0f / (1.0f + __expf(-cg));
+      a.rgb[n * 3 + 2] = 1.0f / (1.0f + __expf(-cb));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last pass's look-ahead DMA must not outlive the wave
+  if (a.dbg_cycles != nullptr && tid == 0) {
+    atomicAdd(a.dbg_cycles, __builtin_amdgcn_s_memtime() - t_begin);
+    atomicAdd(a.dbg_cycles + 1, (unsigned long long)passes);
+  }
+}
+
+}  // namespace nerf
+
 #include "mlp_stash.h"
 using namespace nerf;
 
@@ -213,16 +290,33 @@ extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float
   }
   const int64_t tiles = (n + kTileSamples - 1) / kTileSamples;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+  static const bool legacy = getenv("NERF_FWD_LEGACY") != nullptr;   // development aid: compiler-scheduled chain
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
+        hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mlp_fwd_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
       return fail(NERF_ELAUNCH, "nerf_mlp_fwd: cannot raise dynamic LDS limit to %d", kChainLds);
     attr_set = true;
   }
+  static unsigned long long* dbg = nullptr;
+  if (getenv("NERF_FWD_CYCLES") != nullptr && stash == nullptr && !legacy) {
+    if (dbg == nullptr && hipMalloc(&dbg, 16) != hipSuccess) return fail(NERF_ELAUNCH, "nerf_mlp_fwd: debug buffer");
+    (void)hipMemsetAsync(dbg, 0, 16, as_stream(stream));
+    a.dbg_cycles = dbg;
+  }
   if (stash != nullptr)
     hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
-  else
+  else if (legacy)
     hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  else
+    hipLaunchKernelGGL(mlp_fwd_stream_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  if (a.dbg_cycles != nullptr) {
+    unsigned long long h[2] = {0, 0};
+    (void)hipStreamSynchronize(as_stream(stream));
+    (void)hipMemcpy(h, dbg, 16, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[nerf_mlp_fwd] %.0f shader cycles per 256-sample pass (MFMA floor 75776), %llu passes\n",
+            h[1] ? (double)h[0] / (double)h[1] : 0.0, h[1]);
+  }
   return check_launch("nerf_mlp_fwd");
 }
