@@ -16,8 +16,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
 PER_FILE = {"sample.hip": ["-ffp-contract=off"],
-            # the stream asm clobbers a0..a159; hipcc calls AGPRs past its default split "reserved"
-            "mlp_fwd.hip": ["-Wno-inline-asm"]}
+            "mlp_fwd.hip": ["-Wno-inline-asm"], "mlp_bwd.hip": ["-Wno-inline-asm"]}
 
 
 def _sources():
@@ -46,8 +45,28 @@ def _compile(src, verbose):
     return obj, True
 
 
+GENERATED = {"mlp_mtile_asm.h": "gen_mtile_asm.py", "mlp_stream_asm.h": "gen_stream_asm.py"}
+
+
+def _generate(verbose):
+    """inline-asm headers are generated (and git-ignored): csrc/gen_*.py -> csrc/*.h"""
+    for header, script in GENERATED.items():
+        h, g = os.path.join(CSRC, header), os.path.join(CSRC, script)
+        if os.path.exists(h) and os.path.getmtime(h) > os.path.getmtime(g):
+            continue
+        if verbose:
+            print(f"{script} -> {header}", flush=True)
+        r = subprocess.run([sys.executable, g], capture_output=True, text=True, cwd=CSRC,
+                           env={k: v for k, v in os.environ.items() if not k.startswith("GEN_")})
+        if r.returncode != 0:
+            raise RuntimeError(f"{script} failed:\n{r.stderr}")
+        with open(h, "w") as f:
+            f.write(r.stdout)
+
+
 def build(verbose=False, jobs=None):
     os.makedirs(OUT, exist_ok=True)
+    _generate(verbose)
     srcs = _sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, verbose), srcs))

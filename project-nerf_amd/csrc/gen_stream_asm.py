@@ -1,0 +1,438 @@
+"""Generates mlp_stream_asm.h: the decoder chain kernels' inner pass as ONE inline-asm statement per
+256-sample tile and wave -- forward inference (`fwd_stream_pass`), forward with training stash
+(`fwd_train_stream_pass`) and the dgrad chain (`bwd_stream_pass`).
+
+Why one statement: hipcc cannot be told to keep MFMAs back to back across m-tile epilogues, to keep
+fragment reads in flight across a ring hand-over, to spread stash stores over the MFMA gaps, or to
+leave a counted `s_waitcnt` alone.  Inside a single statement every wait state and counter is ours:
+
+  * literal VGPRs (listed as clobbers; the compiler keeps v0..v87): accumulator tiles
+    X = v[96:111], Y = v[112:127] alternate per m-tile group; activation buffers P = v[128:191],
+    Q = v[192:255] (16 k-steps x 4 registers) alternate per layer; v88..v95 scratch.
+  * MFMA g.k issues back to back; the epilogue of group g-1 (v_cvt_pk_bf16_f32 straight into the
+    next layer's B operand, ReLU = v_pk_max_i16 on the packed sign bits, mask word, stash stores)
+    sits in the MFMA gaps of group g, one unit per gap, starting after the 4th MFMA (the previous
+    tile's last MFMA has then left the pipe).
+  * forward: the bias of group g+1 is read from LDS straight into the tile the epilogue just
+    drained, so every group's first MFMA accumulates in place; dgrad: first MFMA takes C = 0.
+  * A fragments: ds_read_b128 D fragments ahead through a rotating VGPR window, continuing across
+    groups and chunks; every wait is an exact `s_waitcnt lgkmcnt(n)` / `vmcnt(n)` from a
+    simulation of the two in-order queues (stash stores stay in flight across ring hand-overs).
+  * ring hand-over of chunk c: B1 = `vmcnt(n) + s_barrier` before the first read of chunk c+1
+    (every wave's LDS-DMA of chunk c+1 has landed); B2 = `s_barrier` after the first MFMA of
+    chunk c+1 (every wave's reads of chunk c have returned), then the DMA of chunk c+2 into the
+    freed slot, one 1-KiB piece per MFMA gap.
+  * training: ReLU mask word of tile m = sum_q min(bf16 pair q, 1) << q  (bit q: row 2q active,
+    bit 16+q: row 2q+1), one dword per lane and tile; dgrad expands it with shift / and 0x10001 /
+    v_pk_mul_lo_u16.  Stash / gradient images are the blocked layout of mlp_chain.h::stash_block.
+
+The chunk tables are recomputed here and pinned against mlp_plan.h by static_asserts in the output.
+
+Run:  python gen_stream_asm.py > mlp_stream_asm.h
+"""
+import os
+import sys
+from collections import deque
+
+D = int(os.environ.get("GEN_D", 4))                 # A-fragment prefetch depth (window registers)
+EPI_START = 3     # first gap (after MFMA k) that may carry epilogue work
+# timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,vmwait
+ABLATE = set(filter(None, os.environ.get("GEN_NO", "").split(",")))
+CHUNK = 64
+VA, SO, MO, T0 = 88, 89, 90, 95          # scratch VGPRs; v91..v94: mask words (4 rotating slots in dgrad, v91 forward)
+X, Y, P, Q = 96, 112, 128, 192
+FIRST_LITERAL_VGPR = 88
+# literal SGPRs s84..s99: [84:85] h / dh base, [86:87] feat / dfeat, [88:89] hv / dhv, [90:91] current
+# image, [92:93] mask base, [94] 0x00010001, [96:97] layer stride in bytes, [98:99] scratch
+SGPR_LITERALS = range(84, 100)
+
+
+def vr(a, n=1):
+    return f"v{a}" if n == 1 else f"v[{a}:{a + n - 1}]"
+
+
+# ---------------------------------------------------------------- plans
+def fwd_groups():
+    steps = [("PTS0", 8, 0, 4, 0)] + [(f"PTS{l}", 8, 16, 4 if l == 4 else 0, 256 * l) for l in range(1, 8)] + [
+        ("HEAD", 9, 16, 0, 2048), ("VIEW", 4, 16, 2, 2048 + 288), ("RGB", 1, 8, 0, 2048 + 288 + 128)]
+    src = {"PTS0": None, "PTS1": P, "PTS2": Q, "PTS3": P, "PTS4": Q, "PTS5": P, "PTS6": Q, "PTS7": P,
+           "HEAD": Q, "VIEW": P, "RGB": Q}
+    dst = {"PTS0": P, "PTS1": Q, "PTS2": P, "PTS3": Q, "PTS4": P, "PTS5": Q, "PTS6": P, "PTS7": Q,
+           "HEAD": P, "VIEW": Q}
+    groups = []
+    for li, (name, mt, ks_acc, ks_nat, boff) in enumerate(steps):
+        for m in range(mt):
+            bops = [vr(src[name] + 4 * k, 4) for k in range(ks_acc)]
+            code = "x" if name in ("PTS0", "PTS4") else "d"
+            bops += [f"%[{code}{k}]" for k in range(ks_nat)]
+            if name == "RGB":
+                epi = dict(kind="rgb")
+            elif name == "HEAD" and m == 8:
+                epi = dict(kind="sigma")
+            else:
+                # image: the stash array the tile goes to (training); mask_layer: ReLU mask layer or None
+                image = ("h", li) if name.startswith("PTS") else (("feat", 0) if name == "HEAD" else ("hv", 0))
+                epi = dict(kind="cvt", dst=dst[name], m=m, relu=name != "HEAD", image=image, mt=4 if name == "VIEW" else 8,
+                           mask_layer=None if name == "HEAD" else (li if name.startswith("PTS") else 8))
+            groups.append(dict(name=name, m=m, bops=bops, bias=(boff + 32 * m) * 4, epi=epi, src=src[name]))
+    return groups
+
+
+def bwd_groups():
+    # (name, m-tiles, k-steps from the previous step, nat operand, dst buffer, src buffer, image, mask layer)
+    steps = [("B_RGB", 4, 0, "g0", P, None, ("hv", 0), 8), ("B_VIEW", 8, 8, None, Q, P, ("feat", 0), None),
+             ("B_HEAD", 8, 16, "gs", P, Q, ("h", 7), 7)]
+    bufs = [(Q, P), (P, Q)]
+    for i, l in enumerate(range(7, 0, -1)):            # B_PTS7 .. B_PTS1: d(h_{l-1})
+        d, s = bufs[i % 2]
+        steps.append((f"B_PTS{l}", 8, 16, None, d, s, ("h", l - 1), l - 1))
+    groups = []
+    for name, mt, ks_acc, nat, dst, src, image, ml in steps:
+        for m in range(mt):
+            bops = [vr(src + 4 * k, 4) for k in range(ks_acc)] + ([f"%[{nat}]"] if nat else [])
+            epi = dict(kind="cvt", dst=dst, m=m, relu=False, image=image, mt=mt, mask_layer=ml)
+            groups.append(dict(name=name, m=m, bops=bops, bias=None, epi=epi, src=src))
+    return groups
+
+
+def chunk_groups(groups):
+    chunks, fill = [], CHUNK + 1
+    for g in groups:
+        ks = len(g["bops"])
+        if fill + ks > CHUNK:
+            chunks.append(dict(frag0=sum(c["count"] for c in chunks), count=0))
+            fill = 0
+        g["chunk"], g["off"] = len(chunks) - 1, fill
+        fill += ks
+        chunks[-1]["count"] += ks
+    return chunks
+
+
+# ---------------------------------------------------------------- stream
+def generate(mode):
+    bwd, train = mode == "bwd", mode == "train"
+    stash = bwd or train
+    groups = bwd_groups() if bwd else fwd_groups()
+    chunks = chunk_groups(groups)
+    n_groups, n_chunks = len(groups), len(chunks)
+    assert n_groups % 2 == 0 and n_chunks % 2 == 0
+    frags = [(gi, k) for gi, g in enumerate(groups) for k in range(len(g["bops"]))]
+    n_frags = len(frags)
+    assert all(c["count"] > D + 12 for c in chunks[1:-1]), [c["count"] for c in chunks]
+
+    out, lds_q, vm_q = [], [], []      # emitted lines; LDS / vector-memory operations in issue order
+    emit = out.append
+
+    def frag_addr(j):
+        gi, k = frags[j]
+        g = groups[gi]
+        return ("ab1" if g["chunk"] & 1 else "ab0"), (g["off"] + k) * 1024
+
+    def issue_read(j):
+        base, off = frag_addr(j)
+        if "read" in ABLATE and j >= D:
+            return
+        emit(f"ds_read_b128 %[w{j % D}], %[{base}] offset:{off}")
+        lds_q.append(("w", j))
+
+    def wait_lds(tags):
+        hits = [i for i, t in enumerate(lds_q) if t in tags]
+        if not hits:
+            return                                                  # already covered by an earlier wait
+        last = max(hits)
+        n = len(lds_q) - 1 - last
+        assert n <= 15
+        emit(f"s_waitcnt lgkmcnt({n})")
+        del lds_q[:last + 1]
+
+    def wait_vm(pred, unknown_ok):
+        """all queued vector-memory ops matching pred have completed (in-order return)"""
+        hits = [i for i, t in enumerate(vm_q) if pred(t)]
+        if not hits:
+            if unknown_ok:
+                return
+            emit("s_waitcnt vmcnt(0)")                              # issued before this pass: count unknown
+            del vm_q[:]
+            return
+        last = max(hits)
+        n = len(vm_q) - 1 - last
+        assert n <= 63
+        emit(f"s_waitcnt vmcnt({n})")
+        del vm_q[:last + 1]
+
+    def dma_piece(cc, p):
+        if "dma" in ABLATE:
+            return
+        c = chunks[cc % n_chunks]
+        emit(f"v_add_u32 {vr(VA)}, {hex((c['frag0'] + 8 * p) * 1024)}, %[voff]")
+        emit(f"s_add_u32 m0, %[ldsw], {hex((cc & 1) * CHUNK * 1024 + 8 * p * 1024)}")
+        emit("s_nop 0")
+        emit(f"global_load_lds_dwordx4 {vr(VA)}, %[src]")
+        vm_q.append(("dma", cc))
+
+    def dma_pieces(cc):
+        return [(cc, p) for p in range((chunks[cc % n_chunks]["count"] + 7) // 8)]
+
+    cur_image = [None]
+
+    def set_image(image):
+        """SALU: s[90:91] = base of the blocked image the next stores go to"""
+        if image == cur_image[0]:
+            return []
+        prev, cur_image[0] = cur_image[0], image
+        kind, l = image
+        if kind == "h":
+            if prev is not None and prev[0] == "h" and prev[1] == l - 1:
+                return ["s_add_u32 s90, s90, s96", "s_addc_u32 s91, s91, s97"]
+            if prev is not None and prev[0] == "h" and prev[1] == l + 1:
+                return ["s_sub_u32 s90, s90, s96", "s_subb_u32 s91, s91, s97"]
+            if l == 0:
+                return ["s_mov_b32 s90, s84", "s_mov_b32 s91, s85"]
+            assert l == 7
+            return ["s_lshl_b64 s[98:99], s[96:97], 3", "s_sub_u32 s98, s98, s96", "s_subb_u32 s99, s99, s97",
+                    "s_add_u32 s90, s84, s98", "s_addc_u32 s91, s85, s99"]
+        lo = 86 if kind == "feat" else 88
+        return [f"s_mov_b32 s90, s{lo}", f"s_mov_b32 s91, s{lo + 1}"]
+
+    def mask_slot(gi):
+        return 91 + (gi % 4 if bwd else 0)
+
+    def mask_load(gi, src="mo0"):
+        g = groups[gi % n_groups]
+        ml = g["epi"].get("mask_layer")
+        if ml is None or "store" in ABLATE:
+            return []
+        return [f"v_add_u32 {vr(MO)}, {hex((ml * 8 + g['m']) * 2048)}, %[{src}]",
+                ("load", f"global_load_dword {vr(mask_slot(gi))}, {vr(MO)}, s[92:93]", ("ml", gi))]
+
+    def epi_units(gi):
+        """gap-sized units of group gi's epilogue (its accumulators are tile T)"""
+        g = groups[gi]
+        e = g["epi"]
+        T = X if gi % 2 == 0 else Y
+        units = []
+        if e["kind"] == "sigma":
+            return [[f"v_mov_b32 %[sg], {vr(T)}"]]
+        if e["kind"] != "cvt":
+            return []
+        r0 = e["dst"] + 8 * e["m"]
+        masked = e["mask_layer"] is not None
+        for j in range(8):
+            u = [f"v_cvt_pk_bf16_f32 {vr(r0 + j)}, {vr(T + 2 * j)}, {vr(T + 2 * j + 1)}"]
+            if e["relu"]:
+                u.append(f"v_pk_max_i16 {vr(r0 + j)}, {vr(r0 + j)}, 0")
+            if train and masked and "store" not in ABLATE:
+                w = mask_slot(gi)
+                if j == 0:
+                    u.append(f"v_pk_min_u16 {vr(w)}, {vr(r0)}, s94")
+                else:
+                    u += [f"v_pk_min_u16 {vr(T0)}, {vr(r0 + j)}, s94", f"v_lshl_or_b32 {vr(w)}, {vr(T0)}, {j}, {vr(w)}"]
+            if bwd and masked and "store" not in ABLATE:
+                u += [("waitmask", gi)] if j == 0 else []
+                u += [f"v_lshrrev_b32 {vr(T0)}, {j}, {vr(mask_slot(gi))}", f"v_and_b32 {vr(T0)}, s94, {vr(T0)}",
+                      f"v_pk_mul_lo_u16 {vr(r0 + j)}, {vr(r0 + j)}, {vr(T0)}"]
+            units.append(u)
+        if stash and "store" not in ABLATE:
+            so_base = "so8" if e["mt"] == 8 else "so4"
+            units.append(set_image(e["image"]) + [f"v_add_u32 {vr(SO)}, {hex(e['m'] * 2048)}, %[{so_base}]",
+                                                   ("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0, 4)}, s[90:91]")])
+            units.append([("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0 + 4, 4)}, s[90:91] offset:128")])
+            if train and masked:
+                units.append([f"v_add_u32 {vr(MO)}, {hex((e['mask_layer'] * 8 + e['m']) * 2048)}, %[mo0]",
+                              ("store", f"global_store_dword {vr(MO)}, {vr(mask_slot(gi))}, s[92:93]")])
+            if bwd and gi + 4 < n_groups:
+                units.append(mask_load(gi + 4))                      # slot gi % 4 is free again
+        return units
+
+    def emit_unit(u):
+        for line in u:
+            if isinstance(line, tuple) and line[0] == "store":
+                emit(line[1])
+                vm_q.append(("st",))
+            elif isinstance(line, tuple) and line[0] == "load":
+                emit(line[1])
+                vm_q.append(line[2])
+            elif isinstance(line, tuple) and line[0] == "waitmask":
+                wait_vm(lambda t, gi=line[1]: t == ("ml", gi), unknown_ok=False)
+            else:
+                emit(line)
+
+    def bias_reads(gi_next, T):
+        g = groups[gi_next]
+        if g["bias"] is None:
+            return []
+        return [(f"ds_read_b128 {vr(T + 4 * q, 4)}, %[bb] offset:{g['bias'] + 32 * q}", ("b", gi_next, q)) for q in range(4)]
+
+    # ---- pass prologue ----
+    emit("s_mov_b32 %[m0s], m0")
+    if stash:
+        ka = dict(train=(80, 88, 96, 112, 64), bwd=(88, 80, 72, 56, 48))[mode]   # h, feat, hv, mask, n_pad
+        for sreg, off in zip((84, 86, 88, 92, 96), ka):
+            emit(f"s_load_dwordx2 s[{sreg}:{sreg + 1}], %[karg], {hex(off)}")
+        emit("s_mov_b32 s94, 0x10001")
+        emit("s_waitcnt lgkmcnt(0)")
+        emit("s_lshl_b64 s[96:97], s[96:97], 9")                     # layer stride = n_pad * 256 * 2 bytes
+    if bwd and "store" not in ABLATE:
+        emit("s_cmp_eq_u32 %[first], 0")
+        emit("s_cbranch_scc1 .Lwarm%=")
+        for gi in range(3):
+            emit_unit(mask_load(gi))
+        emit(".Lwarm%=:")
+        del vm_q[:]                                                  # conditional: treat as issued before the pass
+    for line, tag in bias_reads(0, X):
+        emit(line)
+        lds_q.append(tag)
+    for j in range(min(D, n_frags)):
+        issue_read(j)
+
+    pending_dma = deque()
+    for gi, g in enumerate(groups):
+        ks = len(g["bops"])
+        T = X if gi % 2 == 0 else Y
+        Tprev = Y if gi % 2 == 0 else X
+        j0 = sum(len(x["bops"]) for x in groups[:gi])
+        first_of_chunk = g["off"] == 0
+        units = epi_units(gi - 1) if gi > 0 else []
+        if "epi" in ABLATE:
+            units = []
+        if bwd and gi == 0 and "store" not in ABLATE:
+            units = [mask_load(3)]                                   # groups 0..2 were prefetched by the previous pass
+        # deadline: this block reads, at k-step kd, what the previous group's epilogue writes
+        kd = None
+        if gi > 0 and groups[gi - 1]["epi"]["kind"] == "cvt" and groups[gi - 1]["epi"]["dst"] == g["src"]:
+            kd = 2 * groups[gi - 1]["epi"]["m"]
+        bias_next = bias_reads(gi + 1, Tprev) if gi + 1 < n_groups else []
+        bias_done = False
+        emit(f"; ---- group {gi}: {g['name']} m={g['m']} chunk {g['chunk']} off {g['off']}")
+        for k in range(ks):
+            j = j0 + k
+            need = {("w", j)}
+            if k == 0:
+                need |= {("b", gi, q) for q in range(4)} & set(lds_q)
+            wait_lds(need)
+            c_in = vr(T, 16) if (k > 0 or g["bias"] is not None) else "0"
+            emit(f"v_mfma_f32_32x32x16_bf16 {vr(T, 16)}, %[w{j % D}], {g['bops'][k]}, {c_in}")
+            # ---- gap fillers ----
+            if first_of_chunk and k == 0 and g["chunk"] > 0:
+                emit("s_barrier")                                   # B2 of the previous chunk
+                pending_dma.extend(dma_pieces(g["chunk"] + 1))
+            jn = j + D
+            if jn < n_frags:
+                gn = groups[frags[jn][0]]
+                if gn["off"] == 0 and frags[jn][1] == 0:             # first read of the next chunk: B1
+                    if "vmwait" not in ABLATE:
+                        wait_vm(lambda t, cc=gn["chunk"]: t == ("dma", cc), unknown_ok=False)
+                    emit("s_barrier")
+                issue_read(jn)
+            if pending_dma and not (first_of_chunk and k == 0):
+                dma_piece(*pending_dma.popleft())
+            if k >= EPI_START or k == ks - 1:
+                n_units = 1
+                if k == ks - 1 or (kd is not None and k >= kd - 2):
+                    n_units = len(units)                             # flush (short block or deadline)
+                    if units and k < 7:
+                        emit("s_nop 11")                             # short block: the previous tile's last MFMA must have drained
+                for _ in range(min(n_units, len(units))):
+                    emit_unit(units.pop(0))
+                if not units and not bias_done:
+                    if kd is not None and k >= kd - 2:
+                        emit("s_nop 1")
+                    for line, tag in bias_next:
+                        emit(line)
+                        lds_q.append(tag)
+                    bias_done = True
+        assert not units and bias_done
+    while pending_dma:
+        dma_piece(*pending_dma.popleft())
+    # ---- pass end ----
+    T = X if (n_groups - 1) % 2 == 0 else Y
+    emit("s_nop 15")
+    emit("s_nop 3")
+    if not bwd:
+        for c, name in enumerate(("cr", "cg", "cb")):
+            emit(f"v_mov_b32 %[{name}], {vr(T + c)}")
+    elif "epi" not in ABLATE:
+        for u in epi_units(n_groups - 1):                            # last tile's epilogue, bare
+            emit_unit(u)
+        if "store" not in ABLATE:
+            for gi in range(3):                                      # look-ahead: the next pass's first mask words
+                emit_unit(mask_load(n_groups + gi, "mo0n"))
+    wait_vm(lambda t: t == ("dma", n_chunks), unknown_ok=True)
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for cc, p in dma_pieces(n_chunks + 1):
+        dma_piece(cc, p)
+    emit("s_mov_b32 m0, %[m0s]")
+    return groups, chunks, out
+
+
+SIGS = {
+    "infer": ("fwd_stream_pass",
+              "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
+              "    unsigned voff, unsigned ldsw, float& sg, float& cr, float& cg, float& cb"),
+    "train": ("fwd_train_stream_pass",
+              "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
+              "    unsigned voff, unsigned ldsw, unsigned so8, unsigned so4, unsigned mo0, const void* karg,\n"
+              "    float& sg, float& cr, float& cg, float& cb"),
+    "bwd": ("bwd_stream_pass",
+            "unsigned ab0, unsigned ab1, const bf16x8& g0, const bf16x8& gs, const char* src, unsigned voff, unsigned ldsw,\n"
+            "    unsigned so8, unsigned so4, unsigned mo0, unsigned mo0n, unsigned first, const void* karg"),
+}
+
+
+def emit_function(mode, p):
+    groups, chunks, lines = generate(mode)
+    if "bar" in ABLATE:
+        lines = [l for l in lines if l != "s_barrier"]
+    name, sig = SIGS[mode]
+    tab = "kBwdChunks" if mode == "bwd" else "kFwdChunks"
+    if mode != "train":
+        p(f"static_assert(plan::{tab}.n_chunks == {len(chunks)} && plan::{tab}.n_groups == {len(groups)}, \"stream plan\");")
+        for i, c in enumerate(chunks):
+            p(f"static_assert(plan::{tab}.chunk_frag0[{i}] == {c['frag0']} && plan::{tab}.chunk_count[{i}] == {c['count']}, \"stream plan\");")
+    p(f"__device__ __forceinline__ void {name}(\n    {sig}) {{")
+    p("  bf16x8 " + ", ".join(f"w{i}" for i in range(D)) + ";")
+    p("  unsigned m0s;")
+    p("  asm volatile(")
+    for ln in lines:
+        if ln.startswith(";"):
+            p(f"      // {ln[2:]}")
+        else:
+            p(f'      "{ln}\\n\\t"')
+    outs = [f'[w{i}] "=&v"(w{i})' for i in range(D)] + ['[m0s] "=&s"(m0s)']
+    ins = ['[ab0] "v"(ab0)', '[ab1] "v"(ab1)', '[src] "s"(src)', '[voff] "v"(voff)', '[ldsw] "s"(ldsw)']
+    if mode == "bwd":
+        ins += ['[g0] "v"(g0)', '[gs] "v"(gs)', '[mo0n] "v"(mo0n)', '[first] "s"(first)']
+    else:
+        outs += ['[sg] "=&v"(sg)', '[cr] "=&v"(cr)', '[cg] "=&v"(cg)', '[cb] "=&v"(cb)']
+        ins += ['[bb] "v"(bb)'] + [f'[x{i}] "v"(x[{i}])' for i in range(4)] + [f'[d{i}] "v"(d[{i}])' for i in range(2)]
+    if mode != "infer":
+        ins += ['[so8] "v"(so8)', '[so4] "v"(so4)', '[mo0] "v"(mo0)', '[karg] "s"(karg)']
+    clob = [f'"v{i}"' for i in range(FIRST_LITERAL_VGPR, 256)]
+    if mode != "infer":
+        clob += [f'"s{i}"' for i in SGPR_LITERALS]
+    p("      : " + ", ".join(outs))
+    p("      : " + ", ".join(ins))
+    p('      : "memory", "scc", ' + ", ".join(clob) + ");")
+    p("}\n")
+    n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+    print(f"{mode}: groups {len(groups)} chunks {[c['count'] for c in chunks]} lines {len(lines)} mfma {n_mfma}", file=sys.stderr)
+
+
+def main():
+    p = print
+    p("// GENERATED by gen_stream_asm.py -- do not edit.  See that file for the design.")
+    p("#pragma once\n")
+    p("namespace nerf {\n")
+    p(f"static_assert(plan::kChunkFrags == {CHUNK}, \"stream plan\");")
+    p("// ab0/ab1: LDS byte address of ring slot 0/1 + lane*16; bb: LDS address of the bias table + 16*half;")
+    p("// voff = wave*1024 + lane*16; ldsw = ring base + wave*1024 (wave-uniform); src = fragment stream;")
+    p("// so8/so4 = wave_tile*MT*2048 + block_lane_offset(col, half) for MT = 8/4; mo0 = (tile*72*512 + tid)*4;")
+    p("// karg = kernarg segment.\n")
+    for mode in os.environ.get("GEN_MODES", "infer,train,bwd").split(","):
+        emit_function(mode, p)
+    p("}  // namespace nerf")
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,72 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_kernel(const BwdArgs
 
 }  // namespace nerf
 
+#include <stddef.h>
+#include "mlp_stream_asm.h"
+
+namespace nerf {
+
+static_assert(offsetof(BwdArgs, n_pad) == 48 && offsetof(BwdArgs, st_mask) == 56 && offsetof(BwdArgs, dhv) == 72 &&
+              offsetof(BwdArgs, dfeat) == 80 && offsetof(BwdArgs, dh) == 88, "kernarg offsets used by the stream asm");
+
+// dgrad chain as one hand-scheduled asm statement per wave and tile (gen_stream_asm.py): this kernel
+// forms the output-layer derivatives and hands the pass its two natural-order operands.
+__global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+
+  WeightRing<true> ring;
+  ring.init(a.packed + kPackBwdOff, smem + kBiasLdsBytes, wave, lane);
+  ring.template issue<0>(0);
+  ring.template issue<1>(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned ab0 = lds_addr(smem + kBiasLdsBytes) + 16u * lane, ab1 = ab0 + kRingSlotBytes;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds_addr(smem + kBiasLdsBytes) + 1024u * wave);
+  const unsigned voff = 1024u * wave + 16u * lane;
+  const char* src = a.packed + kPackBwdOff;
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+
+  const int64_t n_tiles = a.n_pad / kTileSamples;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t wave_tile = tile * 8 + wave;
+    const int64_t n = wave_tile * kWaveSamples + col;
+    const bool live = n < a.n;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gs = 0.f;
+    if (live) {
+      const float r0 = a.rgb[n * 3 + 0], r1 = a.rgb[n * 3 + 1], r2 = a.rgb[n * 3 + 2];
+      g0 = a.d_rgb[n * 3 + 0] * r0 * (1.0f - r0);
+      g1 = a.d_rgb[n * 3 + 1] * r1 * (1.0f - r1);
+      g2 = a.d_rgb[n * 3 + 2] * r2 * (1.0f - r2);
+      gs = a.sigma[n] > 0.0f ? a.d_sigma[n] : 0.0f;
+    }
+    bf16x8 small, in_rgb, in_sigma;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) small[j] = in_sigma[j] = (__bf16)0.0f;
+    if (half == 0) {
+      small[0] = (__bf16)g0; small[1] = (__bf16)g1; small[2] = (__bf16)g2; small[3] = (__bf16)gs;
+      in_sigma[0] = (__bf16)gs;
+    }
+    stash_nat(a.dsmall, wave_tile, 1, 0, col, half, small);
+    in_rgb = small;
+    in_rgb[3] = (__bf16)0.0f;   // column 3 carries d(sigma_pre), not an rgb row
+
+    const unsigned lane32 = block_lane_offset(col, half);
+    const unsigned so8 = (unsigned)wave_tile * (8u * 2048u) + lane32, so4 = (unsigned)wave_tile * (4u * 2048u) + lane32;
+    const unsigned mo0 = (unsigned)tile * (72u * 512u * 4u) + 4u * tid;
+    const bool more = tile + gridDim.x < n_tiles;
+    const unsigned mo0n = more ? (unsigned)(tile + gridDim.x) * (72u * 512u * 4u) + 4u * tid : mo0;
+    const unsigned first = __builtin_amdgcn_readfirstlane(tile == (int64_t)blockIdx.x ? 1u : 0u);
+    bwd_stream_pass(ab0, ab1, in_rgb, in_sigma, src, voff, ldsw, so8, so4, mo0, mo0n, first, karg);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace nerf
+
 using namespace nerf;
 
 int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work, const BwdLayout& bl,
@@ -159,13 +225,17 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
       return fail(NERF_ELAUNCH, "nerf_mlp_bwd: cannot query device");
-    if (hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mlp_bwd_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
       return fail(NERF_ELAUNCH, "nerf_mlp_bwd: cannot raise dynamic LDS limit to %d", kChainLds);
     n_cu = prop.multiProcessorCount;
   }
   const int64_t tiles = bl.n_pad / kTileSamples;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  if (chain_use_stream(n, true))
+    hipLaunchKernelGGL(mlp_bwd_stream_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  else
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   return check_launch("nerf_mlp_bwd (dgrad chain)");
 }
 

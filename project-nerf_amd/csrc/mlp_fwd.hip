@@ -7,6 +7,7 @@
 // accumulators' initial values.  MFMA-bound: 1,186,816 FLOP per sample (+ padding).
 // TRAIN additionally stashes bf16 activations (row-major [n, width], the wgrad kernel's B
 // operands) and ReLU bitmasks for the backward chain.
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include "mlp_chain.h"
@@ -174,14 +175,19 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
 
 }  // namespace nerf
 
-#include "mlp_fwd_stream_asm.h"
+#include "mlp_stream_asm.h"
 
 namespace nerf {
 using namespace plan;
 
-// Inference: the whole 11-step chain of a 256-sample tile is ONE hand-scheduled asm statement per
-// wave (gen_fwd_stream_asm.py); this kernel supplies the sample geometry and Fourier codes, the
-// cold start of the ring, and the sigma / rgb heads' activations.
+static_assert(offsetof(FwdArgs, n_pad) == 64 && offsetof(FwdArgs, st_h) == 80 && offsetof(FwdArgs, st_feat) == 88 &&
+              offsetof(FwdArgs, st_hv) == 96 && offsetof(FwdArgs, st_mask) == 112, "kernarg offsets used by the stream asm");
+
+// The whole 11-step chain of a 256-sample tile is ONE hand-scheduled asm statement per wave
+// (gen_stream_asm.py); this kernel supplies the sample geometry and Fourier codes, the cold start
+// of the ring, and the sigma / rgb heads' activations.  TRAIN: the statement also writes the
+// blocked stash images and one ReLU mask word per lane and m-tile.
+template <bool TRAIN>
 __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = reinterpret_cast<float*>(smem);
@@ -204,6 +210,7 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
   const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds_addr(smem + kBiasLdsBytes) + 1024u * wave);
   const unsigned voff = 1024u * wave + 16u * lane;
   const char* src = a.packed + kPackFwdOff;
+  const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
 
   const int64_t n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -232,7 +239,19 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
     fourier_operand<2, kDirDim>(vx, vy, vz, half, denc);
 
     float sg, cr, cg, cb;
-    fwd_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, sg, cr, cg, cb);
+    if constexpr (TRAIN) {
+      const int64_t wave_tile = tile * 8 + wave;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) stash_nat(a.st_xenc, wave_tile, 4, ks, col, half, xenc[ks]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) stash_nat(a.st_denc, wave_tile, 2, ks, col, half, denc[ks]);
+      const unsigned lane32 = block_lane_offset(col, half);
+      const unsigned so8 = (unsigned)wave_tile * (8u * 2048u) + lane32, so4 = (unsigned)wave_tile * (4u * 2048u) + lane32;
+      const unsigned mo0 = (unsigned)tile * (72u * 512u * 4u) + 4u * tid;
+      fwd_train_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, so8, so4, mo0, karg, sg, cr, cg, cb);
+    } else {
+      fwd_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, sg, cr, cg, cb);
+    }
     if (live && half == 0) {
       a.sigma[n] = fmaxf(sg, 0.0f);
       a.rgb[n * 3 + 0] = 1.0f / (1.0f + __expf(-cr));
@@ -290,27 +309,30 @@ extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float
   }
   const int64_t tiles = (n + kTileSamples - 1) / kTileSamples;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
-  static const bool legacy = getenv("NERF_FWD_LEGACY") != nullptr;   // development aid: compiler-scheduled chain
+  const bool legacy = !chain_use_stream(n, stash != nullptr);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
         hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mlp_fwd_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
+        hipFuncSetAttribute((const void*)mlp_fwd_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mlp_fwd_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
       return fail(NERF_ELAUNCH, "nerf_mlp_fwd: cannot raise dynamic LDS limit to %d", kChainLds);
     attr_set = true;
   }
   static unsigned long long* dbg = nullptr;
-  if (getenv("NERF_FWD_CYCLES") != nullptr && stash == nullptr && !legacy) {
+  if (getenv("NERF_FWD_CYCLES") != nullptr && !legacy) {
     if (dbg == nullptr && hipMalloc(&dbg, 16) != hipSuccess) return fail(NERF_ELAUNCH, "nerf_mlp_fwd: debug buffer");
     (void)hipMemsetAsync(dbg, 0, 16, as_stream(stream));
     a.dbg_cycles = dbg;
   }
-  if (stash != nullptr)
+  if (legacy && stash != nullptr)
     hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else if (legacy)
     hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  else if (stash != nullptr)
+    hipLaunchKernelGGL(mlp_fwd_stream_kernel<true>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else
-    hipLaunchKernelGGL(mlp_fwd_stream_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+    hipLaunchKernelGGL(mlp_fwd_stream_kernel<false>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   if (a.dbg_cycles != nullptr) {
     unsigned long long h[2] = {0, 0};
     (void)hipStreamSynchronize(as_stream(stream));

@@ -4,8 +4,25 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace nerf {
+
+// Two families of chain kernels: hand-scheduled asm streams (gen_stream_asm.py) and the
+// compiler-scheduled kernels built from mlp_chain.h::run_step.
+//   inference        : stream (+10 % render FPS); NERF_CHAIN_LEGACY=1 selects the other (development aid)
+//   training (stash) : compiler-scheduled -- both families are bound by the stash stores and the
+//                      stream dgrad additionally waits on its mask loads behind those stores
+//                      (0.42 vs 0.35 ms); NERF_CHAIN_STREAM_TRAIN=1 selects the streams (their
+//                      32-bit image offsets cover 2^22 samples per launch).
+// Forward and backward of one step must decide alike (the environment is read per call): the ReLU
+// mask words differ between the families (stream: one dword per lane and m-tile, bit q / 16+q =
+// rows 2q / 2q+1; compiler-scheduled: 16 bits per m-tile, bit r = accumulator register r).
+inline bool chain_use_stream(int64_t n, bool training) {
+  if (getenv("NERF_CHAIN_LEGACY") != nullptr) return false;
+  if (!training) return true;
+  return getenv("NERF_CHAIN_STREAM_TRAIN") != nullptr && n <= ((int64_t)1 << 22);
+}
 
 struct StashLayout {
   int64_t n_pad;
@@ -22,7 +39,7 @@ inline StashLayout stash_layout(int64_t n) {
   s.feat = o; o += np * 256 * 2;
   s.hv = o;   o += np * 128 * 2;
   s.denc = o; o += np * 32 * 2;
-  s.mask = o; o += (np / 256) * 9 * 512 * 16;
+  s.mask = o; o += (np / 256) * 9 * 512 * 32;
   s.total = o;
   return s;
 }

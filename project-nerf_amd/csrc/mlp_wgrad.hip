@@ -187,7 +187,9 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
   const int grp = g.lane >> 4, i16 = g.lane & 15, q = i16 >> 2, p = i16 & 3;
   const int hh = grp >> 1;
   g.fhalf = grp & 1;
-  g.off_acc = 64 * (8 * hh + q) + 32 * (p & 1) + 16 * g.fhalf + 8 * (p >> 1);    // + 1024*s + 2048*block
+  // blocked image (mlp_chain.h::stash_block): sample c = 8hh + q (+16s, +4 second read), lane-half p&1,
+  // fragment fhalf, 8-byte row group p>>1
+  g.off_acc = 512 * hh + 128 * g.fhalf + 64 * (p & 1) + 16 * q + 8 * (p >> 1);   // + 1024*s + 2048*block
   g.off_nat = 32 * (8 * hh + q) + 16 * (p >> 1) + 8 * (p & 1) + 1024 * g.fhalf;  // + 512*s + 2048*pair
 
   // this workgroup's span of the cost line

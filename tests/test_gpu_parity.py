@@ -196,9 +196,23 @@ def test_decoder_point_mode_vs_reference_golden(ops):
     np.testing.assert_allclose(sigma.cpu().numpy(), sb[:, 0].numpy(), atol=3e-3 * max(1.0, float(sb.max())))
 
 
+@pytest.fixture
+def chain_family(request, monkeypatch):
+    """selects the chain-kernel family per call (mlp_stash.h::chain_use_stream reads the environment)"""
+    for k in ("NERF_CHAIN_LEGACY", "NERF_CHAIN_STREAM_TRAIN"):
+        monkeypatch.delenv(k, raising=False)
+    if request.param == "compiler-scheduled":
+        monkeypatch.setenv("NERF_CHAIN_LEGACY", "1")
+    elif request.param == "asm-stream":
+        monkeypatch.setenv("NERF_CHAIN_STREAM_TRAIN", "1")
+    return request.param
+
+
+@pytest.mark.parametrize("chain_family", ["default", "compiler-scheduled"], indirect=True)
 @pytest.mark.parametrize("R,S", [(1, 64), (7, 64), (96, 64), (33, 128), (300, 2)])
-def test_decoder_ray_mode_ragged_tiles(ops, R, S):
-    """Tiles that are not multiples of 256 samples, scaled weights so that outputs vary."""
+def test_decoder_ray_mode_ragged_tiles(ops, R, S, chain_family):
+    """Tiles that are not multiples of 256 samples, scaled weights so that outputs vary; the asm-stream
+    inference kernel (default) and the compiler-scheduled one."""
     params = O.nerf_init_params(seed=R + S)
     params = {k: (v * 2.5 if k.endswith("weight") else v) for k, v in params.items()}
     o, d = synth_rays(R, 7)
@@ -262,9 +276,10 @@ def bf16_param_grads(params, pts, dirs, d_rgb, d_sigma):
     return {k: v.grad for k, v in ps.items()}
 
 
+@pytest.mark.parametrize("chain_family", ["default", "compiler-scheduled", "asm-stream"], indirect=True)
 @pytest.mark.parametrize("R,S", [(2, 64), (40, 64), (9, 128)])
-def test_decoder_backward_vs_oracle_autograd(ops, R, S):
-    """dgrad chain + wgrad vs autograd of the oracle.
+def test_decoder_backward_vs_oracle_autograd(ops, R, S, chain_family):
+    """dgrad chain + wgrad vs autograd of the oracle, for both families of chain kernels.
     * against the oracle evaluated with the SAME rounding points (bf16 operands, fp32 accumulate):
       per-tensor relative L2 error <= 2e-2 -- this is the correctness bar;
     * against the pure fp32 oracle: bf16 rounding and the ReLU masks it flips accumulate over the
