@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 FWD_FLOP = 1186816           # per sample, forward  (2 x 593,408 MAC)
 TRAIN_FLOP = 3489024         # per sample, fwd + dgrad + wgrad
+WGRAD_BYTES = 2 * (64 + 8 * 256 + 256 + 128 + 32) + 2 * (16 + 128 + 256 + 8 * 256)   # 9952 B per sample
 DGRAD_FLOP = 2 * (593408 - 35712 - 256 * 63)   # transposed chain, code columns and layer 0 skipped
 WGRAD_FLOP = 2 * 593408
 MFMA_PEAK_TFLOPS = 2500.0    # gfx950 dense bf16 (MI355X_MICROARCH.md)
@@ -254,7 +255,7 @@ def main():
             "mlp_fwd_infer": {"ms": k["mlp_fwd_infer"], "tflops": n * FWD_FLOP / k["mlp_fwd_infer"] * 1e-9},
             "mlp_bwd_dgrad": {"ms": k["mlp_bwd_dgrad"], "tflops": n * DGRAD_FLOP / k["mlp_bwd_dgrad"] * 1e-9},
             "mlp_bwd_wgrad": {"ms": k["mlp_bwd_wgrad"], "tflops": n * WGRAD_FLOP / k["mlp_bwd_wgrad"] * 1e-9,
-                              "gbs": (stash_b + ws_b) / k["mlp_bwd_wgrad"] * 1e-6},
+                              "gbs": WGRAD_BYTES * ((n + 255) // 256 * 256) / k["mlp_bwd_wgrad"] * 1e-6},
             "composite_fwd": {"ms": k["composite_fwd"], "gbs": (n * 20 + R * 32) / k["composite_fwd"] * 1e-6},
             "composite_bwd": {"ms": k["composite_bwd"], "gbs": (n * 36 + R * 32) / k["composite_bwd"] * 1e-6},
             "adam+pack": {"ms": k["adam+pack"]},
@@ -270,7 +271,9 @@ def main():
         except OSError:
             pass
         traffic = lambda name: (pmc.get(name, {}).get("hbm_bytes_per_launch_corrected") if (R, S) == (4096, 64) else None)
-        wgrad_bytes = stash_b + ws_b          # every stashed byte is read exactly once
+        # wgrad reads every stashed image exactly once (not the ReLU mask words):
+        # activations 64+8*256+256+128+32 and gradients 16+128+256+8*256 bf16 per sample
+        wgrad_bytes = WGRAD_BYTES * ((n + 255) // 256 * 256)
         roofs = {
             "mlp_fwd_train": {"bound": "mfma", "kernel": "mlp_fwd_kernel<true>", "achieved": kern["mlp_fwd_train"]["tflops"],
                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kern["mlp_fwd_train"]["tflops"] / MFMA_PEAK_TFLOPS,

@@ -36,7 +36,7 @@ from collections import deque
 
 D = int(os.environ.get("GEN_D", 4))                 # A-fragment prefetch depth (window registers)
 EPI_START = 3     # first gap (after MFMA k) that may carry epilogue work
-# timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,vmwait
+# timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,vmwait,oneimage
 ABLATE = set(filter(None, os.environ.get("GEN_NO", "").split(",")))
 CHUNK = 64
 VA, SO, MO, T0 = 88, 89, 90, 95          # scratch VGPRs; v91..v94: mask words (4 rotating slots in dgrad, v91 forward)
@@ -177,7 +177,7 @@ def generate(mode):
 
     def set_image(image):
         """SALU: s[90:91] = base of the blocked image the next stores go to"""
-        if image == cur_image[0]:
+        if image == cur_image[0] or ("oneimage" in ABLATE and cur_image[0] is not None):
             return []
         prev, cur_image[0] = cur_image[0], image
         kind, l = image
