@@ -235,8 +235,8 @@ def generate(mode):
         if stash and "store" not in ABLATE:
             so_base = "so8" if e["mt"] == 8 else "so4"
             units.append(set_image(e["image"]) + [f"v_add_u32 {vr(SO)}, {hex(e['m'] * 2048)}, %[{so_base}]",
-                                                   ("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0, 4)}, s[90:91]")])
-            units.append([("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0 + 4, 4)}, s[90:91] offset:128")])
+                                                   ("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0, 4)}, s[90:91] nt")])
+            units.append([("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0 + 4, 4)}, s[90:91] offset:128 nt")])
             if train and masked:
                 units.append([f"v_add_u32 {vr(MO)}, {hex((e['mask_layer'] * 8 + e['m']) * 2048)}, %[mo0]",
                               ("store", f"global_store_dword {vr(MO)}, {vr(mask_slot(gi))}, s[92:93]")])
