@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnerf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-COMMON = os.environ.get("NERF_EXTRA_CXXFLAGS", "").split() + ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall",
+COMMON = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
 PER_FILE = {"sample.hip": ["-ffp-contract=off"],
             "mlp_fwd.hip": ["-Wno-inline-asm"], "mlp_bwd.hip": ["-Wno-inline-asm"]}
