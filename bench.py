@@ -94,6 +94,7 @@ def bench_instant(args, device):
     root = write_synthetic_scene(tempfile.mkdtemp() + "/scene", n_train=40, n_test=4, size=200)
     ds = BlenderDataset(root, "train", 1, True, 1.0).to(device)
     test = BlenderDataset(root, "test", 1, True, 1.0)
+    from project_nerf_amd import ops
     from project_nerf_amd.engine import InstantNgpEngine
     iters, batch, S = 1000, 16384, 128
     cfg["train_iters"] = iters
@@ -130,6 +131,45 @@ def bench_instant(args, device):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # ---- per-kernel timings of one steady-state batch (rows a7 / a8 of SURVEY 8) ----
+    lib = ops._lib.load()
+    P = lambda t: t.data_ptr()
+    o, d, _ = ds.sample_random_rays(batch, device)
+    uu = torch.rand(batch, S, device=device)
+    z, slots, pts, dirs = ops.sample_compact(o, d, eng.near, eng.far, S, eng.binary_grid, eng.bound, u=uu)
+    n = pts.shape[0]
+    L = eng.levels.n_levels
+    ws = torch.empty(lib.nerf_imlp_workspace_bytes(n), device=device, dtype=torch.uint8)
+    rgb, sigma = torch.empty(n, 3, device=device), torch.empty(n, device=device)
+    d_rgb, d_sigma, d_feat = torch.randn_like(rgb), torch.randn_like(sigma), torch.empty(n, 2 * L, device=device)
+    stv = ops._stream()
+    k = {
+        "sample_compact": event_ms(lambda: ops.sample_compact(o, d, eng.near, eng.far, S, eng.binary_grid, eng.bound, u=uu), 20),
+        "hash_fwd": event_ms(lambda: ops.hash_encode_fwd(pts, eng.table.view(-1, 2), eng.levels, eng.bound, want_f32=False, out_nat=ws), 20),
+        "imlp_fwd": event_ms(lambda: lib.nerf_imlp_fwd(P(eng.packed), P(ws), P(dirs), n, P(rgb), P(sigma), 1, stv), 20),
+        "imlp_bwd": event_ms(lambda: lib.nerf_imlp_bwd(P(eng.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
+                                                       P(eng.g_net), P(d_feat), stv), 20),
+        "hash_bwd": event_ms(lambda: ops.hash_encode_bwd(pts, eng.levels, eng.bound, d_feat, eng.g_table), 20),
+        "tv_clip_adamw(table)": event_ms(lambda: ops.tv_clip_adamw_step(eng.table, eng.g_table, *eng.state["table"], 1, 0.0,
+                                                                         tv_weight=eng.tv_weight, max_norm=1.0, weight_decay=eng.wd,
+                                                                         grad_scale=1.0, scratch=eng._scratch), 20),
+    }
+    # algorithmic bytes: 8 corners x 8 B per level and point (+ 12 B in, 4 B per feature out); atomics likewise;
+    # the fused regulariser + optimiser streams params, grads and both moments (read) and params + moments (write)
+    gather = n * L * 8 * 8
+    n_tab = eng.table.numel()
+    roof = {
+        "hash_fwd": {"bound": "hbm", "kernel": "hash_fwd_kernel", "achieved": (gather + n * (12 + 2 * L * 2)) / k["hash_fwd"] * 1e-6,
+                     "note": "table gathers (mostly L2 / Infinity Cache hits: the 52 MB table is re-read by every batch)"},
+        "hash_bwd": {"bound": "hbm", "kernel": "hash_bwd_kernel", "achieved": (gather + n * (12 + 2 * L * 4)) / k["hash_bwd"] * 1e-6,
+                     "note": "fp32 atomics, one per corner and feature; levels <= 16384 entries reduced in LDS first"},
+        "tv_clip_adamw(table)": {"bound": "hbm", "kernel": "tv_normsq_kernel + adamw_clip_kernel",
+                                 "achieved": n_tab * 4 * 9 / k["tv_clip_adamw(table)"] * 1e-6},
+        "imlp_fwd": {"bound": "hbm", "kernel": "imlp_fwd_kernel<true>", "achieved": n * (64 + 12 + 16 + 2 * (64 + 16 + 64 + 64 + 48)) / k["imlp_fwd"] * 1e-6,
+                     "note": "operand image in, rgb/sigma out, bf16 stash of every layer input"},
+    }
+    for v in roof.values():
+        v.update({"peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": v["achieved"] / HBM_PEAK_GBS, "traffic": None})
     H = W = 800
     focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
     c2w = torch.tensor(look_at_pose(4.0311 * np.array([0.6, 0.5, 0.62])), dtype=torch.float32)
@@ -150,6 +190,7 @@ def bench_instant(args, device):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "Part 2 Instant-NGP (L16 F2 T2^19 hash grid + tiny MLPs, 128^3 occupancy grid), steady-state train step",
                    "rays_per_gpu": batch, "samples_per_ray": S, "active_ratio": active, "scene": "synthetic 200x200 x 40 views"},
+        "kernels": {kk: {"ms": v} for kk, v in k.items()}, "active_samples": n, "rooflines": roof,
         "render_fps": 1.0 / rt, "render_ms_per_frame": rt * 1e3, "psnr_curve": curve,
         "reference_headline": "26+ dB in 5 min, 10+ FPS (RTX 4060 Laptop, Lego; README.md:12,136)"}))
 

@@ -4,23 +4,52 @@
 
 namespace nerf {
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float lr, float beta1, float beta2,
+                                            float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
+  float pi = p;
+  if (wd != 0.0f) pi *= (1.0f - lr * wd);
+  const float mi = beta1 * m + (1.0f - beta1) * g;
+  const float vi = beta2 * v + (1.0f - beta2) * g * g;
+  m = mi;
+  v = vi;
+  p = pi - (lr * inv_bc1) * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+}
+
+// 16-byte accesses on the 4-aligned body, scalar tail; VEC = false when a base pointer is not 16-byte aligned
+template <bool VEC>
+__device__ __forceinline__ void adam_sweep(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                           float* __restrict__ v, int64_t n, float gs, float lr, float beta1, float beta2,
+                                           float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = VEC ? n / 4 : 0;
+  for (int64_t i = tid; i < n4; i += stride) {
+    f4 pp = reinterpret_cast<f4*>(p)[i], mm = reinterpret_cast<f4*>(m)[i], vv = reinterpret_cast<f4*>(v)[i];
+    const f4 gg = reinterpret_cast<const f4*>(g)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = pp[e], me = mm[e], ve = vv[e];
+      adam_update(pe, gg[e] * gs, me, ve, lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+      pp[e] = pe; mm[e] = me; vv[e] = ve;
+    }
+    reinterpret_cast<f4*>(m)[i] = mm;
+    reinterpret_cast<f4*>(v)[i] = vv;
+    reinterpret_cast<f4*>(p)[i] = pp;
+  }
+  for (int64_t i = 4 * n4 + tid; i < n; i += stride) adam_update(p[i], g[i] * gs, m[i], v[i], lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+}
+
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
             float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
             float inv_bc1, float inv_sqrt_bc2, const float* __restrict__ grad_scale) {
-  const float gs = grad_scale ? *grad_scale : 1.0f;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float pi = p[i];
-    const float gi = g[i] * gs;
-    if (wd != 0.0f) pi *= (1.0f - lr * wd);
-    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[i] = pi - (lr * inv_bc1) * (mi / denom);
-  }
+  adam_sweep<VEC>(p, g, m, v, n, grad_scale ? *grad_scale : 1.0f, lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+}
+
+__host__ inline bool aligned16(const void* a, const void* b, const void* c, const void* d) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
 }
 
 }  // namespace nerf
@@ -32,11 +61,16 @@ extern "C" int nerf_adam_step(float* params, const float* grads, float* exp_avg,
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq, "nerf_adam_step: NULL pointer");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  int64_t blocks = (n + 255) / 256;
+  int64_t blocks = (n / 4 + 255) / 256 + 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(nerf::adam_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params,
-                     grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
-                     (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale_dev);
+  if (nerf::aligned16(params, grads, exp_avg, exp_avg_sq))
+    hipLaunchKernelGGL(nerf::adam_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params,
+                       grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale_dev);
+  else
+    hipLaunchKernelGGL(nerf::adam_kernel<false>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params,
+                       grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale_dev);
   return nerf::check_launch("nerf_adam_step");
 }
 
@@ -51,26 +85,51 @@ namespace nerf {
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.0f) - (x < 0.0f); }
 
+__device__ __forceinline__ float tv_term(float prev, float cur, float next, bool has_prev, bool has_next) {
+  float t = 0.0f;
+  if (has_prev) t += sgn(cur - prev);          // d/dp_i |p_i - p_{i-1}|
+  if (has_next) t -= sgn(next - cur);          // d/dp_i |p_{i+1} - p_i|
+  return t;
+}
+
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 tv_normsq_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t n, float tv_scale,
                  float* __restrict__ normsq) {
   float local = 0.0f;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = VEC ? n / 4 : 0;
+  for (int64_t i = tid; i < n4; i += stride) {
+    f4 gg = reinterpret_cast<f4*>(g)[i];
+    if (tv_scale != 0.0f) {
+      const f4 pp = reinterpret_cast<const f4*>(p)[i];
+      const int64_t e0 = 4 * i;
+      const float before = e0 > 0 ? p[e0 - 1] : 0.0f, after = e0 + 4 < n ? p[e0 + 4] : 0.0f;
+      gg[0] += tv_scale * tv_term(before, pp[0], pp[1], e0 > 0, true);
+      gg[1] += tv_scale * tv_term(pp[0], pp[1], pp[2], true, true);
+      gg[2] += tv_scale * tv_term(pp[1], pp[2], pp[3], true, true);
+      gg[3] += tv_scale * tv_term(pp[2], pp[3], after, true, e0 + 4 < n);
+      reinterpret_cast<f4*>(g)[i] = gg;
+    }
+    local += gg[0] * gg[0] + gg[1] * gg[1] + gg[2] * gg[2] + gg[3] * gg[3];
+  }
+  for (int64_t i = 4 * n4 + tid; i < n; i += stride) {
     float gi = g[i];
     if (tv_scale != 0.0f) {
-      const float pi = p[i];
-      float t = 0.0f;
-      if (i > 0) t += sgn(pi - p[i - 1]);          // d/dp_i |p_i - p_{i-1}|
-      if (i + 1 < n) t -= sgn(p[i + 1] - pi);      // d/dp_i |p_{i+1} - p_i|
-      gi += tv_scale * t;
+      gi += tv_scale * tv_term(i > 0 ? p[i - 1] : 0.0f, p[i], i + 1 < n ? p[i + 1] : 0.0f, i > 0, i + 1 < n);
       g[i] = gi;
     }
     local += gi * gi;
   }
+  // one atomic per workgroup: 16 k same-address float atomics (one per wave) serialise in L2
+  __shared__ float part[4];
   local = wave_sum(local);
-  if ((threadIdx.x & 63) == 0) atomicAdd(normsq, local);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(normsq, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                   int64_t n, float lr, float beta1, float beta2, float eps, float wd, float inv_bc1,
@@ -80,16 +139,7 @@ adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
     const float coef = max_norm / (sqrtf(*normsq * extra_scale * extra_scale) + 1e-6f);   // torch clip_grad_norm_
     gs *= coef < 1.0f ? coef : 1.0f;
   }
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float pi = p[i];
-    const float gi = g[i] * gs;
-    if (wd != 0.0f) pi *= (1.0f - lr * wd);
-    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
-    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] = pi - (lr * inv_bc1) * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-  }
+  adam_sweep<VEC>(p, g, m, v, n, gs, lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
 }
 
 }  // namespace nerf
@@ -102,10 +152,14 @@ extern "C" int nerf_tv_normsq(const float* params, float* grads, int64_t n, floa
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads, "nerf_tv_normsq: NULL pointer");
   const float tv_scale = n > 1 ? tv_weight / (float)(n - 1) : 0.0f;      // d/dp of mean|p[1:] - p[:-1]| * w
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(nerf::tv_normsq_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
-                     tv_scale, normsq_dev);
+  int64_t blocks = (n / 4 + 255) / 256 + 1;
+  if (blocks > 1024) blocks = 1024;
+  if ((((uintptr_t)params | (uintptr_t)grads) & 15) == 0)
+    hipLaunchKernelGGL(nerf::tv_normsq_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
+                       tv_scale, normsq_dev);
+  else
+    hipLaunchKernelGGL(nerf::tv_normsq_kernel<false>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
+                       tv_scale, normsq_dev);
   return nerf::check_launch("nerf_tv_normsq");
 }
 
@@ -116,10 +170,15 @@ extern "C" int nerf_adamw_clip_step(float* params, const float* grads, float* ex
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq, "nerf_adamw_clip_step: NULL pointer");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  int64_t blocks = (n + 255) / 256;
+  int64_t blocks = (n / 4 + 255) / 256 + 1;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(nerf::adamw_clip_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
-                     exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-                     (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale);
+  if (nerf::aligned16(params, grads, exp_avg, exp_avg_sq))
+    hipLaunchKernelGGL(nerf::adamw_clip_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+                       (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale);
+  else
+    hipLaunchKernelGGL(nerf::adamw_clip_kernel<false>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
+                       (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale);
   return nerf::check_launch("nerf_adamw_clip_step");
 }

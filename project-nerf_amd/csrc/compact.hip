@@ -5,8 +5,10 @@
 // appends the ACTIVE samples' (pts, dirs) to compact arrays; `slot_of_sample` records where each
 // sample went (-1 = skipped).  The compositing kernels take that map and treat skipped samples as
 // sigma = 0, rgb = 0 (exactly what the reference's zero-filled scatter produces), so no dense
-// [R*S, 3] tensors are materialised.  Slots are reserved with one atomic per wave (ballot +
-// prefix popcount); their order is arbitrary but consistent within a call.
+// [R*S, 3] tensors are materialised.  Slots are reserved with ONE returning atomic per 1024-thread
+// workgroup and pass (wave ballots -> LDS -> prefix): one per wave meant ~16 k same-address
+// atomics per 2 M samples, which serialise in L2 and were most of the kernel's time.  Slot order is
+// arbitrary but consistent within a call.
 #include "common.h"
 
 namespace nerf {
@@ -20,7 +22,8 @@ __device__ __forceinline__ float depth_plain(int i, int n, float step, float nea
   return add_rn(mul_rn(near_p, sub_rn(1.0f, t)), mul_rn(far_p, t));
 }
 
-__global__ void __launch_bounds__(256)
+constexpr int kCompactThreads = 1024;
+__global__ void __launch_bounds__(kCompactThreads)
 sample_compact_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ u,
                       int64_t n_rays, int S, float near_p, float far_p, float step,
                       const uint8_t* __restrict__ grid, int res, float bound, float scale,
@@ -59,10 +62,20 @@ sample_compact_kernel(const float* __restrict__ rays_o, const float* __restrict_
       }
     }
     const unsigned long long ballot = __ballot(active);
-    unsigned base = 0;
-    const int lane = threadIdx.x & 63;
-    if (lane == 0 && ballot) base = atomicAdd(count, (unsigned)__popcll(ballot));
-    base = __shfl(base, 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ unsigned wave_count[kCompactThreads / 64], block_base;
+    if (lane == 0) wave_count[wave] = (unsigned)__popcll(ballot);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned tot = 0;
+#pragma unroll
+      for (int w = 0; w < kCompactThreads / 64; ++w) tot += wave_count[w];
+      block_base = tot ? atomicAdd(count, tot) : 0u;
+    }
+    __syncthreads();
+    unsigned base = block_base;
+    for (int w = 0; w < wave; ++w) base += wave_count[w];
+    __syncthreads();                                   // wave_count / block_base are rewritten by the next pass
     if (g < total) {
       int slot = -1;
       if (active) {
@@ -92,9 +105,9 @@ extern "C" int nerf_sample_compact(const float* rays_o, const float* rays_d, con
                "nerf_sample_compact: NULL pointer");
   const float step = 1.0f / (float)(n_samples - 1);
   const float scale = (float)((double)resolution / (2.0 * (double)bound));
-  int64_t blocks = (n_rays * n_samples + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(sample_compact_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), rays_o, rays_d, u, n_rays,
+  int64_t blocks = (n_rays * n_samples + kCompactThreads - 1) / kCompactThreads;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sample_compact_kernel, dim3((int)blocks), dim3(kCompactThreads), 0, as_stream(stream), rays_o, rays_d, u, n_rays,
                      n_samples, near_plane, far_plane, step, binary_grid, resolution, bound, scale, z_out, slot_of_sample,
                      pts_compact, dirs_compact, active_count);
   return check_launch("nerf_sample_compact");

@@ -46,6 +46,7 @@ __device__ __forceinline__ Corner corners_of(const HashLevels& L, int lvl, float
   }
   Corner out;
   const unsigned res = L.res[lvl], size = L.size[lvl];
+  const bool pow2 = (size & (size - 1)) == 0;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const unsigned gx = cell[0] + (c & 1), gy = cell[1] + ((c >> 1) & 1), gz = cell[2] + ((c >> 2) & 1);
@@ -55,7 +56,10 @@ __device__ __forceinline__ Corner corners_of(const HashLevels& L, int lvl, float
     out.w[c] = mul_rn(mul_rn(wx, wy), wz);
     unsigned e;
     if (L.dense[lvl]) e = (gx + gy * res + gz * res * res) % size;
-    else e = ((gx * 1u) ^ (gy * 2654435761u) ^ (gz * 805459861u)) % size;
+    else {
+      const unsigned h = (gx * 1u) ^ (gy * 2654435761u) ^ (gz * 805459861u);
+      e = pow2 ? (h & (size - 1)) : (h % size);     // same value; a runtime udiv costs ~30 VALU ops per corner
+    }
     out.idx[c] = e + L.offset[lvl];
   }
   return out;
@@ -104,6 +108,12 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const f
 // unrelated regions.  Levels whose whole table fits in LDS (<= kLdsEntries entries: the dense
 // 16^3 and 24^3 levels, where thousands of samples hit each cell) are reduced in LDS first and
 // flushed with one well-shaped (contiguous) global atomic per entry per workgroup.
+// The larger levels stay on global float atomics, ~21 G/s on MI355X wherever they land.  Two
+// alternatives were built and measured on 200 k points (2.4 ms as is): entries sliced per XCD by
+// HW_REG_XCC_ID so that every 128-byte line stays in one L2 -- 2.4 ms, no change; owner-computes
+// (a workgroup per 16384-entry slice scans the whole batch into LDS, level-major gradient copy,
+// plain read-modify-write flush) -- 3.0 ms, the 32-fold recomputation of the corner hashes costs
+// more than the atomics it removes.
 constexpr int kLdsEntries = 16384;      // 128 KiB of float2
 template <bool in_lds>
 __global__ void __launch_bounds__(512)

@@ -57,11 +57,13 @@ def test_hash_indices_bit_exact_and_features(ops, n):
     np.testing.assert_allclose(feat.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
-def test_hash_backward_scatter_vs_autograd(ops):
+@pytest.mark.parametrize("n", [300, 5000])
+def test_hash_backward_scatter_vs_autograd(ops, n):
     lv = O.hash_grid_levels(16, 19, 16, 1.5)
     t = ops.HashLevelTable(16, 19, 16, 1.5)
-    pts, _ = make_inputs(300, 3)
-    d_feat = torch.randn(300, 32, generator=torch.Generator().manual_seed(4))
+    pts, _ = make_inputs(n, 3)
+    d_feat = torch.randn(n, 32, generator=torch.Generator().manual_seed(4))
+    d_feat[::7] = 0.0                                                   # rows the kernels skip
     table = torch.zeros(t.entries, 2, requires_grad=True)
     (O.hash_encode(lv, table, O.hash_normalise(pts, 1.5)) * d_feat).sum().backward()
     g = torch.zeros(t.entries, 2, device="cuda")
