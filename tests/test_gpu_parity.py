@@ -209,10 +209,11 @@ def chain_family(request, monkeypatch):
 
 
 @pytest.mark.parametrize("chain_family", ["default", "compiler-scheduled"], indirect=True)
-@pytest.mark.parametrize("R,S", [(1, 64), (7, 64), (96, 64), (33, 128), (300, 2)])
+@pytest.mark.parametrize("R,S", [(1, 64), (7, 64), (96, 64), (33, 128), (300, 2), (1101, 64)])
 def test_decoder_ray_mode_ragged_tiles(ops, R, S, chain_family):
     """Tiles that are not multiples of 256 samples, scaled weights so that outputs vary; the asm-stream
-    inference kernel (default) and the compiler-scheduled one."""
+    inference kernel (default) and the compiler-scheduled one.  1101 x 64 = 276 tiles: more tiles than
+    CUs, so some workgroups run a second pass (look-ahead DMA and ring hand-over across passes)."""
     params = O.nerf_init_params(seed=R + S)
     params = {k: (v * 2.5 if k.endswith("weight") else v) for k, v in params.items()}
     o, d = synth_rays(R, 7)
@@ -274,6 +275,35 @@ def bf16_param_grads(params, pts, dirs, d_rgb, d_sigma):
     rgb = torch.sigmoid(_Q.apply(lin(hv, W("rgb_layer.weight"), ps["rgb_layer.bias"]), False, True))
     ((rgb * d_rgb).sum() + (sigma[:, 0] * d_sigma).sum()).backward()
     return {k: v.grad for k, v in ps.items()}
+
+
+def test_decoder_training_families_agree_over_multiple_passes(ops, monkeypatch):
+    """1101 x 64 samples = 276 tiles > 256 CUs: the second pass of a workgroup (stash offsets, mask
+    words, look-ahead DMA) in both families of training kernels; they differ only in summation order."""
+    params = O.nerf_init_params(seed=11)
+    R, S = 1101, 64
+    o, d = synth_rays(R, 3)
+    z = O.stratified_depths(2.0, 6.0, S, R, True, u=torch.rand(R, S, generator=torch.Generator().manual_seed(8))).contiguous()
+    n = R * S
+    gen = torch.Generator().manual_seed(6)
+    d_rgb, d_sigma = dev(torch.randn(n, 3, generator=gen)), dev(torch.randn(n, generator=gen))
+    packed = ops.mlp_pack(dev(flat_params(params)))
+    out = {}
+    for fam, env in (("compiler-scheduled", "NERF_CHAIN_LEGACY"), ("asm-stream", "NERF_CHAIN_STREAM_TRAIN")):
+        for k in ("NERF_CHAIN_LEGACY", "NERF_CHAIN_STREAM_TRAIN"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv(env, "1")
+        stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
+        rgb, sigma = ops.mlp_fwd(packed, dev(o), dev(d), dev(z), stash)
+        out[fam] = (rgb.cpu(), sigma.cpu(), ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb, d_sigma).cpu())
+    a, b = out["compiler-scheduled"], out["asm-stream"]
+    assert float((a[0] - b[0]).abs().max()) < 2e-2 and float((a[1] - b[1]).abs().max()) < 2e-2 * max(1.0, float(a[1].max()))
+    off = 0
+    for name, shape in O.nerf_param_shapes():
+        cnt = int(np.prod(shape))
+        ga, gb = a[2][off:off + cnt], b[2][off:off + cnt]
+        off += cnt
+        assert float((ga - gb).norm() / (ga.norm() + 1e-12)) < 2e-2, name
 
 
 @pytest.mark.parametrize("chain_family", ["default", "compiler-scheduled", "asm-stream"], indirect=True)
