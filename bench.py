@@ -232,7 +232,11 @@ def main():
     eng = VanillaNerfEngine(seed=0, world_size=world, device=str(device))
     R, S = args.rays, args.samples
     o, d, target = synth_rays(R, 100 + rank, device)
-    sync = parallel.allreduce_sum_ if world > 1 else None   # ONE collective per step: flat 2.38 MB gradient
+    # the flat 2.38 MB gradient is all-reduced in two ranges, the first while the second is still being
+    # computed (NERF_BENCH_SYNC_ALLREDUCE=1: one blocking collective after the backward pass instead)
+    blocking = os.environ.get("NERF_BENCH_SYNC_ALLREDUCE") is not None
+    sync = parallel.allreduce_sum_ if world > 1 and blocking else None
+    sync_async = parallel.allreduce_sum_async if world > 1 and not blocking else None
 
     def barrier():
         if world > 1:
@@ -240,11 +244,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        eng.train_step(o, d, target, S, sync_grads=sync)
+        eng.train_step(o, d, target, S, sync_grads=sync, sync_grads_async=sync_async)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = eng.train_step(o, d, target, S, sync_grads=sync)
+        loss = eng.train_step(o, d, target, S, sync_grads=sync, sync_grads_async=sync_async)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

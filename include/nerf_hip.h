@@ -181,6 +181,14 @@ int nerf_mlp_bwd(const void* packed, const void* stash, const float* rgb, const 
 int nerf_mlp_bwd_dgrad(const void* packed, const void* stash, const float* rgb, const float* sigma,
                        const float* d_rgb, const float* d_sigma, int64_t n, void* workspace,
                        nerf_stream_t stream);
+/* nerf_mlp_bwd_wgrad_part: the weight-gradient pass in two launches for a data-parallel caller that
+ * all-reduces one parameter range while the other is still being computed.  part 1 writes
+ * grads_f32[split, 595844) (pts_layers.4 .. rgb_layer), part 2 writes grads_f32[0, split)
+ * (pts_layers.0 .. 3), split = nerf_mlp_wgrad_part_split(); part 0 = nerf_mlp_bwd_wgrad.  Each
+ * part overwrites exactly its own range. */
+int64_t nerf_mlp_wgrad_part_split(void);
+int nerf_mlp_bwd_wgrad_part(const void* stash, const void* workspace, int64_t n, float* grads_f32, int part,
+                            nerf_stream_t stream);
 int nerf_mlp_bwd_wgrad(const void* stash, const void* workspace, int64_t n, float* grads_f32,
                        nerf_stream_t stream);
 

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "nerf_mlp_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_bwd_dgrad": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
     "nerf_mlp_bwd_wgrad": (i32, [c_ptr, c_ptr, i64, c_ptr, c_ptr]),
+    "nerf_mlp_wgrad_part_split": (i64, []),
+    "nerf_mlp_bwd_wgrad_part": (i32, [c_ptr, c_ptr, i64, c_ptr, i32, c_ptr]),
     "nerf_hash_encode_fwd": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_imlp_packed_bytes": (size_t, []),

@@ -225,8 +225,11 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
 
 using namespace nerf;
 
+// part 0: all twelve layer jobs; part 1: pts_layers.4 .. rgb_layer (parameters [kW4, end)); part 2:
+// pts_layers.0 .. 3 (parameters [0, kW4)).  Parts 1 and 2 let a data-parallel caller all-reduce the
+// first range while the second is still being computed.
 int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work, const BwdLayout& bl,
-                      int64_t n, float* grads, hipStream_t stream) {
+                      int64_t n, float* grads, int part, hipStream_t stream) {
   WgradArgs args{};
   const size_t np = (size_t)sl.n_pad;
   const char* xenc = stash + sl.xenc;
@@ -288,6 +291,11 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
     j.b_acc = stash + sl.hv; j.b_acc_bytes = 8192; j.nt_acc = 4; j.ones = 1; j.bias_nat_col = -1;
     j.w_off = kWRgb; j.w_ld = 128; j.o_row0 = 0; j.o_valid = 3; j.acc_valid = 128; j.bias_off = kBRgb; j.kind = 5;
     add(j);
+  }
+  if (part != 0) {                     // jobs are in parameter order: 0..3 = pts_layers.0..3
+    const int lo = part == 1 ? 4 : 0, hi = part == 1 ? nj : 4;
+    for (int j = lo; j < hi; ++j) args.jobs[j - lo] = args.jobs[j];
+    nj = hi - lo;
   }
   args.n_jobs = nj;
   return wgrad_launch(args, n, grads, stream);

@@ -102,7 +102,7 @@ class VanillaNerfEngine:
 
     # -- training step (reference run.py:314-338) ------------------------------
     def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 64,
-                   u: Optional[Tensor] = None, sync_grads=None) -> Tensor:
+                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None) -> Tensor:
         R = rays_o.shape[0]
         n = R * n_samples
         if u is None:
@@ -117,8 +117,14 @@ class VanillaNerfEngine:
         loss = (diff * diff).mean()
         g_pred = diff * (2.0 / diff.numel())
         d_rgb, d_sigma, _ = ops.composite_bwd(rgb3, sig2, z, rays_d, self.bg, None, g_pred, None, None, None)
-        ops.mlp_bwd(self.packed, stash, rgb, sigma, d_rgb.view(n, 3), d_sigma.view(n), self.grads,
-                    self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)))
+        if sync_grads_async is not None:
+            # weight gradients in two launches: the late layers' range is all-reduced (RCCL) while the
+            # early layers' is still being computed; both are averaged by grad_scale below
+            ops.mlp_bwd_overlapped(self.packed, stash, rgb, sigma, d_rgb.view(n, 3), d_sigma.view(n), self.grads,
+                                   self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)), sync_grads_async)
+        else:
+            ops.mlp_bwd(self.packed, stash, rgb, sigma, d_rgb.view(n, 3), d_sigma.view(n), self.grads,
+                        self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)))
         if sync_grads is not None:
             sync_grads(self.grads)            # RCCL all-reduce (sum); averaged by grad_scale below
         self.step_count += 1

@@ -311,6 +311,26 @@ def mlp_bwd(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Te
     return grads
 
 
+def mlp_bwd_overlapped(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Tensor, d_sigma: Tensor,
+                       grads: Tensor, workspace: Tensor, reduce_async) -> None:
+    """mlp_bwd for data-parallel training: dgrad, then the weight gradients in two launches;
+    ``reduce_async(view)`` starts the all-reduce of a finished parameter range and returns a
+    handle (``.wait()``) or None -- the first range is on the wire while the second is computed."""
+    lib = _lib.load()
+    n = sigma.numel()
+    _lib.check(lib.nerf_mlp_bwd_dgrad(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
+                                      _p(workspace), _stream()), "nerf_mlp_bwd_dgrad")
+    split = lib.nerf_mlp_wgrad_part_split()
+    handles = []
+    for part, view in ((1, grads[split:]), (2, grads[:split])):
+        _lib.check(lib.nerf_mlp_bwd_wgrad_part(_p(stash), _p(workspace), n, _p(grads), part, _stream()),
+                   "nerf_mlp_bwd_wgrad_part")
+        handles.append(reduce_async(view))
+    for h in handles:
+        if h is not None:
+            h.wait()
+
+
 class _Decoder(torch.autograd.Function):
     """Fused Fourier-encode + 8x256 decoder: forward stashes, backward = dgrad chain + wgrad."""
 

@@ -46,6 +46,16 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def allreduce_sum_async(flat: torch.Tensor):
+    """Starts the in-place sum over ranks of a (contiguous view of a) flat buffer; returns the work
+    handle, or None when there is nothing to do.  With the nccl (= RCCL) backend the collective runs
+    on the communicator's own stream behind the work already queued on the current stream, so
+    kernels launched afterwards overlap with it; ``handle.wait()`` orders the current stream after it."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
 def gather_row_bands(band: torch.Tensor, rows_total: int, dst: int = 0) -> Optional[torch.Tensor]:
     """Each rank holds rows shard_range(rows_total, rank, world) of an image [rows, W, C]; returns
     the assembled image on ``dst`` (None elsewhere)."""

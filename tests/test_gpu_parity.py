@@ -277,6 +277,28 @@ def bf16_param_grads(params, pts, dirs, d_rgb, d_sigma):
     return {k: v.grad for k, v in ps.items()}
 
 
+def test_decoder_backward_in_two_parts_equals_one_launch(ops):
+    """nerf_mlp_bwd_wgrad_part 1 + 2 (the data-parallel, comm-overlapped form) == nerf_mlp_bwd"""
+    params = O.nerf_init_params(seed=5)
+    R, S = 37, 64
+    o, d = synth_rays(R, 9)
+    z = O.stratified_depths(2.0, 6.0, S, R, True, u=torch.rand(R, S, generator=torch.Generator().manual_seed(3))).contiguous()
+    n = R * S
+    gen = torch.Generator().manual_seed(7)
+    d_rgb, d_sigma = dev(torch.randn(n, 3, generator=gen)), dev(torch.randn(n, generator=gen))
+    packed = ops.mlp_pack(dev(flat_params(params)))
+    stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
+    rgb, sigma = ops.mlp_fwd(packed, dev(o), dev(d), dev(z), stash)
+    whole = ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb, d_sigma)
+    parts = torch.full_like(whole, float("nan"))
+    ws = torch.empty(ops.mlp_bwd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    seen = []
+    ops.mlp_bwd_overlapped(packed, stash, rgb, sigma, d_rgb, d_sigma, parts, ws, lambda v: seen.append(v.numel()))
+    assert sum(seen) == whole.numel() and len(seen) == 2
+    assert torch.isfinite(parts).all()
+    assert float((parts - whole).norm() / whole.norm()) < 1e-5      # float-atomic summation order only
+
+
 def test_decoder_training_families_agree_over_multiple_passes(ops, monkeypatch):
     """1101 x 64 samples = 276 tiles > 256 CUs: the second pass of a workgroup (stash offsets, mask
     words, look-ahead DMA) in both families of training kernels; they differ only in summation order."""

@@ -35,6 +35,12 @@ def _worker(rank, world, port, out):
     grad /= rays.shape[0]
     full = (2 * (rays @ a)[:, None] * rays).mean(0)
     ok_grad = torch.allclose(grad, full, rtol=1e-5, atol=1e-6)
+    # the overlapped form: two ranges of one flat buffer reduced by two asynchronous collectives
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    handles = [P.allreduce_sum_async(flat[6:]), P.allreduce_sum_async(flat[:6])]
+    for h in handles:
+        h.wait()
+    ok_grad = ok_grad and torch.equal(flat, torch.arange(10, dtype=torch.float32) * sum(range(1, world + 1)))
     # row-band gather of a rendered image
     H = 13
     img = torch.arange(H * 5 * 3, dtype=torch.float32).view(H, 5, 3)
