@@ -230,7 +230,8 @@ __device__ __forceinline__ void stash_block(__bf16* base, int64_t wave_tile, int
                                             const bf16x8& lo, const bf16x8& hi) {
   char* p = reinterpret_cast<char*>(base) + (wave_tile * n_mtiles + m) * 2048 + block_lane_offset(col, half);
   // non-temporal: the images are streamed out once and read back by another kernel; plain stores
-  // made the training step 7 % slower (they displace the weight stream in L2)
+  // made the training step 7 % slower (they displace the weight stream in L2); sc0/sc1 variants
+  // of the store were measured too: `nt` alone is what matters
   __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8*>(p));
   __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8*>(p + 128));
 }
