@@ -9,6 +9,8 @@
 // hash-map budget, xor-prime hash above), trilinear blend of F = 2 features.  Gather-bound:
 // 16 levels x 8 corners x 8 B (fp32 table) per point; the 52 MB table lives in the 256 MB
 // Infinity Cache.  Backward: 16 float atomics per (point, level).
+#include <stdlib.h>
+#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace nerf {
@@ -150,6 +152,80 @@ hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0
   }
 }
 
+// ---- packed-fp16 gradient table (what tinycudann itself accumulates in) ----------------------
+// Global atomics retire at ~21 G operations/s on MI355X whatever their width (tools/probe/
+// atomic_rate.hip: two fp32 adds per element 10.4 G elements/s, one packed fp16 pair or one 64-bit
+// add 21-24 G/s), and the fp32 scatter needs two per corner.  Here both features of a corner go out
+// as ONE global_atomic_pk_add_f16 into a half2 table, scaled by a power of two chosen from
+// max|d_feat| so that the largest contribution lands at 64 (room for 1000 of them per entry below
+// the fp16 maximum, full 11-bit precision down to 1e-6 of the largest); the table is then
+// converted back to fp32 and unscaled.  Levels that fit in LDS still accumulate in fp32 there.
+__global__ void __launch_bounds__(256)
+absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out_bits) {
+  float m = 0.0f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+
+// power-of-two scale that maps absmax to [32, 64]; 1 for an all-zero (or non-finite) gradient
+__device__ __forceinline__ float f16_grad_scale(unsigned absmax_bits) {
+  const float a = __uint_as_float(absmax_bits);
+  if (!(a > 0.0f) || !(a < 3.0e38f)) return 1.0f;
+  int e;
+  frexpf(a, &e);                       // a = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.0f, 6 - e);
+}
+
+template <bool in_lds>
+__global__ void __launch_bounds__(512)
+hash_bwd_f16_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0, const float* __restrict__ d_feat,
+                    __half2* __restrict__ g16, const unsigned* __restrict__ absmax_bits) {
+  extern __shared__ __attribute__((aligned(16))) float lds_acc[];
+  const int lvl = lvl0 + blockIdx.y;
+  const unsigned size = L.size[lvl], offset = L.offset[lvl];
+  const float S = f16_grad_scale(*absmax_bits);
+  if (in_lds) {
+    for (unsigned i = threadIdx.x; i < 2 * size; i += blockDim.x) lds_acc[i] = 0.0f;
+    __syncthreads();
+  }
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0] * S, g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1] * S;
+    if (g0 == 0.0f && g1 == 0.0f) continue;
+    const Corner c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (in_lds) {
+        atomicAdd(lds_acc + 2 * (c.idx[k] - offset) + 0, c.w[k] * g0);
+        atomicAdd(lds_acc + 2 * (c.idx[k] - offset) + 1, c.w[k] * g1);
+      } else {
+        unsafeAtomicAdd(g16 + c.idx[k], __floats2half2_rn(c.w[k] * g0, c.w[k] * g1));
+      }
+    }
+  }
+  if (in_lds) {
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < size; i += blockDim.x) {
+      const float v0 = lds_acc[2 * i], v1 = lds_acc[2 * i + 1];
+      if (v0 != 0.0f || v1 != 0.0f) unsafeAtomicAdd(g16 + offset + i, __floats2half2_rn(v0, v1));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+hash_grad_unscale_kernel(const __half2* __restrict__ g16, int64_t entries, const unsigned* __restrict__ absmax_bits,
+                         float2* __restrict__ out) {
+  const float inv = 1.0f / f16_grad_scale(*absmax_bits);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < entries; i += (int64_t)gridDim.x * blockDim.x) {
+    const float2 v = __half22float2(g16[i]);
+    out[i] = make_float2(v.x * inv, v.y * inv);
+  }
+}
+
 static int fill_levels(HashLevels& L, int n_levels, const float* scale, const unsigned* res, const unsigned* size,
                        const unsigned* offset, const unsigned* dense, float bound) {
   if (n_levels < 1 || n_levels > kMaxLevels) return fail(NERF_EINVAL, "hash grid: n_levels=%d (1..16)", n_levels);
@@ -214,8 +290,66 @@ extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, c
   if (n_small < n_levels) {
     int64_t bx = (n + 511) / 512;
     if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((int)bx, n_levels - n_small), dim3(512), 0, as_stream(stream), pts, n, L,
-                       n_small, d_feat, d_table);
+    int first = n_small, count = n_levels - n_small;
+    if (const char* only = getenv("NERF_HASH_BWD_ONLY_LEVEL")) {   // development aid: time one level's atomics
+      first = atoi(only);
+      count = 1;
+      if (first < n_small || first >= n_levels) return check_launch("nerf_hash_encode_bwd");
+    }
+    hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((int)bx, count), dim3(512), 0, as_stream(stream), pts, n, L,
+                       first, d_feat, d_table);
   }
   return check_launch("nerf_hash_encode_bwd");
+}
+
+extern "C" size_t nerf_hash_bwd_f16_workspace_bytes(int64_t entries) {
+  return entries > 0 ? 256 + (size_t)entries * sizeof(__half2) : 0;
+}
+
+extern "C" int nerf_hash_encode_bwd_f16(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                        const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                        const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                                        int64_t entries, void* workspace, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && entries > 0, "nerf_hash_encode_bwd_f16: n=%lld entries=%lld", (long long)n, (long long)entries);
+  NERF_REQUIRE(d_table && workspace && (((uintptr_t)workspace) & 255) == 0, "nerf_hash_encode_bwd_f16: NULL / misaligned pointer");
+  if (n == 0) {
+    if (hipMemsetAsync(d_table, 0, (size_t)entries * 8, as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_f16: memset failed");
+    return NERF_OK;
+  }
+  NERF_REQUIRE(pts && d_feat && scale_host && res_host && size_host && offset_host && dense_host,
+               "nerf_hash_encode_bwd_f16: NULL pointer");
+  HashLevels L;
+  int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
+  if (rc != NERF_OK) return rc;
+  NERF_REQUIRE((int64_t)offset_host[n_levels - 1] + size_host[n_levels - 1] <= entries,
+               "nerf_hash_encode_bwd_f16: level table exceeds entries=%lld", (long long)entries);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)hash_bwd_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEntries * 8) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_f16: cannot raise dynamic LDS limit");
+    attr_set = true;
+  }
+  unsigned* absmax = static_cast<unsigned*>(workspace);
+  __half2* g16 = reinterpret_cast<__half2*>(static_cast<char*>(workspace) + 256);
+  if (hipMemsetAsync(workspace, 0, 256 + (size_t)entries * sizeof(__half2), as_stream(stream)) != hipSuccess)
+    return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_f16: memset failed");
+  hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, as_stream(stream), d_feat, n * 2 * n_levels, absmax);
+  int n_small = 0;
+  while (n_small < n_levels && size_host[n_small] <= (unsigned)kLdsEntries) ++n_small;
+  if (n_small > 0) {
+    int64_t bx = (n + 511) / 512;
+    if (bx > 128) bx = 128;
+    hipLaunchKernelGGL(hash_bwd_f16_kernel<true>, dim3((int)bx, n_small), dim3(512), kLdsEntries * 8, as_stream(stream), pts, n, L, 0,
+                       d_feat, g16, absmax);
+  }
+  if (n_small < n_levels) {
+    int64_t bx = (n + 511) / 512;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(hash_bwd_f16_kernel<false>, dim3((int)bx, n_levels - n_small), dim3(512), 0, as_stream(stream), pts, n, L,
+                       n_small, d_feat, g16, absmax);
+  }
+  hipLaunchKernelGGL(hash_grad_unscale_kernel, dim3(2048), dim3(256), 0, as_stream(stream), g16, entries, absmax,
+                     reinterpret_cast<float2*>(d_table));
+  return check_launch("nerf_hash_encode_bwd_f16");
 }
