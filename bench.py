@@ -99,7 +99,6 @@ def bench_instant(args, device):
     iters, batch, S = 1000, 16384, 128
     cfg["train_iters"] = iters
     torch.manual_seed(0)
-    cfg["hash_grad_fp16"] = os.environ.get("NERF_HASH_GRAD_FP32") is None     # fp16 pairs (tinycudann's type) unless asked
     eng = InstantNgpEngine(cfg, device=str(device), seed=0)
 
     def psnr():
@@ -150,9 +149,7 @@ def bench_instant(args, device):
         "imlp_fwd": event_ms(lambda: lib.nerf_imlp_fwd(P(eng.packed), P(ws), P(dirs), n, P(rgb), P(sigma), 1, stv), 20),
         "imlp_bwd": event_ms(lambda: lib.nerf_imlp_bwd(P(eng.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
                                                        P(eng.g_net), P(d_feat), stv), 20),
-        "hash_bwd(fp32 atomics)": event_ms(lambda: ops.hash_encode_bwd(pts, eng.levels, eng.bound, d_feat, eng.g_table), 20),
-        "hash_bwd": (event_ms(lambda: ops.hash_encode_bwd_f16(pts, eng.levels, eng.bound, d_feat, eng.g_table, eng._ws16), 20)
-                     if eng.hash_grad_fp16 else None),
+        "hash_bwd": event_ms(lambda: ops.hash_encode_bwd(pts, eng.levels, eng.bound, d_feat, eng.g_table), 20),
         "tv_clip_adamw(table)": event_ms(lambda: ops.tv_clip_adamw_step(eng.table, eng.g_table, *eng.state["table"], 1, 0.0,
                                                                          tv_weight=eng.tv_weight, max_norm=1.0, weight_decay=eng.wd,
                                                                          grad_scale=1.0, scratch=eng._scratch), 20),
@@ -164,10 +161,9 @@ def bench_instant(args, device):
     roof = {
         "hash_fwd": {"bound": "hbm", "kernel": "hash_fwd_kernel", "achieved": (gather + n * (12 + 2 * L * 2)) / k["hash_fwd"] * 1e-6,
                      "note": "table gathers (mostly L2 / Infinity Cache hits: the 52 MB table is re-read by every batch)"},
-        "hash_bwd": {"bound": "hbm", "kernel": "hash_bwd_f16_kernel" if eng.hash_grad_fp16 else "hash_bwd_kernel",
-                     "achieved": (gather + n * (12 + 2 * L * 4)) / (k["hash_bwd"] or k["hash_bwd(fp32 atomics)"]) * 1e-6,
-                     "note": "one packed fp16 atomic per corner (fp32: one per corner and feature); the chip retires ~21 G "
-                             "global atomics/s of any width; levels <= 16384 entries reduced in LDS first"},
+        "hash_bwd": {"bound": "hbm", "kernel": "hash_bwd_kernel", "achieved": (gather + n * (12 + 2 * L * 4)) / k["hash_bwd"] * 1e-6,
+                     "note": "fp32 atomics, 4 lanes per (point, level) so that one instruction carries 16 adjacent bytes per point: "
+                             "the chip retires ~21 G atomic LINE requests/s; levels <= 16384 entries reduced in LDS first"},
         "tv_clip_adamw(table)": {"bound": "hbm", "kernel": "tv_normsq_kernel + adamw_clip_kernel",
                                  "achieved": n_tab * 4 * 9 / k["tv_clip_adamw(table)"] * 1e-6},
         "imlp_fwd": {"bound": "hbm", "kernel": "imlp_fwd_kernel<true>", "achieved": n * (64 + 12 + 16 + 2 * (64 + 16 + 64 + 64 + 48)) / k["imlp_fwd"] * 1e-6,
@@ -195,8 +191,7 @@ def bench_instant(args, device):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "Part 2 Instant-NGP (L16 F2 T2^19 hash grid + tiny MLPs, 128^3 occupancy grid), steady-state train step",
                    "rays_per_gpu": batch, "samples_per_ray": S, "active_ratio": active, "scene": "synthetic 200x200 x 40 views"},
-        "kernels": {kk: {"ms": v} for kk, v in k.items() if v is not None}, "active_samples": n, "rooflines": roof,
-        "hash_grad_dtype": "fp16 pairs" if eng.hash_grad_fp16 else "fp32",
+        "kernels": {kk: {"ms": v} for kk, v in k.items()}, "active_samples": n, "rooflines": roof,
         "render_fps": 1.0 / rt, "render_ms_per_frame": rt * 1e3, "psnr_curve": curve,
         "reference_headline": "26+ dB in 5 min, 10+ FPS (RTX 4060 Laptop, Lego; README.md:12,136)"}))
 

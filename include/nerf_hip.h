@@ -213,19 +213,7 @@ int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float*
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
                          nerf_stream_t stream);
-/* The same scatter accumulated the way tinycudann does it: both features of a corner in ONE packed
- * fp16 atomic (global atomics retire at the same rate whatever their width, so this halves the
- * pass).  Contributions are scaled by a power of two derived from max|d_feat| (the largest lands
- * at 64: no overflow below ~1000 maximal contributions per entry, 11-bit precision down to 1e-6 of
- * the largest), accumulated in a half2 table inside `workspace`
- * (nerf_hash_bwd_f16_workspace_bytes(entries), 256-B aligned), then unscaled into d_table
- * [entries, 2] fp32, which is OVERWRITTEN (not accumulated into).  Stated tolerance against the
- * fp32 scatter: 2e-3 of the largest gradient of the table. */
-size_t nerf_hash_bwd_f16_workspace_bytes(int64_t entries);
-int nerf_hash_encode_bwd_f16(const float* pts, int64_t n, int n_levels, const float* scale_host,
-                             const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
-                             const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
-                             int64_t entries, void* workspace, nerf_stream_t stream);
+
 
 /* ---- a7: Instant decoder (two bias-free tiny MLPs, bf16 MFMA) -----------------------
  * replaces the two tinycudann FullyFusedMLP networks of InstantNeRFDecoder

@@ -10,7 +10,6 @@
 // 16 levels x 8 corners x 8 B (fp32 table) per point; the 52 MB table lives in the 256 MB
 // Infinity Cache.  Backward: 16 float atomics per (point, level).
 #include <stdlib.h>
-#include <hip/hip_fp16.h>
 #include "common.h"
 
 namespace nerf {
@@ -110,12 +109,12 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const f
 // unrelated regions.  Levels whose whole table fits in LDS (<= kLdsEntries entries: the dense
 // 16^3 and 24^3 levels, where thousands of samples hit each cell) are reduced in LDS first and
 // flushed with one well-shaped (contiguous) global atomic per entry per workgroup.
-// The larger levels stay on global float atomics, ~21 G/s on MI355X wherever they land.  Two
-// alternatives were built and measured on 200 k points (2.4 ms as is): entries sliced per XCD by
-// HW_REG_XCC_ID so that every 128-byte line stays in one L2 -- 2.4 ms, no change; owner-computes
-// (a workgroup per 16384-entry slice scans the whole batch into LDS, level-major gradient copy,
-// plain read-modify-write flush) -- 3.0 ms, the 32-fold recomputation of the corner hashes costs
-// more than the atomics it removes.
+// The larger levels use global float atomics, coalesced four lanes per (point, level) (see the
+// kernel body).  Built, measured on 200 k points and dropped: entries sliced per XCD by
+// HW_REG_XCC_ID so that every 128-byte line stays in one L2 -- no change; owner-computes (a
+// workgroup per 16384-entry slice scans the whole batch into LDS) -- slower, the 32-fold
+// recomputation of the corner hashes costs more than the atomics it removes; a packed-fp16
+// gradient table (one atomic per corner) -- 1.29 ms against 0.72 ms for the coalesced fp32 form.
 constexpr int kLdsEntries = 16384;      // 128 KiB of float2
 template <bool in_lds>
 __global__ void __launch_bounds__(512)
@@ -128,18 +127,37 @@ hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0
     for (unsigned i = threadIdx.x; i < 2 * size; i += blockDim.x) lds_acc[i] = 0.0f;
     __syncthreads();
   }
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-    const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0], g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1];
-    if (g0 == 0.0f && g1 == 0.0f) continue;
-    const Corner c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
+  if (in_lds) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+      const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0], g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1];
+      if (g0 == 0.0f && g1 == 0.0f) continue;
+      const Corner c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (in_lds) {
+      for (int k = 0; k < 8; ++k) {
         atomicAdd(lds_acc + 2 * (c.idx[k] - offset) + 0, c.w[k] * g0);
         atomicAdd(lds_acc + 2 * (c.idx[k] - offset) + 1, c.w[k] * g1);
-      } else {
-        atomicAdd(d_table + 2 * (size_t)c.idx[k] + 0, c.w[k] * g0);
-        atomicAdd(d_table + 2 * (size_t)c.idx[k] + 1, c.w[k] * g1);
+      }
+    }
+  } else {
+    // Global float atomics retire per 128-byte LINE REQUEST (~21 G/s on MI355X), not per lane: lanes
+    // of one instruction that fall into the same line are merged (tools/probe/atomic_rate.hip: 2
+    // lanes per line 42 G elements/s, 16 per line 324 G/s).  Four consecutive lanes therefore share
+    // one (point, level): lane bit 0 = feature, bit 1 = the x offset of the corner.  Each of the four
+    // instructions (one per (dy, dz)) then carries, per point, the two features of the two
+    // x-neighbouring corners -- 16 adjacent bytes in 15 of 16 cases, since the x coordinate enters
+    // the index with prime 1 -- i.e. 4 line requests per point and level instead of 16.
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < 4 * n; t += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t p = t >> 2;
+      const int f = (int)(t & 1), dx = (int)((t >> 1) & 1);
+      const float g = d_feat[p * (2 * L.n_levels) + 2 * lvl + f];
+      if (g == 0.0f) continue;
+      const Corner c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // corner index bit 0 is the x offset (corners_of); selects, not a runtime-indexed array
+        const unsigned e = dx ? c.idx[2 * q + 1] : c.idx[2 * q];
+        const float w = dx ? c.w[2 * q + 1] : c.w[2 * q];
+        atomicAdd(d_table + 2 * (size_t)e + f, w * g);
       }
     }
   }
@@ -149,80 +167,6 @@ hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0
       const float v = lds_acc[i];
       if (v != 0.0f) atomicAdd(d_table + 2 * (size_t)offset + i, v);
     }
-  }
-}
-
-// ---- packed-fp16 gradient table (what tinycudann itself accumulates in) ----------------------
-// Global atomics retire at ~21 G operations/s on MI355X whatever their width (tools/probe/
-// atomic_rate.hip: two fp32 adds per element 10.4 G elements/s, one packed fp16 pair or one 64-bit
-// add 21-24 G/s), and the fp32 scatter needs two per corner.  Here both features of a corner go out
-// as ONE global_atomic_pk_add_f16 into a half2 table, scaled by a power of two chosen from
-// max|d_feat| so that the largest contribution lands at 64 (room for 1000 of them per entry below
-// the fp16 maximum, full 11-bit precision down to 1e-6 of the largest); the table is then
-// converted back to fp32 and unscaled.  Levels that fit in LDS still accumulate in fp32 there.
-__global__ void __launch_bounds__(256)
-absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out_bits) {
-  float m = 0.0f;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(x[i]));
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  __shared__ float part[4];
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
-}
-
-// power-of-two scale that maps absmax to [32, 64]; 1 for an all-zero (or non-finite) gradient
-__device__ __forceinline__ float f16_grad_scale(unsigned absmax_bits) {
-  const float a = __uint_as_float(absmax_bits);
-  if (!(a > 0.0f) || !(a < 3.0e38f)) return 1.0f;
-  int e;
-  frexpf(a, &e);                       // a = m * 2^e, m in [0.5, 1)
-  return ldexpf(1.0f, 6 - e);
-}
-
-template <bool in_lds>
-__global__ void __launch_bounds__(512)
-hash_bwd_f16_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0, const float* __restrict__ d_feat,
-                    __half2* __restrict__ g16, const unsigned* __restrict__ absmax_bits) {
-  extern __shared__ __attribute__((aligned(16))) float lds_acc[];
-  const int lvl = lvl0 + blockIdx.y;
-  const unsigned size = L.size[lvl], offset = L.offset[lvl];
-  const float S = f16_grad_scale(*absmax_bits);
-  if (in_lds) {
-    for (unsigned i = threadIdx.x; i < 2 * size; i += blockDim.x) lds_acc[i] = 0.0f;
-    __syncthreads();
-  }
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-    const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0] * S, g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1] * S;
-    if (g0 == 0.0f && g1 == 0.0f) continue;
-    const Corner c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (in_lds) {
-        atomicAdd(lds_acc + 2 * (c.idx[k] - offset) + 0, c.w[k] * g0);
-        atomicAdd(lds_acc + 2 * (c.idx[k] - offset) + 1, c.w[k] * g1);
-      } else {
-        unsafeAtomicAdd(g16 + c.idx[k], __floats2half2_rn(c.w[k] * g0, c.w[k] * g1));
-      }
-    }
-  }
-  if (in_lds) {
-    __syncthreads();
-    for (unsigned i = threadIdx.x; i < size; i += blockDim.x) {
-      const float v0 = lds_acc[2 * i], v1 = lds_acc[2 * i + 1];
-      if (v0 != 0.0f || v1 != 0.0f) unsafeAtomicAdd(g16 + offset + i, __floats2half2_rn(v0, v1));
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256)
-hash_grad_unscale_kernel(const __half2* __restrict__ g16, int64_t entries, const unsigned* __restrict__ absmax_bits,
-                         float2* __restrict__ out) {
-  const float inv = 1.0f / f16_grad_scale(*absmax_bits);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < entries; i += (int64_t)gridDim.x * blockDim.x) {
-    const float2 v = __half22float2(g16[i]);
-    out[i] = make_float2(v.x * inv, v.y * inv);
   }
 }
 
@@ -288,8 +232,8 @@ extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, c
                        d_feat, d_table);
   }
   if (n_small < n_levels) {
-    int64_t bx = (n + 511) / 512;
-    if (bx > 256) bx = 256;
+    int64_t bx = (4 * n + 511) / 512;
+    if (bx > 1024) bx = 1024;
     int first = n_small, count = n_levels - n_small;
     if (const char* only = getenv("NERF_HASH_BWD_ONLY_LEVEL")) {   // development aid: time one level's atomics
       first = atoi(only);
@@ -300,56 +244,4 @@ extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, c
                        first, d_feat, d_table);
   }
   return check_launch("nerf_hash_encode_bwd");
-}
-
-extern "C" size_t nerf_hash_bwd_f16_workspace_bytes(int64_t entries) {
-  return entries > 0 ? 256 + (size_t)entries * sizeof(__half2) : 0;
-}
-
-extern "C" int nerf_hash_encode_bwd_f16(const float* pts, int64_t n, int n_levels, const float* scale_host,
-                                        const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
-                                        const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
-                                        int64_t entries, void* workspace, nerf_stream_t stream) {
-  NERF_REQUIRE(n >= 0 && entries > 0, "nerf_hash_encode_bwd_f16: n=%lld entries=%lld", (long long)n, (long long)entries);
-  NERF_REQUIRE(d_table && workspace && (((uintptr_t)workspace) & 255) == 0, "nerf_hash_encode_bwd_f16: NULL / misaligned pointer");
-  if (n == 0) {
-    if (hipMemsetAsync(d_table, 0, (size_t)entries * 8, as_stream(stream)) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_f16: memset failed");
-    return NERF_OK;
-  }
-  NERF_REQUIRE(pts && d_feat && scale_host && res_host && size_host && offset_host && dense_host,
-               "nerf_hash_encode_bwd_f16: NULL pointer");
-  HashLevels L;
-  int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
-  if (rc != NERF_OK) return rc;
-  NERF_REQUIRE((int64_t)offset_host[n_levels - 1] + size_host[n_levels - 1] <= entries,
-               "nerf_hash_encode_bwd_f16: level table exceeds entries=%lld", (long long)entries);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)hash_bwd_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEntries * 8) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_f16: cannot raise dynamic LDS limit");
-    attr_set = true;
-  }
-  unsigned* absmax = static_cast<unsigned*>(workspace);
-  __half2* g16 = reinterpret_cast<__half2*>(static_cast<char*>(workspace) + 256);
-  if (hipMemsetAsync(workspace, 0, 256 + (size_t)entries * sizeof(__half2), as_stream(stream)) != hipSuccess)
-    return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_f16: memset failed");
-  hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, as_stream(stream), d_feat, n * 2 * n_levels, absmax);
-  int n_small = 0;
-  while (n_small < n_levels && size_host[n_small] <= (unsigned)kLdsEntries) ++n_small;
-  if (n_small > 0) {
-    int64_t bx = (n + 511) / 512;
-    if (bx > 128) bx = 128;
-    hipLaunchKernelGGL(hash_bwd_f16_kernel<true>, dim3((int)bx, n_small), dim3(512), kLdsEntries * 8, as_stream(stream), pts, n, L, 0,
-                       d_feat, g16, absmax);
-  }
-  if (n_small < n_levels) {
-    int64_t bx = (n + 511) / 512;
-    if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(hash_bwd_f16_kernel<false>, dim3((int)bx, n_levels - n_small), dim3(512), 0, as_stream(stream), pts, n, L,
-                       n_small, d_feat, g16, absmax);
-  }
-  hipLaunchKernelGGL(hash_grad_unscale_kernel, dim3(2048), dim3(256), 0, as_stream(stream), g16, entries, absmax,
-                     reinterpret_cast<float2*>(d_table));
-  return check_launch("nerf_hash_encode_bwd_f16");
 }

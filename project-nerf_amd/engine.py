@@ -212,10 +212,6 @@ class InstantNgpEngine:
         self.binary_grid = torch.ones(res, res, res, dtype=torch.bool, device=self.device)
         self.step_count, self.world_size = 0, world_size
         self._scratch = torch.empty(1, device=self.device)
-        # hash-table gradients accumulated in packed fp16 (one atomic per corner, tinycudann's own
-        # accumulation type) unless the config asks for the fp32 scatter (two atomics per corner)
-        self.hash_grad_fp16 = bool(cfg.get("hash_grad_fp16", True))
-        self._ws16 = None
 
     def lr(self) -> float:
         import math
@@ -240,8 +236,7 @@ class InstantNgpEngine:
         z, slots, pts, dirs = ops.sample_compact(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid,
                                                  self.bound, u=u)
         n = pts.shape[0]
-        if not self.hash_grad_fp16 or n == 0:
-            self.g_table.zero_()
+        self.g_table.zero_()
         if n == 0:
             self.g_net.zero_()
             pred = self.bg.expand(R, 3)
@@ -265,10 +260,7 @@ class InstantNgpEngine:
             d_feat = torch.empty(n, 2 * self.levels.n_levels, device=self.device)
             ops._lib.check(lib.nerf_imlp_bwd(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
                                              P(self.g_net), P(d_feat), ops._stream()), "nerf_imlp_bwd")
-            if self.hash_grad_fp16:
-                self._ws16 = ops.hash_encode_bwd_f16(pts, self.levels, self.bound, d_feat, self.g_table, self._ws16)
-            else:
-                ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table)
+            ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table)
         if sync_grads is not None:
             sync_grads(self.g_table)
             sync_grads(self.g_net)

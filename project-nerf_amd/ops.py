@@ -409,21 +409,6 @@ def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: T
                                         _p(d_feat), _p(d_table), _stream()), "nerf_hash_encode_bwd")
 
 
-def hash_encode_bwd_f16(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor, d_table: Tensor,
-                        workspace: Optional[Tensor] = None) -> Tensor:
-    """d_table [entries, 2] = scatter of d_feat, accumulated in packed fp16 (one atomic per corner, as
-    tinycudann does) and unscaled to fp32; OVERWRITES d_table.  Returns the workspace for reuse."""
-    lib = _lib.load()
-    pts, d_feat = _dev(pts, "pts"), _dev(d_feat, "d_feat")
-    entries = d_table.numel() // 2
-    if workspace is None:
-        workspace = torch.empty(lib.nerf_hash_bwd_f16_workspace_bytes(entries), dtype=torch.uint8, device=pts.device)
-    _lib.check(lib.nerf_hash_encode_bwd_f16(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
-                                            _p(d_feat), _p(d_table), entries, _p(workspace), _stream()),
-               "nerf_hash_encode_bwd_f16")
-    return workspace
-
-
 IMLP_PARAM_COUNT = 11264
 IMLP_SIGMA_PARAMS = 3072
 

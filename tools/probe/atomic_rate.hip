@@ -12,6 +12,11 @@ __global__ void __launch_bounds__(512) k(float* t32, __half2* t16, unsigned long
     if (MODE == 1) atomicAdd(t32 + 2 * (size_t)e, 1.0f);
     if (MODE == 2) unsafeAtomicAdd(t16 + e, __floats2half2_rn(1.0f, 2.0f));
     if (MODE == 3) atomicAdd(t64 + e, 0x0000000100000002ull);
+    // lanes in groups of 2 / 4 / 16 land in the same 128-byte line (adjacent half2 entries)
+    if (MODE == 4) unsafeAtomicAdd(t16 + ((hsh((unsigned)i >> 1) & mask & ~1u) | (i & 1)), __floats2half2_rn(1.0f, 2.0f));
+    if (MODE == 5) unsafeAtomicAdd(t16 + ((hsh((unsigned)i >> 2) & mask & ~3u) | (i & 3)), __floats2half2_rn(1.0f, 2.0f));
+    if (MODE == 6) unsafeAtomicAdd(t16 + ((hsh((unsigned)i >> 4) & mask & ~15u) | (i & 15)), __floats2half2_rn(1.0f, 2.0f));
+    if (MODE == 7) { const unsigned b = (hsh((unsigned)i >> 1) & mask & ~1u) | (i & 1); atomicAdd(t32 + 2 * (size_t)b, 1.0f); atomicAdd(t32 + 2 * (size_t)b + 1, 2.0f); }
   }
 }
 template <int MODE>
@@ -36,5 +41,9 @@ int main() {
   run<1>(t32, t16, t64, entries - 1, n, "1 x fp32 atomic");
   run<2>(t32, t16, t64, entries - 1, n, "1 x packed fp16 pair");
   run<3>(t32, t16, t64, entries - 1, n, "1 x 64-bit integer add");
+  run<4>(t32, t16, t64, entries - 1, n, "fp16 pair, 2 lanes per line");
+  run<5>(t32, t16, t64, entries - 1, n, "fp16 pair, 4 lanes per line");
+  run<6>(t32, t16, t64, entries - 1, n, "fp16 pair, 16 lanes per line");
+  run<7>(t32, t16, t64, entries - 1, n, "2 x fp32, 2 lanes per line");
   return 0;
 }
