@@ -50,6 +50,17 @@ int nerf_sample_rays(const float* rays_o, const float* rays_d, const float* u,
                      int64_t n_rays, int n_samples, float near_plane, float far_plane,
                      float* z_out, float* pts_out, float* dirs_out, nerf_stream_t stream);
 
+/* ---- f1: batch sampling from device-resident frames ------------------------------
+ * replaces the body of BlenderDataset.sample_random_rays after its three index draws
+ * (src/dataset.py:150-171): pixel -> camera direction ((x - W/2)/f, -(y - H/2)/f, -1), rotation by
+ * c2w[:3,:3], normalisation, origin = c2w[:3,3] * scene_scale, RGBA fetch.
+ *   images [n_images,H,W,4] fp32, poses [n_images,4,4] fp32 row-major, img_idx / pix_y / pix_x [batch]
+ *   int64 (the caller draws them; values must be in range) -> rays_o [batch,3], rays_d [batch,3]
+ *   unit, rgba [batch,4]. */
+int nerf_gather_rays(const float* images, const float* poses, const int64_t* img_idx, const int64_t* pix_y,
+                     const int64_t* pix_x, int64_t batch, int n_images, int H, int W, float focal,
+                     float scene_scale, float* rays_o, float* rays_d, float* rgba, nerf_stream_t stream);
+
 /* ---- a3: occupancy lookup ---------------------------------------------------
  * replaces DensityGrid.get_active_mask (src/renderer.py:134-166).
  *   pts [N,3]; binary_grid [res,res,res] bytes (torch.bool storage);

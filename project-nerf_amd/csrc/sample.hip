@@ -82,6 +82,38 @@ active_mask_kernel(const float* __restrict__ pts, int64_t n, const uint8_t* __re
   }
 }
 
+// Batch sampling from GPU-resident frames: the body of
+// BlenderDataset.sample_random_rays after the three index draws (reference src/dataset.py:150-171)
+// -- camera-space direction of the pixel (no +0.5 centre offset, -y, -z), rotation by c2w[:3,:3],
+// normalisation, origin = c2w[:3,3] * scene_scale, RGBA fetch -- as one kernel instead of a
+// batched 3x3 GEMM plus a dozen elementwise launches.
+__global__ void __launch_bounds__(256)
+gather_rays_kernel(const float* __restrict__ images, const float* __restrict__ poses, const int64_t* __restrict__ img_idx,
+                   const int64_t* __restrict__ pix_y, const int64_t* __restrict__ pix_x, int64_t batch, int H, int W,
+                   float half_w, float half_h, float focal, float scene_scale, float* __restrict__ rays_o,
+                   float* __restrict__ rays_d, float* __restrict__ rgba) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < batch; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t im = img_idx[r], py = pix_y[r], px = pix_x[r];
+    const float* c2w = poses + im * 16;
+    const float x = sub_rn((float)px, half_w) / focal;
+    const float y = -(sub_rn((float)py, half_h) / focal);
+    const float z = -1.0f;
+    float d[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      d[i] = add_rn(add_rn(mul_rn(c2w[4 * i + 0], x), mul_rn(c2w[4 * i + 1], y)), mul_rn(c2w[4 * i + 2], z));
+    const float nrm = sqrtf(add_rn(add_rn(mul_rn(d[0], d[0]), mul_rn(d[1], d[1])), mul_rn(d[2], d[2])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      rays_d[r * 3 + i] = d[i] / nrm;
+      const float o = c2w[4 * i + 3];
+      rays_o[r * 3 + i] = scene_scale != 1.0f ? mul_rn(o, scene_scale) : o;
+    }
+    const float4 c = *reinterpret_cast<const float4*>(images + ((im * H + py) * W + px) * 4);
+    *reinterpret_cast<float4*>(rgba + r * 4) = c;
+  }
+}
+
 static inline int grid_for(int64_t work, int block) {
   int64_t b = (work + block - 1) / block;
   if (b > 256 * 8) b = 256 * 8;
@@ -120,4 +152,16 @@ extern "C" int nerf_active_mask(const float* pts, int64_t n, const uint8_t* bina
   hipLaunchKernelGGL(active_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), pts,
                      n, binary_grid, resolution, bound, scale, mask_out, idx_out);
   return check_launch("nerf_active_mask");
+}
+
+extern "C" int nerf_gather_rays(const float* images, const float* poses, const int64_t* img_idx, const int64_t* pix_y,
+                                const int64_t* pix_x, int64_t batch, int n_images, int H, int W, float focal,
+                                float scene_scale, float* rays_o, float* rays_d, float* rgba, nerf_stream_t stream) {
+  NERF_REQUIRE(batch >= 0 && n_images > 0 && H > 0 && W > 0 && focal > 0.0f, "nerf_gather_rays: bad sizes");
+  if (batch == 0) return NERF_OK;
+  NERF_REQUIRE(images && poses && img_idx && pix_y && pix_x && rays_o && rays_d && rgba, "nerf_gather_rays: NULL pointer");
+  NERF_REQUIRE((((uintptr_t)images | (uintptr_t)rgba) & 15) == 0, "nerf_gather_rays: images / rgba must be 16-byte aligned");
+  hipLaunchKernelGGL(gather_rays_kernel, dim3(grid_for(batch, 256)), dim3(256), 0, as_stream(stream), images, poses, img_idx,
+                     pix_y, pix_x, batch, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, rays_o, rays_d, rgba);
+  return check_launch("nerf_gather_rays");
 }

@@ -72,6 +72,11 @@ class BlenderDataset:
         img = torch.randint(0, len(self), (batch_size,), device=dev)
         py = torch.randint(0, self.H, (batch_size,), device=dev)
         px = torch.randint(0, self.W, (batch_size,), device=dev)
+        if dev.type == "cuda" and dev == torch.device(device):
+            # frames resident on the GPU (``.to(device)``): one kernel instead of a batched 3x3 GEMM
+            # and a dozen elementwise launches (0.22 ms of a 1.5 ms Instant-NGP step)
+            from . import ops
+            return ops.gather_rays(self.images, self.poses, img, py, px, self.focal, self.scene_scale)
         c2w = self.poses[img]
         dirs = torch.stack([(px - self.W * 0.5) / self.focal, -(py - self.H * 0.5) / self.focal,
                             -torch.ones_like(px)], dim=-1)

@@ -68,6 +68,23 @@ def active_mask(pts: Tensor, binary_grid: Tensor, bound: float, want_index: bool
     return (mask, idx) if want_index else mask
 
 
+# --------------------------------------------------------------------------- f1 batch sampling
+def gather_rays(images: Tensor, poses: Tensor, img_idx: Tensor, pix_y: Tensor, pix_x: Tensor, focal: float,
+                scene_scale: float = 1.0) -> Tuple[Tensor, Tensor, Tensor]:
+    """Rays and RGBA targets of the drawn pixels from device-resident frames (one kernel)."""
+    lib = _lib.load()
+    images, poses = _dev(images, "images"), _dev(poses, "poses")
+    n_img, H, W, _ = images.shape
+    B = img_idx.numel()
+    idx = [_dev(t.to(torch.int64), "index", torch.int64) for t in (img_idx, pix_y, pix_x)]
+    o = torch.empty(B, 3, device=images.device)
+    d = torch.empty(B, 3, device=images.device)
+    rgba = torch.empty(B, 4, device=images.device)
+    _lib.check(lib.nerf_gather_rays(_p(images), _p(poses), _p(idx[0]), _p(idx[1]), _p(idx[2]), B, n_img, H, W, float(focal),
+                                    float(scene_scale), _p(o), _p(d), _p(rgba), _stream()), "nerf_gather_rays")
+    return o, d, rgba
+
+
 # --------------------------------------------------------------------------- a1-a4 fused
 def sample_compact(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_samples: int,
                    binary_grid: Tensor, bound: float, u: Optional[Tensor] = None):
