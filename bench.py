@@ -321,12 +321,12 @@ def main():
         # activations 64+8*256+256+128+32 and gradients 16+128+256+8*256 bf16 per sample
         wgrad_bytes = WGRAD_BYTES * ((n + 255) // 256 * 256)
         roofs = {
-            "mlp_fwd_train": {"bound": "mfma", "kernel": "mlp_fwd_kernel<true>", "achieved": kern["mlp_fwd_train"]["tflops"],
+            "mlp_fwd_train": {"bound": "mfma", "kernel": "mlp_fwd_stream_kernel<true>", "achieved": kern["mlp_fwd_train"]["tflops"],
                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kern["mlp_fwd_train"]["tflops"] / MFMA_PEAK_TFLOPS,
-                              "traffic": traffic("mlp_fwd_kernel<true>"), "work_per_launch": n * FWD_FLOP, "launch_ms": k["mlp_fwd_train"]},
-            "mlp_bwd_dgrad": {"bound": "mfma", "kernel": "mlp_bwd_kernel", "achieved": kern["mlp_bwd_dgrad"]["tflops"],
+                              "traffic": traffic("mlp_fwd_stream_kernel<true>"), "work_per_launch": n * FWD_FLOP, "launch_ms": k["mlp_fwd_train"]},
+            "mlp_bwd_dgrad": {"bound": "mfma", "kernel": "mlp_bwd_stream_kernel", "achieved": kern["mlp_bwd_dgrad"]["tflops"],
                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kern["mlp_bwd_dgrad"]["tflops"] / MFMA_PEAK_TFLOPS,
-                              "traffic": traffic("mlp_bwd_kernel"), "work_per_launch": n * DGRAD_FLOP, "launch_ms": k["mlp_bwd_dgrad"]},
+                              "traffic": traffic("mlp_bwd_stream_kernel"), "work_per_launch": n * DGRAD_FLOP, "launch_ms": k["mlp_bwd_dgrad"]},
             "mlp_bwd_wgrad": {"bound": "hbm", "kernel": "mlp_wgrad_kernel", "achieved": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6 / HBM_PEAK_GBS,
                               "traffic": traffic("mlp_wgrad_kernel"), "work_per_launch": wgrad_bytes, "launch_ms": k["mlp_bwd_wgrad"]},

@@ -199,20 +199,17 @@ def test_decoder_point_mode_vs_reference_golden(ops):
 @pytest.fixture
 def chain_family(request, monkeypatch):
     """selects the chain-kernel family per call (mlp_stash.h::chain_use_stream reads the environment)"""
-    for k in ("NERF_CHAIN_LEGACY", "NERF_CHAIN_STREAM_TRAIN"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("NERF_CHAIN_LEGACY", raising=False)
     if request.param == "compiler-scheduled":
         monkeypatch.setenv("NERF_CHAIN_LEGACY", "1")
-    elif request.param == "asm-stream":
-        monkeypatch.setenv("NERF_CHAIN_STREAM_TRAIN", "1")
     return request.param
 
 
-@pytest.mark.parametrize("chain_family", ["default", "compiler-scheduled"], indirect=True)
+@pytest.mark.parametrize("chain_family", ["asm-stream", "compiler-scheduled"], indirect=True)
 @pytest.mark.parametrize("R,S", [(1, 64), (7, 64), (96, 64), (33, 128), (300, 2), (1101, 64)])
 def test_decoder_ray_mode_ragged_tiles(ops, R, S, chain_family):
     """Tiles that are not multiples of 256 samples, scaled weights so that outputs vary; the asm-stream
-    inference kernel (default) and the compiler-scheduled one.  1101 x 64 = 276 tiles: more tiles than
+    kernels (default) and the compiler-scheduled ones.  1101 x 64 = 276 tiles: more tiles than
     CUs, so some workgroups run a second pass (look-ahead DMA and ring hand-over across passes)."""
     params = O.nerf_init_params(seed=R + S)
     params = {k: (v * 2.5 if k.endswith("weight") else v) for k, v in params.items()}
@@ -311,10 +308,10 @@ def test_decoder_training_families_agree_over_multiple_passes(ops, monkeypatch):
     d_rgb, d_sigma = dev(torch.randn(n, 3, generator=gen)), dev(torch.randn(n, generator=gen))
     packed = ops.mlp_pack(dev(flat_params(params)))
     out = {}
-    for fam, env in (("compiler-scheduled", "NERF_CHAIN_LEGACY"), ("asm-stream", "NERF_CHAIN_STREAM_TRAIN")):
-        for k in ("NERF_CHAIN_LEGACY", "NERF_CHAIN_STREAM_TRAIN"):
-            monkeypatch.delenv(k, raising=False)
-        monkeypatch.setenv(env, "1")
+    for fam in ("compiler-scheduled", "asm-stream"):
+        monkeypatch.delenv("NERF_CHAIN_LEGACY", raising=False)
+        if fam == "compiler-scheduled":
+            monkeypatch.setenv("NERF_CHAIN_LEGACY", "1")
         stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
         rgb, sigma = ops.mlp_fwd(packed, dev(o), dev(d), dev(z), stash)
         out[fam] = (rgb.cpu(), sigma.cpu(), ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb, d_sigma).cpu())
@@ -328,7 +325,7 @@ def test_decoder_training_families_agree_over_multiple_passes(ops, monkeypatch):
         assert float((ga - gb).norm() / (ga.norm() + 1e-12)) < 2e-2, name
 
 
-@pytest.mark.parametrize("chain_family", ["default", "compiler-scheduled", "asm-stream"], indirect=True)
+@pytest.mark.parametrize("chain_family", ["asm-stream", "compiler-scheduled"], indirect=True)
 @pytest.mark.parametrize("R,S", [(2, 64), (40, 64), (9, 128)])
 def test_decoder_backward_vs_oracle_autograd(ops, R, S, chain_family):
     """dgrad chain + wgrad vs autograd of the oracle, for both families of chain kernels.

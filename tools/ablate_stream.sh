@@ -7,5 +7,5 @@ for v in "${@}"; do
   IFS=: read no d <<< "$v"
   GEN_NO=$no GEN_D=${d:-4} python3 gen_stream_asm.py > mlp_stream_asm.h 2>/dev/null
   (cd ../.. && timeout 900 python3 project-nerf_amd/build.py -q > /dev/null) || exit 1
-  echo "== NO=$no D=${d:-4}: $(cd ../.. && NERF_CHAIN_STREAM_TRAIN=1 timeout -k 10 200 python3 tools/time_decoder.py 2>&1 | grep 'fwd\|bwd' | tr '\n' ' ')"
+  echo "== NO=$no D=${d:-4}: $(cd ../.. && timeout -k 10 200 python3 tools/time_decoder.py 2>&1 | grep 'fwd\|bwd' | tr '\n' ' ')"
 done
