@@ -75,10 +75,13 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const f
                 float* __restrict__ out_f32, __bf16* __restrict__ out_nat, unsigned* __restrict__ idx_out) {
   // the operand image is padded to whole 128-point tiles: pad rows repeat the last point so that
   // every stashed value is finite (their gradients are zero downstream)
-  const int64_t total = (out_nat != nullptr ? n_pad : n) * L.n_levels;
-  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = g / L.n_levels;
-    const int lvl = (int)(g - p * L.n_levels);
+  // level-major: blockIdx.y = level, consecutive lanes = consecutive points = neighbouring samples of a
+  // ray, so a wave's gathers at the coarse and middle levels fall into few cache lines (point-major,
+  // 16 lanes of a wave hit 16 different level tables)
+  const int64_t rows = out_nat != nullptr ? n_pad : n;
+  const int lvl = blockIdx.y;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < rows; p += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = p * L.n_levels + lvl;
     const int64_t ps = p < n ? p : n - 1;
     const Corner c = corners_of(L, lvl, pts[ps * 3 + 0], pts[ps * 3 + 1], pts[ps * 3 + 2]);
     float f0 = 0.0f, f1 = 0.0f;
@@ -201,9 +204,9 @@ extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* ta
   int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
   if (rc != NERF_OK) return rc;
   const int64_t n_pad = (n + 127) / 128 * 128;
-  int64_t blocks = (n_pad * n_levels + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(hash_fwd_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), pts, n, n_pad,
+  int64_t blocks = (n_pad + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(hash_fwd_kernel, dim3((int)blocks, n_levels), dim3(256), 0, as_stream(stream), pts, n, n_pad,
                      reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out);
   return check_launch("nerf_hash_encode_fwd");
 }
