@@ -40,6 +40,15 @@ typedef void* nerf_stream_t;
 const char* nerf_last_error(void);
 int nerf_abi_version(void);
 
+/* Development options (kernel-family selection, timing skeletons).  Defaults are read from the
+ * environment ONCE per process (NERF_CHAIN_LEGACY, NERF_FWD_CYCLES, NERF_WGRAD_OVH,
+ * NERF_WGRAD_DEBUG, NERF_WGRAD_ONLY, NERF_HASH_BWD_ONLY_LEVEL, NERF_STASH_BF16); afterwards they
+ * change only through nerf_set_option.  Names: "chain_legacy", "fwd_cycles", "wgrad_overhead",
+ * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "stash_bf16".  No hot-path launch reads the
+ * environment. */
+int nerf_set_option(const char* name, int value);
+int nerf_get_option(const char* name, int* value_out);
+
 /* ---- a1+a2: stratified depths and ray points ------------------------------
  * replaces sample_stratified (src/renderer.py:186-201) and the pts/view_dirs
  * block of render_rays (src/renderer.py:291-299).
@@ -257,12 +266,14 @@ int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 /* Fused regulariser + global-norm clip + AdamW for one flat parameter group:
  * replaces, per group, the TV-L1 term on `representation.encoding.params` and its backward
  * (run.py:611-618), clip_grad_norm_(group, max_norm) (run.py:624-627) and AdamW.step() (run.py:629).
- *   nerf_tv_normsq      : grads += tv_weight * d/dp mean|p[1:] - p[:-1]|  (tv_weight 0: skip), then
- *                         *normsq_dev = sum(grads^2)                       (device fp32 scalar)
+ *   nerf_tv_normsq      : grads = grads * grad_scale + tv_weight * d/dp mean|p[1:] - p[:-1]|  (tv_weight 0:
+ *                         no TV term; grad_scale = 1/world after a summing all-reduce: it scales the data
+ *                         gradient only, the regulariser is a function of the replicated parameters),
+ *                         then *normsq_dev = sum(grads^2)                  (device fp32 scalar)
  *   nerf_adamw_clip_step: AdamW with grads scaled by grad_scale * min(1, max_norm / (norm + 1e-6)),
  *                         norm = grad_scale * sqrt(*normsq_dev); normsq_dev NULL or max_norm <= 0: no clip. */
-int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float* normsq_dev,
-                   nerf_stream_t stream);
+int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
+                   float* normsq_dev, nerf_stream_t stream);
 int nerf_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                          int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                          const float* normsq_dev, float max_norm, float grad_scale, nerf_stream_t stream);

@@ -22,6 +22,8 @@ size_t = ctypes.c_size_t
 PROTOTYPES = {
     "nerf_last_error": (ctypes.c_char_p, []),
     "nerf_abi_version": (i32, []),
+    "nerf_set_option": (i32, [ctypes.c_char_p, i32]),
+    "nerf_get_option": (i32, [ctypes.c_char_p, ctypes.POINTER(i32)]),
     "nerf_sample_rays": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_gather_rays": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, i32, i32, f32, f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_active_mask": (i32, [c_ptr, i64, c_ptr, i32, f32, c_ptr, c_ptr, c_ptr]),
@@ -55,7 +57,7 @@ PROTOTYPES = {
     "nerf_imlp_fwd": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
     "nerf_imlp_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_adam_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, c_ptr]),
-    "nerf_tv_normsq": (i32, [c_ptr, c_ptr, i64, f32, c_ptr, c_ptr]),
+    "nerf_tv_normsq": (i32, [c_ptr, c_ptr, i64, f32, f32, c_ptr, c_ptr]),
     "nerf_adamw_clip_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr]),
 }
 
@@ -85,6 +87,17 @@ def load():
         raise NerfHipError(f"ABI version mismatch: library reports {lib.nerf_abi_version()}, binding expects 1")
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int) -> None:
+    """Development switch of the library (kernel family, timing skeletons); see include/nerf_hip.h."""
+    check(load().nerf_set_option(name.encode(), int(value)), f"nerf_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    out = i32(0)
+    check(load().nerf_get_option(name.encode(), ctypes.byref(out)), f"nerf_get_option({name})")
+    return out.value
 
 
 def check(code, what):

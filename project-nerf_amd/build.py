@@ -48,11 +48,21 @@ def _compile(src, verbose):
 GENERATED = {"mlp_mtile_asm.h": "gen_mtile_asm.py", "mlp_stream_asm.h": "gen_stream_asm.py"}
 
 
+def _default_config(header):
+    """False for a header generated with timing ablations or a non-default window depth
+    (tools/ablate_stream.sh): such a stream is numerically wrong and must never be reused."""
+    with open(header) as f:
+        head = f.read(400)
+    cfg = [ln for ln in head.splitlines() if ln.startswith("// GEN_CONFIG")]
+    return not cfg or cfg[0].strip() == "// GEN_CONFIG D=4 NO="
+
+
 def _generate(verbose):
     """inline-asm headers are generated (and git-ignored): csrc/gen_*.py -> csrc/*.h"""
     for header, script in GENERATED.items():
         h, g = os.path.join(CSRC, header), os.path.join(CSRC, script)
-        if os.path.exists(h) and os.path.getmtime(h) > os.path.getmtime(g):
+        keep = os.environ.get("NERF_BUILD_KEEP_HEADERS") is not None      # tools/ablate_stream.sh only
+        if os.path.exists(h) and os.path.getmtime(h) > os.path.getmtime(g) and (keep or _default_config(h)):
             continue
         if verbose:
             print(f"{script} -> {header}", flush=True)

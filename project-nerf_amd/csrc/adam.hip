@@ -94,13 +94,17 @@ __device__ __forceinline__ float tv_term(float prev, float cur, float next, bool
 
 template <bool VEC>
 __global__ void __launch_bounds__(256)
-tv_normsq_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t n, float tv_scale,
+tv_normsq_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t n, float tv_scale, float grad_scale,
                  float* __restrict__ normsq) {
+  // grad_scale (1/world after a summing all-reduce) applies to the DATA gradient only: the TV term is
+  // a function of the replicated parameters and must not be divided by the world size
+  const bool rewrite = tv_scale != 0.0f || grad_scale != 1.0f;
   float local = 0.0f;
   const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n4 = VEC ? n / 4 : 0;
   for (int64_t i = tid; i < n4; i += stride) {
     f4 gg = reinterpret_cast<f4*>(g)[i];
+    gg[0] *= grad_scale; gg[1] *= grad_scale; gg[2] *= grad_scale; gg[3] *= grad_scale;
     if (tv_scale != 0.0f) {
       const f4 pp = reinterpret_cast<const f4*>(p)[i];
       const int64_t e0 = 4 * i;
@@ -109,16 +113,15 @@ tv_normsq_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t n, 
       gg[1] += tv_scale * tv_term(pp[0], pp[1], pp[2], true, true);
       gg[2] += tv_scale * tv_term(pp[1], pp[2], pp[3], true, true);
       gg[3] += tv_scale * tv_term(pp[2], pp[3], after, true, e0 + 4 < n);
-      reinterpret_cast<f4*>(g)[i] = gg;
     }
+    if (rewrite) reinterpret_cast<f4*>(g)[i] = gg;
     local += gg[0] * gg[0] + gg[1] * gg[1] + gg[2] * gg[2] + gg[3] * gg[3];
   }
   for (int64_t i = 4 * n4 + tid; i < n; i += stride) {
-    float gi = g[i];
-    if (tv_scale != 0.0f) {
+    float gi = g[i] * grad_scale;
+    if (tv_scale != 0.0f)
       gi += tv_scale * tv_term(i > 0 ? p[i - 1] : 0.0f, p[i], i + 1 < n ? p[i + 1] : 0.0f, i > 0, i + 1 < n);
-      g[i] = gi;
-    }
+    if (rewrite) g[i] = gi;
     local += gi * gi;
   }
   // one atomic per workgroup: 16 k same-address float atomics (one per wave) serialise in L2
@@ -144,8 +147,8 @@ adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
 
 }  // namespace nerf
 
-extern "C" int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float* normsq_dev,
-                              nerf_stream_t stream) {
+extern "C" int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
+                              float* normsq_dev, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && normsq_dev, "nerf_tv_normsq: bad arguments");
   if (hipMemsetAsync(normsq_dev, 0, sizeof(float), nerf::as_stream(stream)) != hipSuccess)
     return nerf::fail(NERF_ELAUNCH, "nerf_tv_normsq: memset failed");
@@ -156,10 +159,10 @@ extern "C" int nerf_tv_normsq(const float* params, float* grads, int64_t n, floa
   if (blocks > 1024) blocks = 1024;
   if ((((uintptr_t)params | (uintptr_t)grads) & 15) == 0)
     hipLaunchKernelGGL(nerf::tv_normsq_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
-                       tv_scale, normsq_dev);
+                       tv_scale, grad_scale, normsq_dev);
   else
     hipLaunchKernelGGL(nerf::tv_normsq_kernel<false>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
-                       tv_scale, normsq_dev);
+                       tv_scale, grad_scale, normsq_dev);
   return nerf::check_launch("nerf_tv_normsq");
 }
 

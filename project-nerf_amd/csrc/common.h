@@ -20,6 +20,23 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(nerf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Development options (api.cpp): defaults come from the environment, read ONCE per process
+// (NERF_CHAIN_LEGACY, NERF_WGRAD_DEBUG, ...); nerf_set_option() changes them afterwards.
+struct Options {
+  int chain_legacy = 0;          // compiler-scheduled chain kernels instead of the asm streams
+  int fwd_cycles = 0;            // print shader cycles per pass of the forward stream kernel
+  int wgrad_overhead = 98304;    // span cost model: fixed share per ring iteration (bytes)
+  int wgrad_debug = 0;           // skeleton timing: 1 no compute, 2 no DMA, 4 no flush
+  int wgrad_only = -1;           // keep one job kind
+  int hash_bwd_only_level = -1;  // time one level's atomics
+  int stash_bf16 = 0;            // training images in bf16 (round-1 format) instead of fp8
+};
+Options& options();
+
+// Per-device launch facts (api.cpp), keyed by the calling thread's current HIP device.
+int device_cu_count(int* n_cu);
+int ensure_dynamic_lds(const void* kernel, int bytes, const char* what);
+
 #define NERF_REQUIRE(cond, ...) \
   do {                          \
     if (!(cond)) return ::nerf::fail(NERF_EINVAL, __VA_ARGS__); \

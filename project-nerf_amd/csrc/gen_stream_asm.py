@@ -422,6 +422,7 @@ def emit_function(mode, p):
 def main():
     p = print
     p("// GENERATED by gen_stream_asm.py -- do not edit.  See that file for the design.")
+    p(f"// GEN_CONFIG D={D} NO={','.join(sorted(ABLATE))}")
     p("#pragma once\n")
     p("namespace nerf {\n")
     p(f"static_assert(plan::kChunkFrags == {CHUNK}, \"stream plan\");")

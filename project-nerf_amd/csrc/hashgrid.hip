@@ -222,12 +222,8 @@ extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, c
   HashLevels L;
   int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
   if (rc != NERF_OK) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)hash_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsEntries * 8) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd: cannot raise dynamic LDS limit");
-    attr_set = true;
-  }
+  rc = ensure_dynamic_lds((const void*)hash_bwd_kernel<true>, kLdsEntries * 8, "nerf_hash_encode_bwd");
+  if (rc != NERF_OK) return rc;
   int n_small = 0;                      // leading levels whose table fits in LDS
   while (n_small < n_levels && size_host[n_small] <= (unsigned)kLdsEntries) ++n_small;
   if (n_small > 0) {
@@ -240,8 +236,8 @@ extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, c
     int64_t bx = (4 * n + 511) / 512;
     if (bx > 1024) bx = 1024;
     int first = n_small, count = n_levels - n_small;
-    if (const char* only = getenv("NERF_HASH_BWD_ONLY_LEVEL")) {   // development aid: time one level's atomics
-      first = atoi(only);
+    if (options().hash_bwd_only_level >= 0) {   // development aid: time one level's atomics
+      first = options().hash_bwd_only_level;
       count = 1;
       if (first < n_small || first >= n_levels) return check_launch("nerf_hash_encode_bwd");
     }

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(kIThreads) imlp_bwd_kernel(const IArgs a) {
       g0 = a.d_rgb[n * 3 + 0] * r0 * (1.0f - r0);
       g1 = a.d_rgb[n * 3 + 1] * r1 * (1.0f - r1);
       g2 = a.d_rgb[n * 3 + 2] * r2 * (1.0f - r2);
-      gs = a.d_sigma[n] * (1.0f - expf(-a.sigma[n]));          // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+      gs = a.d_sigma[n] * -expm1f(-a.sigma[n]);                // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x)), no cancellation
     }
     bf16x8 small;
 #pragma unroll
@@ -264,13 +264,8 @@ static IArgs iargs(const void* packed, void* ws, const float* dirs, int64_t n, f
 }
 
 static int grid_for_tiles(int64_t tiles) {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    n_cu = prop.multiProcessorCount;
-  }
+  int n_cu = 0;
+  if (device_cu_count(&n_cu) != NERF_OK) return -1;
   const int64_t cap = (int64_t)n_cu * 4;
   return (int)(tiles < cap ? tiles : cap);
 }

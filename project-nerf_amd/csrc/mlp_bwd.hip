@@ -219,20 +219,14 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
   a.dhv = reinterpret_cast<__bf16*>(w + bl.dhv);
   a.dfeat = reinterpret_cast<__bf16*>(w + bl.dfeat);
   a.dh = reinterpret_cast<__bf16*>(w + bl.dh);
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_mlp_bwd: cannot query device");
-    if (hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mlp_bwd_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_mlp_bwd: cannot raise dynamic LDS limit to %d", kChainLds);
-    n_cu = prop.multiProcessorCount;
-  }
+  int n_cu = 0;
+  if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
+  const bool stream_family = chain_use_stream(n, true);
+  if (int rc = ensure_dynamic_lds(stream_family ? (const void*)mlp_bwd_stream_kernel : (const void*)mlp_bwd_kernel, kChainLds,
+                                  "nerf_mlp_bwd"); rc != NERF_OK) return rc;
   const int64_t tiles = bl.n_pad / kTileSamples;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
-  if (chain_use_stream(n, true))
+  if (stream_family)
     hipLaunchKernelGGL(mlp_bwd_stream_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);

@@ -5,8 +5,8 @@
 // tile of one step, cast to bf16, IS the MFMA B operand of the next).  Weights stream
 // through a 2 x 64 KiB LDS ring (global_load_lds_dwordx4), biases sit in LDS as the
 // accumulators' initial values.  MFMA-bound: 1,186,816 FLOP per sample (+ padding).
-// TRAIN additionally stashes bf16 activations (row-major [n, width], the wgrad kernel's B
-// operands) and ReLU bitmasks for the backward chain.
+// TRAIN additionally stashes every layer input as a blocked image (mlp_chain.h::stash_block, the
+// wgrad kernel's B operands) and ReLU bitmasks for the backward chain.
 #include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -299,28 +299,16 @@ extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float
     a.st_denc = reinterpret_cast<__bf16*>(b + s.denc);
     a.st_mask = reinterpret_cast<uint4*>(b + s.mask);
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_mlp_fwd: cannot query device");
-    n_cu = prop.multiProcessorCount;
-  }
+  int n_cu = 0;
+  if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
   const int64_t tiles = (n + kTileSamples - 1) / kTileSamples;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
   const bool legacy = !chain_use_stream(n, stash != nullptr);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mlp_fwd_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mlp_fwd_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_mlp_fwd: cannot raise dynamic LDS limit to %d", kChainLds);
-    attr_set = true;
-  }
+  const void* kernel = legacy ? (stash != nullptr ? (const void*)mlp_fwd_kernel<true> : (const void*)mlp_fwd_kernel<false>)
+                              : (stash != nullptr ? (const void*)mlp_fwd_stream_kernel<true> : (const void*)mlp_fwd_stream_kernel<false>);
+  if (int rc = ensure_dynamic_lds(kernel, kChainLds, "nerf_mlp_fwd"); rc != NERF_OK) return rc;
   static unsigned long long* dbg = nullptr;
-  if (getenv("NERF_FWD_CYCLES") != nullptr && !legacy) {
+  if (options().fwd_cycles && !legacy) {
     if (dbg == nullptr && hipMalloc(&dbg, 16) != hipSuccess) return fail(NERF_ELAUNCH, "nerf_mlp_fwd: debug buffer");
     (void)hipMemsetAsync(dbg, 0, 16, as_stream(stream));
     a.dbg_cycles = dbg;

@@ -162,9 +162,8 @@ constexpr size_t kPackBwdOff = kPackFwdOff + (size_t)kFwdFrags * kFragBytes + kS
 constexpr size_t kPackBiasOff = kPackBwdOff + (size_t)kBwdFrags * kFragBytes + kStreamPad;
 constexpr size_t kPackBytes = kPackBiasOff + ((kBiasFloats * 4 + 255) / 256) * 256;
 
-// ---- training stash layout: per sample, bf16 row-major activations ----
-// [xenc 64 | h0..h7 8x256 | feat 256 | hv 128 | denc 32] followed by relu bitmasks.
-// Each block is its own [n, width] matrix so the wgrad kernel sees plain row-major tiles.
+// ---- training stash: blocked images [xenc 64 | h0..h7 8x256 | feat 256 | hv 128 | denc 32] per
+// sample, followed by relu bitmasks; byte layout in mlp_stash.h, block shapes in mlp_chain.h.
 constexpr int kStashXenc = 64, kStashDenc = 32;
 
 }  // namespace plan

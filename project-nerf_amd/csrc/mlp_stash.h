@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "common.h"
 
 namespace nerf {
 
@@ -15,12 +16,13 @@ namespace nerf {
 //                      non-temporal; before that the stream dgrad lost 0.07 ms waiting on its mask
 //                      loads behind the stores).  The streams' 32-bit image offsets cover 2^22
 //                      samples per launch; larger launches take the compiler-scheduled kernels.
-//   NERF_CHAIN_LEGACY=1 selects the compiler-scheduled family everywhere (development aid, tests).
-// Forward and backward of one step must decide alike (the environment is read per call): the ReLU
+//   option chain_legacy (env NERF_CHAIN_LEGACY=1, or nerf_set_option) selects the compiler-scheduled
+//   family everywhere (development aid, tests).
+// Forward and backward of one step must decide alike: the ReLU
 // mask words differ between the families (stream: one dword per lane and m-tile, bit q / 16+q =
 // rows 2q / 2q+1; compiler-scheduled: 16 bits per m-tile, bit r = accumulator register r).
 inline bool chain_use_stream(int64_t n, bool training) {
-  if (getenv("NERF_CHAIN_LEGACY") != nullptr) return false;
+  if (options().chain_legacy) return false;
   return !training || n <= ((int64_t)1 << 22);
 }
 

@@ -308,8 +308,7 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   // independent of the stage's bytes (9..36 KB), so the fixed share dominates (sweep: 4 KB ->
   // 0.88 ms, 16 KB -> 0.64, 96 KB -> 0.53); with byte-only costs the workgroups owning the narrow
   // layers (rgb: 9 KB per wave tile) ran 3x more iterations and finished last (1.11 ms).
-  int overhead = 98304;
-  if (const char* o = getenv("NERF_WGRAD_OVH")) overhead = atoi(o);
+  const int overhead = options().wgrad_overhead;
   for (int j = 0; j < nj; ++j)
     args.jobs[j].cost = args.jobs[j].a_bytes + args.jobs[j].b_acc_bytes + args.jobs[j].b_nat_bytes + overhead;
   args.wave_tiles = (int)((n + 31) / 32);
@@ -320,9 +319,9 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   }
   args.total_cost = c;
   args.grads = grads;
-  if (const char* dbg = getenv("NERF_WGRAD_DEBUG")) args.debug = atoi(dbg);
-  if (const char* only = getenv("NERF_WGRAD_ONLY")) {   // development aid: keep one job kind
-    const int kind = atoi(only);
+  args.debug = options().wgrad_debug;
+  if (options().wgrad_only >= 0) {   // development aid: keep one job kind
+    const int kind = options().wgrad_only;
     int m = 0;
     for (int j = 0; j < args.n_jobs; ++j) if (args.jobs[j].kind == kind) args.jobs[m++] = args.jobs[j];
     args.n_jobs = m;
@@ -332,16 +331,9 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
     args.total_cost = cc;
   }
 
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_mlp_bwd: cannot query device");
-    n_cu = prop.multiProcessorCount;
-    if (hipFuncSetAttribute((const void*)mlp_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLds) != hipSuccess)
-      return fail(NERF_ELAUNCH, "nerf_mlp_bwd: cannot raise dynamic LDS limit to %d", kWgLds);
-  }
+  int n_cu = 0;
+  if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
+  if (int rc = ensure_dynamic_lds((const void*)mlp_wgrad_kernel, kWgLds, "nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
   long long want = (long long)args.wave_tiles * nj / 4;   // at least ~4 wave tiles per span
   int grid = (int)(want < 1 ? 1 : (want > n_cu ? n_cu : want));
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid), dim3(512), kWgLds, stream, args);

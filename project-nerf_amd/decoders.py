@@ -5,6 +5,7 @@ import torch.nn as nn
 
 from . import ops
 from .abstract import BaseDecoder
+from .embeddings import ParamHolder
 
 
 class StandardMLP(BaseDecoder):
@@ -73,3 +74,38 @@ class NeRFDecoder(BaseDecoder):
         raise NotImplementedError(
             "NeRFDecoder consumes raw coordinates through the fused kernel: call NeuralField(x, d) or "
             "NeRFDecoder.field(pts, dirs); separately encoded inputs are not a supported entry point")
+
+
+class InstantNeRFDecoder(BaseDecoder):
+    """reference src/decoders.py:90-162: sigma-net 32->64->16, colour-net (16+27)->64->64->3."""
+
+    def __init__(self, pos_dim, dir_dim, hidden_dim=64):
+        super().__init__()
+        if (pos_dim, dir_dim, hidden_dim) != (32, 27, 64):
+            raise NotImplementedError("libnerf_hip is compiled for pos 32 / dir 27 / hidden 64")
+
+        def xavier(rows, cols, fan_in, fan_out):
+            return (torch.rand(rows, cols) * 2 - 1) * (6.0 / (fan_in + fan_out)) ** 0.5
+        s = torch.cat([xavier(64, 32, 32, 64).reshape(-1), xavier(16, 64, 64, 16).reshape(-1)])
+        w1 = xavier(64, 48, 43, 64)
+        w1[:, 43:] = 0
+        w3 = xavier(16, 64, 64, 3)
+        w3[3:] = 0
+        c = torch.cat([w1.reshape(-1), xavier(64, 64, 64, 64).reshape(-1), w3.reshape(-1)])
+        self.sigma_net = ParamHolder(s)
+        self.color_net = ParamHolder(c)
+        self._packed, self._version = None, None
+
+    def flat_parameters(self):
+        return torch.cat([self.sigma_net.params, self.color_net.params])
+
+    def packed_weights(self):
+        v = (self.sigma_net.params._version, self.color_net.params._version)
+        if self._packed is None or v != self._version or self._packed.device != self.sigma_net.params.device:
+            with torch.no_grad():
+                self._packed = ops.imlp_pack(self.flat_parameters())
+            self._version = v
+        return self._packed
+
+    def forward(self, x_enc, d_enc):
+        raise NotImplementedError("the Instant decoder runs fused with the hash encoding: call NeuralField(x, d)")

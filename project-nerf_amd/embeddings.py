@@ -1,5 +1,6 @@
 """Encodings (reference src/embeddings.py) backed by the HIP kernels."""
 import torch
+import torch.nn as nn
 
 from . import ops
 from .abstract import BaseRepresentation
@@ -25,6 +26,43 @@ class FourierRepresentation(BaseRepresentation):
         if x.requires_grad:
             raise NotImplementedError("gradients w.r.t. encoded coordinates are not part of the static path")
         return ops.fourier_encode(x, self.L)
+
+    @property
+    def out_dim(self):
+        return self._out_dim
+
+
+class ParamHolder(nn.Module):
+    """Stands in for a tcnn module (tcnn.Encoding / tcnn.Network): one flat fp32 ``params`` vector,
+    so that state_dict keys read ``...encoding.params`` / ``...sigma_net.params`` as in the reference."""
+
+    def __init__(self, init, n_output_dims=None):
+        super().__init__()
+        self.params = nn.Parameter(init)
+        self.n_output_dims = n_output_dims
+
+
+class HashRepresentation(BaseRepresentation):
+    """reference src/embeddings.py:39-93."""
+
+    def __init__(self, n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
+                 per_level_scale=1.5, bound=1.0):
+        super().__init__()
+        if n_features_per_level != 2 or n_levels != 16:
+            raise NotImplementedError("libnerf_hip is compiled for 16 levels x 2 features (32 hash channels)")
+        self.bound = bound
+        self.levels = ops.HashLevelTable(n_levels, log2_hashmap_size, base_resolution, per_level_scale)
+        init = (torch.rand(self.levels.entries * 2) * 2 - 1) * 1e-4
+        self.encoding = ParamHolder(init, n_output_dims=n_levels * n_features_per_level)
+        self._out_dim = self.encoding.n_output_dims
+
+    def table(self):
+        return self.encoding.params.view(-1, 2)
+
+    def forward(self, x):
+        if x.requires_grad or self.encoding.params.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("differentiate through NeuralField (fused hash + decoder), not the bare encoding")
+        return ops.hash_encode_fwd(x, self.table(), self.levels, self.bound)[0]
 
     @property
     def out_dim(self):

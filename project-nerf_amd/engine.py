@@ -183,6 +183,9 @@ class InstantNgpEngine:
         cfg = dict(cfg or {})
         self.device = torch.device(device)
         self.bound = float(cfg.get("scene_bound", 1.5))
+        if cfg.get("n_levels", 16) != 16 or cfg.get("n_features_per_level", 2) != 2 or cfg.get("hidden_dim", 64) != 64:
+            raise NotImplementedError("libnerf_hip's tiny-MLP kernels are compiled for 16 levels x 2 features (32 hash "
+                                      "channels) and 64 hidden units")
         self.levels = ops.HashLevelTable(cfg.get("n_levels", 16), cfg.get("log2_hashmap_size", 19),
                                          cfg.get("base_resolution", 16), cfg.get("per_level_scale", 1.5))
         g = torch.Generator().manual_seed(seed)

@@ -12,79 +12,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .abstract import BaseDecoder, BaseRepresentation
-from .embeddings import FourierRepresentation
-
-
-class _ParamHolder(nn.Module):
-    """Stands in for a tcnn module: one flat fp32 ``params`` vector."""
-
-    def __init__(self, init, n_output_dims=None):
-        super().__init__()
-        self.params = nn.Parameter(init)
-        self.n_output_dims = n_output_dims
-
-
-class HashRepresentation(BaseRepresentation):
-    """reference src/embeddings.py:39-93."""
-
-    def __init__(self, n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
-                 per_level_scale=1.5, bound=1.0):
-        super().__init__()
-        if n_features_per_level != 2 or n_levels != 16:
-            raise NotImplementedError("libnerf_hip is compiled for 16 levels x 2 features (32 hash channels)")
-        self.bound = bound
-        self.levels = ops.HashLevelTable(n_levels, log2_hashmap_size, base_resolution, per_level_scale)
-        init = (torch.rand(self.levels.entries * 2) * 2 - 1) * 1e-4
-        self.encoding = _ParamHolder(init, n_output_dims=n_levels * n_features_per_level)
-        self._out_dim = self.encoding.n_output_dims
-
-    def table(self):
-        return self.encoding.params.view(-1, 2)
-
-    def forward(self, x):
-        if x.requires_grad or self.encoding.params.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("differentiate through NeuralField (fused hash + decoder), not the bare encoding")
-        return ops.hash_encode_fwd(x, self.table(), self.levels, self.bound)[0]
-
-    @property
-    def out_dim(self):
-        return self._out_dim
-
-
-class InstantNeRFDecoder(BaseDecoder):
-    """reference src/decoders.py:90-162: sigma-net 32->64->16, colour-net (16+27)->64->64->3."""
-
-    def __init__(self, pos_dim, dir_dim, hidden_dim=64):
-        super().__init__()
-        if (pos_dim, dir_dim, hidden_dim) != (32, 27, 64):
-            raise NotImplementedError("libnerf_hip is compiled for pos 32 / dir 27 / hidden 64")
-
-        def xavier(rows, cols, fan_in, fan_out):
-            return (torch.rand(rows, cols) * 2 - 1) * (6.0 / (fan_in + fan_out)) ** 0.5
-        s = torch.cat([xavier(64, 32, 32, 64).reshape(-1), xavier(16, 64, 64, 16).reshape(-1)])
-        w1 = xavier(64, 48, 43, 64)
-        w1[:, 43:] = 0
-        w3 = xavier(16, 64, 64, 3)
-        w3[3:] = 0
-        c = torch.cat([w1.reshape(-1), xavier(64, 64, 64, 64).reshape(-1), w3.reshape(-1)])
-        self.sigma_net = _ParamHolder(s)
-        self.color_net = _ParamHolder(c)
-        self._packed, self._version = None, None
-
-    def flat_parameters(self):
-        return torch.cat([self.sigma_net.params, self.color_net.params])
-
-    def packed_weights(self):
-        v = (self.sigma_net.params._version, self.color_net.params._version)
-        if self._packed is None or v != self._version or self._packed.device != self.sigma_net.params.device:
-            with torch.no_grad():
-                self._packed = ops.imlp_pack(self.flat_parameters())
-            self._version = v
-        return self._packed
-
-    def forward(self, x_enc, d_enc):
-        raise NotImplementedError("the Instant decoder runs fused with the hash encoding: call NeuralField(x, d)")
+from .decoders import InstantNeRFDecoder
+from .embeddings import FourierRepresentation, HashRepresentation
 
 
 def build_instant_field(field, config):

@@ -500,14 +500,16 @@ def tv_clip_adamw_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_s
                        tv_weight: float = 0.0, max_norm: float = 0.0, weight_decay: float = 0.0,
                        beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0,
                        scratch: Optional[Tensor] = None) -> None:
-    """TV-L1 gradient (optional) + global-norm clip + AdamW on one flat group, two streaming passes."""
+    """TV-L1 gradient (optional) + global-norm clip + AdamW on one flat group, two streaming passes.
+    ``grad_scale`` (1/world after a summing all-reduce) scales the data gradient BEFORE the TV term is
+    added, so the regulariser keeps its weight on any number of ranks (reference run.py:611-629)."""
     lib = _lib.load()
     for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         if _dev(t, nm) is not t:
             raise ValueError(f"{nm} must be contiguous")
     normsq = scratch if scratch is not None else torch.empty(1, device=params.device)
-    _lib.check(lib.nerf_tv_normsq(_p(params), _p(grads), params.numel(), tv_weight, _p(normsq), _stream()),
+    _lib.check(lib.nerf_tv_normsq(_p(params), _p(grads), params.numel(), tv_weight, grad_scale, _p(normsq), _stream()),
                "nerf_tv_normsq")
     _lib.check(lib.nerf_adamw_clip_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), step, lr,
-                                        beta1, beta2, eps, weight_decay, _p(normsq), max_norm, grad_scale, _stream()),
+                                        beta1, beta2, eps, weight_decay, _p(normsq), max_norm, 1.0, _stream()),
                "nerf_adamw_clip_step")

@@ -197,12 +197,12 @@ def test_decoder_point_mode_vs_reference_golden(ops):
 
 
 @pytest.fixture
-def chain_family(request, monkeypatch):
-    """selects the chain-kernel family per call (mlp_stash.h::chain_use_stream reads the environment)"""
-    monkeypatch.delenv("NERF_CHAIN_LEGACY", raising=False)
-    if request.param == "compiler-scheduled":
-        monkeypatch.setenv("NERF_CHAIN_LEGACY", "1")
-    return request.param
+def chain_family(request):
+    """selects the chain-kernel family (library option chain_legacy, see include/nerf_hip.h)"""
+    from project_nerf_amd import _lib
+    _lib.set_option("chain_legacy", 1 if request.param == "compiler-scheduled" else 0)
+    yield request.param
+    _lib.set_option("chain_legacy", 0)
 
 
 @pytest.mark.parametrize("chain_family", ["asm-stream", "compiler-scheduled"], indirect=True)
@@ -309,9 +309,7 @@ def test_decoder_training_families_agree_over_multiple_passes(ops, monkeypatch):
     packed = ops.mlp_pack(dev(flat_params(params)))
     out = {}
     for fam in ("compiler-scheduled", "asm-stream"):
-        monkeypatch.delenv("NERF_CHAIN_LEGACY", raising=False)
-        if fam == "compiler-scheduled":
-            monkeypatch.setenv("NERF_CHAIN_LEGACY", "1")
+        ops._lib.set_option("chain_legacy", 1 if fam == "compiler-scheduled" else 0)
         stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
         rgb, sigma = ops.mlp_fwd(packed, dev(o), dev(d), dev(z), stash)
         out[fam] = (rgb.cpu(), sigma.cpu(), ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb, d_sigma).cpu())

@@ -20,5 +20,5 @@ def tm(it=10):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
 print(f"all levels: {tm():.3f} ms")
 for lvl in range(16):
-    os.environ["NERF_HASH_BWD_ONLY_LEVEL"] = str(lvl)
+    ops._lib.set_option("hash_bwd_only_level", lvl)
     print(f"LDS levels + level {lvl:2d} (res {t.res[lvl] if hasattr(t, 'res') else '?'}): {tm():.3f} ms", flush=True)

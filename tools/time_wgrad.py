@@ -22,15 +22,15 @@ def t(it=20):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
 gb = (stash.numel() + ws.numel()) * 1e-9
 for dbg in (0, 1, 2, 3):
-    os.environ["NERF_WGRAD_DEBUG"] = str(dbg)
+    ops._lib.set_option("wgrad_debug", dbg)
     ms = t()
     print(f"debug={dbg}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s", flush=True)
-os.environ["NERF_WGRAD_DEBUG"] = "0"
+ops._lib.set_option("wgrad_debug", 0)
 for ovh in (49152, 65536, 98304, 131072, 262144, 1048576):
-    os.environ['NERF_WGRAD_OVH'] = str(ovh); print('ovh', ovh, f'{t():.3f} ms', flush=True)
+    ops._lib.set_option("wgrad_overhead", ovh); print('ovh', ovh, f'{t():.3f} ms', flush=True)
 for kind, nb in ():
-    os.environ["NERF_WGRAD_ONLY"] = str(kind)
+    ops._lib.set_option("wgrad_only", kind)
     for dbg in (0, 1, 2):
-        os.environ["NERF_WGRAD_DEBUG"] = str(dbg)
+        ops._lib.set_option("wgrad_debug", dbg)
         ms = t()
         print(f"kind {kind} debug={dbg}: {ms:.3f} ms  {nb*1024*8192e-9/ms*1e3:.0f} GB/s", flush=True)
