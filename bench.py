@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 FWD_FLOP = 1186816           # per sample, forward  (2 x 593,408 MAC)
 TRAIN_FLOP = 3489024         # per sample, fwd + dgrad + wgrad
-WGRAD_BYTES = 2 * (64 + 8 * 256 + 256 + 128 + 32) + 2 * (16 + 128 + 256 + 8 * 256)   # 9952 B per sample
+WGRAD_ELEMS = (64 + 8 * 256 + 256 + 128 + 32) + (16 + 128 + 256 + 8 * 256)   # image elements per sample read by wgrad: 4976
 DGRAD_FLOP = 2 * (593408 - 35712 - 256 * 63)   # transposed chain, code columns and layer 0 skipped
 WGRAD_FLOP = 2 * 593408
 MFMA_PEAK_TFLOPS = 2500.0    # gfx950 dense bf16 (MI355X_MICROARCH.md)
@@ -296,6 +296,8 @@ def main():
         tp, tm, tv = eng.params.clone(), torch.zeros_like(grads), torch.zeros_like(grads)
         k["adam+pack"] = event_ms(lambda: (ops.adam_step(tp, grads, tm, tv, 1, 5e-4), ops.mlp_pack(eng.params, eng.packed)), 20)
         stash_b, ws_b = ops.mlp_stash_bytes(n), ops.mlp_bwd_workspace_bytes(n)
+        image_bytes = 1 if stash_b < 4000 * n else 2      # 8-bit images (asm-stream family) or bf16
+        WGRAD_BYTES = WGRAD_ELEMS * image_bytes
         kern = {
             "mlp_fwd_train": {"ms": k["mlp_fwd_train"], "tflops": n * FWD_FLOP / k["mlp_fwd_train"] * 1e-9},
             "mlp_fwd_infer": {"ms": k["mlp_fwd_infer"], "tflops": n * FWD_FLOP / k["mlp_fwd_infer"] * 1e-9},

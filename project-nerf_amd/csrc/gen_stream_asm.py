@@ -24,7 +24,13 @@ leave a counted `s_waitcnt` alone.  Inside a single statement every wait state a
     freed slot, one 1-KiB piece per MFMA gap.
   * training: ReLU mask word of tile m = sum_q min(bf16 pair q, 1) << q  (bit q: row 2q active,
     bit 16+q: row 2q+1), one dword per lane and tile; dgrad expands it with shift / and 0x10001 /
-    v_pk_mul_lo_u16.  Stash / gradient images are the blocked layout of mlp_chain.h::stash_block.
+    v_pk_mul_lo_u16.
+  * training images are 8-bit: the bf16 pair the chain keeps for the next layer is converted once
+    more (v_cvt_scalef32_pk_fp8_bf16: e4m3 activations; ..._bf8_bf16: e5m2 pre-activation gradients,
+    divided by the power-of-two scale in s95) into the accumulator tile the epilogue has just drained
+    (register k of that tile is free once pairs 2k, 2k+1 are converted), so one 16-byte store per lane
+    and m-tile carries the tile's 16 rows: block = 1 KiB per (32-sample wave tile, m-tile), lane (c, h)
+    at byte 32c + 16h (mlp_chain.h::stash_block8).  MODE.FP16_OVFL makes the conversions saturate.
 
 The chunk tables are recomputed here and pinned against mlp_plan.h by static_asserts in the output.
 
@@ -43,7 +49,8 @@ VA, SO, MO, T0 = 88, 89, 90, 95          # scratch VGPRs; v91..v94: mask words (
 X, Y, P, Q = 96, 112, 128, 192
 FIRST_LITERAL_VGPR = 88
 # literal SGPRs s84..s99: [84:85] h / dh base, [86:87] feat / dfeat, [88:89] hv / dhv, [90:91] current
-# image, [92:93] mask base, [94] 0x00010001, [96:97] layer stride in bytes, [98:99] scratch
+# image, [92:93] mask base, [94] 0x00010001, [95] image scale (divisor), [96:97] layer stride in bytes,
+# [98:99] scratch
 SGPR_LITERALS = range(84, 100)
 
 
@@ -231,12 +238,15 @@ def generate(mode):
                 u += [("waitmask", gi)] if j == 0 else []
                 u += [f"v_lshrrev_b32 {vr(T0)}, {j}, {vr(mask_slot(gi))}", f"v_and_b32 {vr(T0)}, s94, {vr(T0)}",
                       f"v_pk_mul_lo_u16 {vr(r0 + j)}, {vr(r0 + j)}, {vr(T0)}"]
+            if stash and "store" not in ABLATE:
+                # 8-bit image: bytes 2j, 2j+1 of the lane's 16-byte record, staged in the drained tile
+                cvt8 = "v_cvt_scalef32_pk_bf8_bf16" if bwd else "v_cvt_scalef32_pk_fp8_bf16"
+                u.append(f"{cvt8} {vr(T + (j >> 1))}, {vr(r0 + j)}, s95" + (" op_sel:[0,0,1]" if j & 1 else ""))
             units.append(u)
         if stash and "store" not in ABLATE:
             so_base = "so8" if e["mt"] == 8 else "so4"
-            units.append(set_image(e["image"]) + [f"v_add_u32 {vr(SO)}, {hex(e['m'] * 2048)}, %[{so_base}]",
-                                                   ("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0, 4)}, s[90:91] nt")])
-            units.append([("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0 + 4, 4)}, s[90:91] offset:128 nt")])
+            units.append(set_image(e["image"]) + [f"v_add_u32 {vr(SO)}, {hex(e['m'] * 1024)}, %[{so_base}]",
+                                                   ("store", f"global_store_dwordx4 {vr(SO)}, {vr(T, 4)}, s[90:91] nt")])
             if train and masked:
                 units.append([f"v_add_u32 {vr(MO)}, {hex((e['mask_layer'] * 8 + e['m']) * 2048)}, %[mo0]",
                               ("store", f"global_store_dword {vr(MO)}, {vr(mask_slot(gi))}, s[92:93]")])
@@ -270,8 +280,10 @@ def generate(mode):
         for sreg, off in zip((84, 86, 88, 92, 96), ka):
             emit(f"s_load_dwordx2 s[{sreg}:{sreg + 1}], %[karg], {hex(off)}")
         emit("s_mov_b32 s94, 0x10001")
+        emit("s_mov_b32 s95, %[scale]")                              # divisor of the 8-bit images
+        emit("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")      # MODE.FP16_OVFL: 8-bit conversions saturate
         emit("s_waitcnt lgkmcnt(0)")
-        emit("s_lshl_b64 s[96:97], s[96:97], 9")                     # layer stride = n_pad * 256 * 2 bytes
+        emit("s_lshl_b64 s[96:97], s[96:97], 8")                     # layer stride = n_pad * 256 bytes
     if bwd and "store" not in ABLATE:
         emit("s_cmp_eq_u32 %[first], 0")
         emit("s_cbranch_scc1 .Lwarm%=")
@@ -372,11 +384,11 @@ SIGS = {
               "    unsigned voff, unsigned ldsw, float& sg, float& cr, float& cg, float& cb"),
     "train": ("fwd_train_stream_pass",
               "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
-              "    unsigned voff, unsigned ldsw, unsigned so8, unsigned so4, unsigned mo0, const void* karg,\n"
+              "    unsigned voff, unsigned ldsw, unsigned so8, unsigned so4, unsigned mo0, const void* karg, float scale,\n"
               "    float& sg, float& cr, float& cg, float& cb"),
     "bwd": ("bwd_stream_pass",
             "unsigned ab0, unsigned ab1, const bf16x8& g0, const bf16x8& gs, const char* src, unsigned voff, unsigned ldsw,\n"
-            "    unsigned so8, unsigned so4, unsigned mo0, unsigned mo0n, unsigned first, const void* karg"),
+            "    unsigned so8, unsigned so4, unsigned mo0, unsigned mo0n, unsigned first, const void* karg, float scale"),
 }
 
 
@@ -407,7 +419,7 @@ def emit_function(mode, p):
         outs += ['[sg] "=&v"(sg)', '[cr] "=&v"(cr)', '[cg] "=&v"(cg)', '[cb] "=&v"(cb)']
         ins += ['[bb] "v"(bb)'] + [f'[x{i}] "v"(x[{i}])' for i in range(4)] + [f'[d{i}] "v"(d[{i}])' for i in range(2)]
     if mode != "infer":
-        ins += ['[so8] "v"(so8)', '[so4] "v"(so4)', '[mo0] "v"(mo0)', '[karg] "s"(karg)']
+        ins += ['[so8] "v"(so8)', '[so4] "v"(so4)', '[mo0] "v"(mo0)', '[karg] "s"(karg)', '[scale] "s"(scale)']
     clob = [f'"v{i}"' for i in range(FIRST_LITERAL_VGPR, 256)]
     if mode != "infer":
         clob += [f'"s{i}"' for i in SGPR_LITERALS]
@@ -428,7 +440,7 @@ def main():
     p(f"static_assert(plan::kChunkFrags == {CHUNK}, \"stream plan\");")
     p("// ab0/ab1: LDS byte address of ring slot 0/1 + lane*16; bb: LDS address of the bias table + 16*half;")
     p("// voff = wave*1024 + lane*16; ldsw = ring base + wave*1024 (wave-uniform); src = fragment stream;")
-    p("// so8/so4 = wave_tile*MT*2048 + block_lane_offset(col, half) for MT = 8/4; mo0 = (tile*72*512 + tid)*4;")
+    p("// so8/so4 = wave_tile*MT*1024 + block8_lane_offset(col, half) for MT = 8/4; mo0 = (tile*72*512 + tid)*4;")
     p("// karg = kernarg segment.\n")
     for mode in os.environ.get("GEN_MODES", "infer,train,bwd").split(","):
         emit_function(mode, p)

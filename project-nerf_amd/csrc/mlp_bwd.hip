@@ -25,7 +25,37 @@ struct BwdArgs {
   __bf16* dhv;            // blocked [n_pad,128]
   __bf16* dfeat;          // blocked [n_pad,256]
   __bf16* dh;             // 8 x blocked [n_pad,256]
+  float* amax;            // 8-bit images: max |output-layer derivative| of the launch (bwd_amax_kernel)
 };
+
+// output-layer derivatives of one sample: sigmoid' and relu' applied to the upstream gradients
+__device__ __forceinline__ void out_derivs(const BwdArgs& a, int64_t n, float& g0, float& g1, float& g2, float& gs) {
+  const float r0 = a.rgb[n * 3 + 0], r1 = a.rgb[n * 3 + 1], r2 = a.rgb[n * 3 + 2];
+  g0 = a.d_rgb[n * 3 + 0] * r0 * (1.0f - r0);
+  g1 = a.d_rgb[n * 3 + 1] * r1 * (1.0f - r1);
+  g2 = a.d_rgb[n * 3 + 2] * r2 * (1.0f - r2);
+  gs = a.sigma[n] > 0.0f ? a.d_sigma[n] : 0.0f;
+}
+
+// amax of the dgrad chain's inputs: the e5m2 gradient images are divided by a power of two derived
+// from it (mlp_stash.h::grad_image_scale).  Non-negative floats order like their bit patterns.
+__global__ void __launch_bounds__(256) bwd_amax_kernel(const BwdArgs a) {
+  float m = 0.0f;
+  for (int64_t n = blockIdx.x * 256 + threadIdx.x; n < a.n; n += (int64_t)gridDim.x * 256) {
+    float g0, g1, g2, gs;
+    out_derivs(a, n, g0, g1, g2, gs);
+    m = fmaxf(fmaxf(m, fabsf(g0)), fmaxf(fmaxf(fabsf(g1), fabsf(g2)), fabsf(gs)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (m == m && m < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(a.amax), __builtin_bit_cast(unsigned, m));
+  }
+}
 
 __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -47,13 +77,7 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_kernel(const BwdArgs
 
     // ---- output-layer derivatives: sigmoid' and relu' ----
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, gs = 0.f;
-    if (live) {
-      const float r0 = a.rgb[n * 3 + 0], r1 = a.rgb[n * 3 + 1], r2 = a.rgb[n * 3 + 2];
-      g0 = a.d_rgb[n * 3 + 0] * r0 * (1.0f - r0);
-      g1 = a.d_rgb[n * 3 + 1] * r1 * (1.0f - r1);
-      g2 = a.d_rgb[n * 3 + 2] * r2 * (1.0f - r2);
-      gs = a.sigma[n] > 0.0f ? a.d_sigma[n] : 0.0f;
-    }
+    if (live) out_derivs(a, n, g0, g1, g2, gs);
     bf16x8 small;
 #pragma unroll
     for (int j = 0; j < 8; ++j) small[j] = (__bf16)0.0f;
@@ -156,19 +180,17 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const 
   const char* src = a.packed + kPackBwdOff;
   const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
 
+  // e5m2 gradient images, divided by a power of two that puts the launch's largest output-layer
+  // derivative in [64, 128) (the chain itself runs on unscaled bf16; wgrad multiplies the scale back)
+  set_fp8_saturate();
+  const float gscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, grad_image_scale(*a.amax))));
   const int64_t n_tiles = a.n_pad / kTileSamples;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t wave_tile = tile * 8 + wave;
     const int64_t n = wave_tile * kWaveSamples + col;
     const bool live = n < a.n;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, gs = 0.f;
-    if (live) {
-      const float r0 = a.rgb[n * 3 + 0], r1 = a.rgb[n * 3 + 1], r2 = a.rgb[n * 3 + 2];
-      g0 = a.d_rgb[n * 3 + 0] * r0 * (1.0f - r0);
-      g1 = a.d_rgb[n * 3 + 1] * r1 * (1.0f - r1);
-      g2 = a.d_rgb[n * 3 + 2] * r2 * (1.0f - r2);
-      gs = a.sigma[n] > 0.0f ? a.d_sigma[n] : 0.0f;
-    }
+    if (live) out_derivs(a, n, g0, g1, g2, gs);
     bf16x8 small, in_rgb, in_sigma;
 #pragma unroll
     for (int j = 0; j < 8; ++j) small[j] = in_sigma[j] = (__bf16)0.0f;
@@ -176,17 +198,17 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const 
       small[0] = (__bf16)g0; small[1] = (__bf16)g1; small[2] = (__bf16)g2; small[3] = (__bf16)gs;
       in_sigma[0] = (__bf16)gs;
     }
-    stash_nat(a.dsmall, wave_tile, 1, 0, col, half, small);
+    stash_nat8<true>(reinterpret_cast<char*>(a.dsmall), wave_tile, 1, 0, col, half, small, gscale);
     in_rgb = small;
     in_rgb[3] = (__bf16)0.0f;   // column 3 carries d(sigma_pre), not an rgb row
 
-    const unsigned lane32 = block_lane_offset(col, half);
-    const unsigned so8 = (unsigned)wave_tile * (8u * 2048u) + lane32, so4 = (unsigned)wave_tile * (4u * 2048u) + lane32;
+    const unsigned lane32 = block8_lane_offset(col, half);
+    const unsigned so8 = (unsigned)wave_tile * (8u * 1024u) + lane32, so4 = (unsigned)wave_tile * (4u * 1024u) + lane32;
     const unsigned mo0 = (unsigned)tile * (72u * 512u * 4u) + 4u * tid;
     const bool more = tile + gridDim.x < n_tiles;
     const unsigned mo0n = more ? (unsigned)(tile + gridDim.x) * (72u * 512u * 4u) + 4u * tid : mo0;
     const unsigned first = __builtin_amdgcn_readfirstlane(tile == (int64_t)blockIdx.x ? 1u : 0u);
-    bwd_stream_pass(ab0, ab1, in_rgb, in_sigma, src, voff, ldsw, so8, so4, mo0, mo0n, first, karg);
+    bwd_stream_pass(ab0, ab1, in_rgb, in_sigma, src, voff, ldsw, so8, so4, mo0, mo0n, first, karg, gscale);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -219,6 +241,7 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
   a.dhv = reinterpret_cast<__bf16*>(w + bl.dhv);
   a.dfeat = reinterpret_cast<__bf16*>(w + bl.dfeat);
   a.dh = reinterpret_cast<__bf16*>(w + bl.dh);
+  a.amax = reinterpret_cast<float*>(w + bl.amax);
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
   const bool stream_family = chain_use_stream(n, true);
@@ -226,6 +249,12 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
                                   "nerf_mlp_bwd"); rc != NERF_OK) return rc;
   const int64_t tiles = bl.n_pad / kTileSamples;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+  if (bl.fp8) {
+    if (hipMemsetAsync(a.amax, 0, sizeof(float), as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_mlp_bwd: memset failed");
+    const int64_t want = (n + 1023) / 1024;
+    hipLaunchKernelGGL(bwd_amax_kernel, dim3((int)(want < 1024 ? want : 1024)), dim3(256), 0, as_stream(stream), a);
+  }
   if (stream_family)
     hipLaunchKernelGGL(mlp_bwd_stream_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else

@@ -13,6 +13,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kChainThreads = 512;                 // 8 waves, 2 per SIMD
 constexpr int kWaveSamples = 32;                   // one 32-column MFMA tile per wave
@@ -241,6 +243,42 @@ __device__ __forceinline__ void stash_nat(__bf16* base, int64_t wave_tile, int n
                                           const bf16x8& v) {
   char* p = reinterpret_cast<char*>(base) + ((wave_tile * n_ks + ks) * 64 + 2 * col + half) * 16;
   __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
+}
+
+// ---- 8-bit images (asm-stream family, gen_stream_asm.py) ----
+// acc-type block: 1 KiB per (32-sample wave tile, m-tile); lane (c, h) owns 16 bytes at 32c + 16h =
+// its 16 accumulator rows (r&3) + 8(r>>2) + 4h, r = byte index.  One wave store instruction fills the
+// whole block; the wgrad kernel's ds_read_b64_tr_b8 reads a 16-sample x 32-row operand from 512
+// contiguous bytes (conflict-free).
+__device__ __forceinline__ unsigned block8_lane_offset(int col, int half) { return 32u * col + 16u * half; }
+
+// bf16x8 -> 8 x e4m3 (BF8 = false) or e5m2 (true), each divided by `scale`; MODE.FP16_OVFL must be set
+// (saturation).  The s_nop keeps the half-register writes apart (dst_sel forwarding hazard).
+template <bool BF8>
+__device__ __forceinline__ u32x2 cvt8_bf16x8(const bf16x8& v, float scale) {
+  const u32x4 w = __builtin_bit_cast(u32x4, v);
+  unsigned r0 = 0u, r1 = 0u;
+  const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+  if constexpr (BF8)
+    asm volatile("v_cvt_scalef32_pk_bf8_bf16 %0, %2, %6\n\tv_cvt_scalef32_pk_bf8_bf16 %1, %4, %6\n\ts_nop 1\n\t"
+                 "v_cvt_scalef32_pk_bf8_bf16 %0, %3, %6 op_sel:[0,0,1]\n\tv_cvt_scalef32_pk_bf8_bf16 %1, %5, %6 op_sel:[0,0,1]\n\ts_nop 1"
+                 : "+v"(r0), "+v"(r1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(scale));
+  else
+    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %2, %6\n\tv_cvt_scalef32_pk_fp8_bf16 %1, %4, %6\n\ts_nop 1\n\t"
+                 "v_cvt_scalef32_pk_fp8_bf16 %0, %3, %6 op_sel:[0,0,1]\n\tv_cvt_scalef32_pk_fp8_bf16 %1, %5, %6 op_sel:[0,0,1]\n\ts_nop 1"
+                 : "+v"(r0), "+v"(r1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(scale));
+  return u32x2{r0, r1};
+}
+// natural-order operand, 8-bit: 512-byte block per (wave tile, k-step); sample c's 16-byte record is
+// [lane-half 0: features 16ks + 0..7 | lane-half 1: features 16ks + 8..15]
+template <bool BF8>
+__device__ __forceinline__ void stash_nat8(char* base, int64_t wave_tile, int n_ks, int ks, int col, int half,
+                                           const bf16x8& v, float scale) {
+  char* p = base + (wave_tile * n_ks + ks) * 512 + 16 * col + 8 * half;
+  __builtin_nontemporal_store(cvt8_bf16x8<BF8>(v, scale), reinterpret_cast<u32x2*>(p));
+}
+__device__ __forceinline__ void set_fp8_saturate() {
+  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL
 }
 
 // ---------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "mlp_chain.h"
+#include "mlp_stash.h"
 
 namespace nerf {
 using namespace plan;
@@ -24,7 +25,9 @@ struct FwdArgs {
   int n_samples;        // 0: point mode (rays_o = pts[n,3], rays_d = dirs[n,3] used as given)
   float* rgb;
   float* sigma;
-  // training stash: blocked images (see stash_block / stash_nat), n rounded up to whole tiles
+  // training stash: blocked images, n rounded up to whole tiles -- bf16 (stash_block / stash_nat) in the
+  // compiler-scheduled kernel, 8-bit (stash_block8 / stash_nat8) in the asm-stream kernel; the pointers
+  // below are byte bases either way (mlp_stash.h::stash_layout)
   int64_t n_pad;        // ceil(n / 256) * 256
   __bf16* st_xenc;      // nat  [n_pad, 64]
   __bf16* st_h;         // 8 x blocked [n_pad, 256], layer l at st_h + l * n_pad * 256
@@ -212,6 +215,7 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
   const char* src = a.packed + kPackFwdOff;
   const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
 
+  if constexpr (TRAIN) set_fp8_saturate();
   const int64_t n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   unsigned passes = 0;
@@ -240,15 +244,17 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
 
     float sg, cr, cg, cb;
     if constexpr (TRAIN) {
+      // 8-bit (e4m3) images of every layer input; kActScale divides before the conversion (1: values
+      // above 448 saturate in the image only -- the chain itself stays bf16)
       const int64_t wave_tile = tile * 8 + wave;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) stash_nat(a.st_xenc, wave_tile, 4, ks, col, half, xenc[ks]);
+      for (int ks = 0; ks < 4; ++ks) stash_nat8<false>(reinterpret_cast<char*>(a.st_xenc), wave_tile, 4, ks, col, half, xenc[ks], kActScale);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) stash_nat(a.st_denc, wave_tile, 2, ks, col, half, denc[ks]);
-      const unsigned lane32 = block_lane_offset(col, half);
-      const unsigned so8 = (unsigned)wave_tile * (8u * 2048u) + lane32, so4 = (unsigned)wave_tile * (4u * 2048u) + lane32;
+      for (int ks = 0; ks < 2; ++ks) stash_nat8<false>(reinterpret_cast<char*>(a.st_denc), wave_tile, 2, ks, col, half, denc[ks], kActScale);
+      const unsigned lane32 = block8_lane_offset(col, half);
+      const unsigned so8 = (unsigned)wave_tile * (8u * 1024u) + lane32, so4 = (unsigned)wave_tile * (4u * 1024u) + lane32;
       const unsigned mo0 = (unsigned)tile * (72u * 512u * 4u) + 4u * tid;
-      fwd_train_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, so8, so4, mo0, karg, sg, cr, cg, cb);
+      fwd_train_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, so8, so4, mo0, karg, kActScale, sg, cr, cg, cb);
     } else {
       fwd_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, sg, cr, cg, cb);
     }
@@ -268,7 +274,6 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
 
 }  // namespace nerf
 
-#include "mlp_stash.h"
 using namespace nerf;
 
 extern "C" size_t nerf_mlp_stash_bytes(int64_t n) { return n > 0 ? stash_layout(n).total : 0; }
@@ -293,7 +298,7 @@ extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float
     char* b = static_cast<char*>(stash);
     a.n_pad = s.n_pad;
     a.st_xenc = reinterpret_cast<__bf16*>(b + s.xenc);
-    a.st_h = reinterpret_cast<__bf16*>(b + s.h);
+    a.st_h = reinterpret_cast<__bf16*>(b + s.h);   // layer l at + l * n_pad * 256 elements of the image's width
     a.st_feat = reinterpret_cast<__bf16*>(b + s.feat);
     a.st_hv = reinterpret_cast<__bf16*>(b + s.hv);
     a.st_denc = reinterpret_cast<__bf16*>(b + s.denc);

@@ -26,47 +26,72 @@ inline bool chain_use_stream(int64_t n, bool training) {
   return !training || n <= ((int64_t)1 << 22);
 }
 
+// Element width of the training images.  The asm-stream family writes 8-bit images: e4m3
+// activations (forward) and e5m2 pre-activation gradients (dgrad), both consumed by
+// v_mfma_f32_32x32x16_bf8_fp8 in the wgrad kernel -- half the bytes of every image crosses HBM
+// (step traffic 5.8 -> 3.0 GB at 4096 x 64 samples).  The compiler-scheduled family keeps bf16.
+inline bool stash_fp8(int64_t n) { return chain_use_stream(n, true); }
+// divisor of the activation images before the e4m3 conversion (a power of two).  1: the image
+// saturates at 448 and flushes below 2^-10; the chain's own bf16 values are unaffected.
+constexpr float kActScale = 1.0f;
+
 struct StashLayout {
   int64_t n_pad;
+  int fp8;          // 1: 8-bit images (1 byte per element), 0: bf16
   size_t xenc, h, feat, hv, denc, mask, total;
 };
 
 inline StashLayout stash_layout(int64_t n) {
   StashLayout s{};
   s.n_pad = (n + 255) / 256 * 256;
-  const size_t np = (size_t)s.n_pad;
+  s.fp8 = stash_fp8(n) ? 1 : 0;
+  const size_t np = (size_t)s.n_pad, eb = s.fp8 ? 1 : 2;
   size_t o = 0;
-  s.xenc = o; o += np * 64 * 2;
-  s.h = o;    o += np * 256 * 2 * 8;
-  s.feat = o; o += np * 256 * 2;
-  s.hv = o;   o += np * 128 * 2;
-  s.denc = o; o += np * 32 * 2;
+  s.xenc = o; o += np * 64 * eb;
+  s.h = o;    o += np * 256 * eb * 8;
+  s.feat = o; o += np * 256 * eb;
+  s.hv = o;   o += np * 128 * eb;
+  s.denc = o; o += np * 32 * eb;
   s.mask = o; o += (np / 256) * 9 * 512 * 32;
   s.total = o;
   return s;
 }
 
-// backward workspace: bf16 blocked gradients w.r.t. pre-activations
+// backward workspace: blocked gradients w.r.t. pre-activations (bf16, or e5m2 divided by the
+// power-of-two scale the dgrad launch derives from the largest output-layer derivative)
 struct BwdLayout {
   int64_t n_pad;
+  int fp8;
   size_t dsmall;   // nat [n_pad,16]: cols 0..2 d(rgb_pre), col 3 d(sigma_pre)
   size_t dhv;      // blocked [n_pad,128]
   size_t dfeat;    // blocked [n_pad,256]
-  size_t dh;       // 8 x blocked [n_pad,256], layer l at dh + l * n_pad * 512
+  size_t dh;       // 8 x blocked [n_pad,256], layer l at dh + l * n_pad * 256 * element bytes
+  size_t amax;     // one fp32: max |output-layer derivative| of this launch (8-bit images only)
   size_t total;
 };
 
 inline BwdLayout bwd_layout(int64_t n) {
   BwdLayout s{};
   s.n_pad = (n + 255) / 256 * 256;
-  const size_t np = (size_t)s.n_pad;
+  s.fp8 = stash_fp8(n) ? 1 : 0;
+  const size_t np = (size_t)s.n_pad, eb = s.fp8 ? 1 : 2;
   size_t o = 0;
-  s.dsmall = o; o += np * 16 * 2;
-  s.dhv = o;    o += np * 128 * 2;
-  s.dfeat = o;  o += np * 256 * 2;
-  s.dh = o;     o += np * 256 * 2 * 8;
+  s.dsmall = o; o += np * 16 * eb;
+  s.dhv = o;    o += np * 128 * eb;
+  s.dfeat = o;  o += np * 256 * eb;
+  s.dh = o;     o += np * 256 * eb * 8;
+  s.amax = o;   o += 256;
   s.total = o;
   return s;
+}
+
+// gradient-image divisor from the launch's amax: a power of two that puts amax in [64, 128)
+// (e5m2 tops out at 57344: ~9 binades of headroom for growth along the chain, 20 below)
+__host__ __device__ inline float grad_image_scale(float amax) {
+  const unsigned bits = __builtin_bit_cast(unsigned, amax);
+  int e = (int)((bits >> 23) & 0xffu) - 6;
+  e = e < 1 ? 1 : (e > 254 ? 254 : e);
+  return __builtin_bit_cast(float, (unsigned)e << 23);
 }
 
 }  // namespace nerf

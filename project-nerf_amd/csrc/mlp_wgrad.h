@@ -36,9 +36,10 @@ struct WgradJob {
 struct WgradArgs {
   WgradJob jobs[kMaxJobs];
   int n_jobs;
-  int wave_tiles;
+  int wave_tiles;       // ring stages per job: 32-sample wave tiles (bf16) or 64-sample pairs (8-bit)
   long long total_cost;
   float* grads;
+  const float* amax;    // non-null: 8-bit images; *amax = the dgrad launch's largest output-layer derivative
   int debug;            // development aid (NERF_WGRAD_DEBUG): bit0 skip MFMA/LDS reads, bit1 skip DMA, bit2 skip flush
 };
 

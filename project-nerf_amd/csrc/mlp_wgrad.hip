@@ -49,12 +49,26 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
 
 struct LaneGeo {
   int lane, wave, fhalf, off_acc, off_nat;
+  int off_acc8, off_nat8;   // 8-bit images (ds_read_b64_tr_b8)
 };
+
+// 8-bit operand of the contraction over samples: ONE transposing read returns, for the lane's feature,
+// the 8 consecutive samples of its k-half (tools/probe/fp8_probe.hip pins the instruction's lane map)
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) i32x2* lds_i32x2_t;
+__device__ __forceinline__ long tr_frag8(const char* p) {
+  return __builtin_bit_cast(long, __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2_t)(p)));
+}
+// lane r of an acc-type 8-bit operand holds feature row phi(r) of its 32-row tile (the record of
+// lane-half r>>4 is 16 consecutive accumulator registers); natural-order operands are the identity
+__device__ __forceinline__ int phi8(int r) { return (r & 3) + 8 * ((r & 15) >> 2) + 4 * (r >> 4); }
 
 // One job span [wt0, wt1) of one layer.  OWNER mode (SPLIT = false): wave w owns output rows
 // 32w.. x all NT = NT_ACC + NT_NAT + ONES column tiles.  SPLIT mode (single 16-row natural A
 // block, dsmall): wave w owns column tile w (w < NT_ACC) and wave NT_ACC % 8 the ones tile.
-template <int NT_ACC, int NT_NAT, bool ONES, bool SPLIT>
+// FP8: the images are 8-bit (A = e5m2 gradients, B = e4m3 activations); one ring stage then holds TWO wave
+// tiles (64 samples = four k-steps): same bytes per stage as one bf16 wave tile, half the iterations.
+template <int NT_ACC, int NT_NAT, bool ONES, bool SPLIT, bool FP8>
 __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob job, int wt0, int wt1,
                                         char* smem, const LaneGeo g) {
   constexpr int NT = SPLIT ? 2 : NT_ACC + NT_NAT + (ONES ? 1 : 0);
@@ -106,6 +120,7 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  const long ones8 = 0x3838383838383838L;   // 8 x e4m3 1.0
 
   __builtin_amdgcn_s_barrier();   // previous span's readers are done with the ring
   if (wt0 + 0 < wt1) issue(wt0 + 0);
@@ -121,6 +136,36 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
     const char* pa = SPLIT ? stage + g.off_nat - 1024 * g.fhalf : stage + wave * 2048 + g.off_acc;
     const char* pb = stage + kWgStageA + g.off_acc + (SPLIT ? (wave < NT_ACC ? wave : 0) * 2048 : 0);
     const char* pn = stage + kWgStageA + kWgStageB + g.off_nat;
+    if constexpr (FP8) {
+      const int half_a = job.a_bytes >> 1, half_b = job.b_acc_bytes >> 1, half_n = job.b_nat_bytes >> 1;
+      const char* pa8 = SPLIT ? stage + g.off_nat8 - 512 * g.fhalf : stage + wave * 1024 + g.off_acc8;
+      const char* pb8 = stage + kWgStageA + g.off_acc8 + (SPLIT ? (wave < NT_ACC ? wave : 0) * 1024 : 0);
+      const char* pn8 = stage + kWgStageA + kWgStageB + g.off_nat8;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = s >> 1, ss = s & 1;
+        long af = SPLIT ? tr_frag8(pa8 + t * half_a + 256 * ss) : tr_frag8(pa8 + t * half_a + 512 * ss);
+        if (SPLIT && g.fhalf) af = 0;
+        if constexpr (SPLIT) {
+          if (wave < NT_ACC)
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(af, tr_frag8(pb8 + t * half_b + 512 * ss), acc[0], 0, 0, 0);
+          if (ONES && wave == NT_ACC % 8) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(af, ones8, acc[1], 0, 0, 0);
+        } else {
+          long bf[NT_ACC + NT_NAT + 1];
+#pragma unroll
+          for (int k = 0; k < NT_ACC; ++k) bf[k] = tr_frag8(pb8 + t * half_b + k * 1024 + 512 * ss);
+#pragma unroll
+          for (int k = 0; k < NT_NAT; ++k) bf[NT_ACC + k] = tr_frag8(pn8 + t * half_n + k * 1024 + 256 * ss);
+          bf[NT_ACC + NT_NAT] = ones8;
+#pragma unroll
+          for (int k = 0; k < NT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(af, bf[k], acc[k], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1 + NT_ACC + NT_NAT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af = SPLIT ? tr_frag<128>(pa + 512 * s) : tr_frag<256>(pa + 1024 * s);
@@ -153,15 +198,23 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
   if (!active || (args.debug & 4)) return;
   const int c32 = lane & 31, hrow = lane >> 5;
   const int m_tile = SPLIT ? 0 : wave;
+  // 8-bit images: acc-type operands carry their tile's rows in the order phi8; the sums come back in
+  // units of (gradient scale) x (activation scale), bias sums (all-ones operand) of the gradient scale alone
+  const int c_acc = FP8 ? phi8(c32) : c32;
+  float w_scale = 1.0f, b_scale = 1.0f;
+  if constexpr (FP8) {
+    b_scale = grad_image_scale(*args.amax);
+    w_scale = b_scale * kActScale;
+  }
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     int col = -1, bias_here = 0;
     bool use = true;
     if constexpr (SPLIT) {
-      if (k == 0) { use = wave < NT_ACC; const int i = wave * 32 + c32; if (i < job.acc_valid) col = job.acc_col0 + i; }
+      if (k == 0) { use = wave < NT_ACC; const int i = wave * 32 + c_acc; if (i < job.acc_valid) col = job.acc_col0 + i; }
       else { use = ONES && wave == NT_ACC % 8; bias_here = (c32 == 0); }
     } else {
-      if (k < NT_ACC) { const int i = k * 32 + c32; if (i < job.acc_valid) col = job.acc_col0 + i; }
+      if (k < NT_ACC) { const int i = k * 32 + c_acc; if (i < job.acc_valid) col = job.acc_col0 + i; }
       else if (k < NT_ACC + NT_NAT) {
         const int i = (k - NT_ACC) * 32 + c32;
         if (i < job.nat_valid) col = job.nat_col0 + i;
@@ -169,12 +222,14 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
       } else bias_here = (c32 == 0);
     }
     if (!use) continue;
+    const bool ones_tile = SPLIT ? k == 1 : k == NT_ACC + NT_NAT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int o = 32 * m_tile + (r & 3) + 8 * (r >> 2) + 4 * hrow - job.o_row0;
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hrow;
+      const int o = 32 * m_tile + ((FP8 && !SPLIT) ? phi8(row) : row) - job.o_row0;
       if (o >= 0 && o < job.o_valid) {
-        if (col >= 0) atomicAdd(args.grads + job.w_off + o * job.w_ld + col, acc[k][r]);
-        if (bias_here) atomicAdd(args.grads + job.bias_off + o, acc[k][r]);
+        if (col >= 0) atomicAdd(args.grads + job.w_off + o * job.w_ld + col, acc[k][r] * w_scale);
+        if (bias_here) atomicAdd(args.grads + job.bias_off + o, acc[k][r] * (ones_tile ? b_scale : w_scale));
       }
     }
   }
@@ -194,6 +249,11 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
   // fragment fhalf, 8-byte row group p>>1
   g.off_acc = 512 * hh + 128 * g.fhalf + 64 * (p & 1) + 16 * q + 8 * (p >> 1);   // + 1024*s + 2048*block
   g.off_nat = 32 * (8 * hh + q) + 16 * (p >> 1) + 8 * (p & 1) + 1024 * g.fhalf;  // + 512*s + 2048*pair
+  // 8-bit images (ds_read_b64_tr_b8): lane 2q8+p8 of a 16-lane group supplies sample 8hh + q8, 8-byte piece p8
+  // of the 16-byte record of lane-half (acc) / k-step (nat) fhalf
+  const int q8 = i16 >> 1, p8 = i16 & 1;
+  g.off_acc8 = 256 * hh + 32 * q8 + 16 * g.fhalf + 8 * p8;            // + 512*ss + 1024*block + wave-tile half
+  g.off_nat8 = 512 * g.fhalf + 16 * (8 * hh + q8) + 8 * p8;          // + 256*ss + 1024*pair + wave-tile half
 
   // this workgroup's span of the cost line
   const long long lo = args.total_cost * blockIdx.x / gridDim.x;
@@ -206,17 +266,28 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
     const long long a0 = lo > j0 ? lo - j0 : 0, a1 = (hi < j1 ? hi : j1) - j0;
     const int wt0 = (int)((a0 + job.cost - 1) / job.cost), wt1 = (int)((a1 + job.cost - 1) / job.cost);
     if (wt0 >= wt1) continue;
+    if (args.amax != nullptr) {   // 8-bit images (vanilla decoder, asm-stream family)
+      switch (job.kind) {
+        case 0: run_job<8, 0, true, false, true>(args, job, wt0, wt1, smem, g); break;
+        case 1: run_job<8, 2, false, false, true>(args, job, wt0, wt1, smem, g); break;
+        case 2: run_job<0, 2, false, false, true>(args, job, wt0, wt1, smem, g); break;
+        case 3: run_job<8, 1, false, false, true>(args, job, wt0, wt1, smem, g); break;
+        case 4: run_job<8, 0, true, true, true>(args, job, wt0, wt1, smem, g); break;
+        default: run_job<4, 0, true, true, true>(args, job, wt0, wt1, smem, g); break;
+      }
+      continue;
+    }
     switch (job.kind) {
-      case 0: run_job<8, 0, true, false>(args, job, wt0, wt1, smem, g); break;    // 256x256 (+bias)
-      case 1: run_job<8, 2, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.4
-      case 2: run_job<0, 2, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.0
-      case 3: run_job<8, 1, false, false>(args, job, wt0, wt1, smem, g); break;   // view_layer
-      case 4: run_job<8, 0, true, true>(args, job, wt0, wt1, smem, g); break;     // sigma_layer
-      case 5: run_job<4, 0, true, true>(args, job, wt0, wt1, smem, g); break;     // rgb_layer
-      case 6: run_job<0, 1, false, false>(args, job, wt0, wt1, smem, g); break;   // instant sigma-net layer 1
-      case 7: run_job<2, 0, false, false>(args, job, wt0, wt1, smem, g); break;   // instant 64-wide layers
-      case 8: run_job<1, 1, false, false>(args, job, wt0, wt1, smem, g); break;   // instant colour-net layer 1
-      default: run_job<2, 0, false, true>(args, job, wt0, wt1, smem, g); break;   // instant rgb layer
+      case 0: run_job<8, 0, true, false, false>(args, job, wt0, wt1, smem, g); break;    // 256x256 (+bias)
+      case 1: run_job<8, 2, false, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.4
+      case 2: run_job<0, 2, false, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.0
+      case 3: run_job<8, 1, false, false, false>(args, job, wt0, wt1, smem, g); break;   // view_layer
+      case 4: run_job<8, 0, true, true, false>(args, job, wt0, wt1, smem, g); break;     // sigma_layer
+      case 5: run_job<4, 0, true, true, false>(args, job, wt0, wt1, smem, g); break;     // rgb_layer
+      case 6: run_job<0, 1, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant sigma-net layer 1
+      case 7: run_job<2, 0, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant 64-wide layers
+      case 8: run_job<1, 1, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant colour-net layer 1
+      default: run_job<2, 0, false, true, false>(args, job, wt0, wt1, smem, g); break;   // instant rgb layer
     }
   }
 }
@@ -231,11 +302,15 @@ using namespace nerf;
 int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work, const BwdLayout& bl,
                       int64_t n, float* grads, int part, hipStream_t stream) {
   WgradArgs args{};
-  const size_t np = (size_t)sl.n_pad;
+  const size_t np = (size_t)sl.n_pad, eb = sl.fp8 ? 1 : 2;
+  if (sl.fp8 != bl.fp8) return fail(NERF_EINVAL, "nerf_mlp_bwd: stash and workspace disagree on the image width");
+  // job byte counts are per ring stage: one 32-sample wave tile of bf16 images or TWO wave tiles of
+  // 8-bit images -- the same numbers either way
+  args.amax = sl.fp8 ? reinterpret_cast<const float*>(work + bl.amax) : nullptr;
   const char* xenc = stash + sl.xenc;
   const char* denc = stash + sl.denc;
-  auto st_h = [&](int l) { return stash + sl.h + (size_t)l * np * 512; };
-  auto dh = [&](int l) { return work + bl.dh + (size_t)l * np * 512; };
+  auto st_h = [&](int l) { return stash + sl.h + (size_t)l * np * 256 * eb; };
+  auto dh = [&](int l) { return work + bl.dh + (size_t)l * np * 256 * eb; };
   int nj = 0;
   auto add = [&](WgradJob j) {
     args.jobs[nj++] = j;
@@ -311,7 +386,7 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   const int overhead = options().wgrad_overhead;
   for (int j = 0; j < nj; ++j)
     args.jobs[j].cost = args.jobs[j].a_bytes + args.jobs[j].b_acc_bytes + args.jobs[j].b_nat_bytes + overhead;
-  args.wave_tiles = (int)((n + 31) / 32);
+  args.wave_tiles = args.amax != nullptr ? (int)((n + 63) / 64) : (int)((n + 31) / 32);   // ring stages per job
   long long c = 0;
   for (int j = 0; j < nj; ++j) {
     args.jobs[j].cost0 = c;

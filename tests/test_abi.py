@@ -57,7 +57,13 @@ def test_load_and_size_queries(lib):
     assert h.nerf_mlp_packed_bytes() % 256 == 0 and h.nerf_mlp_packed_bytes() > 2 * 1024 * 1024
     assert h.nerf_mlp_stash_bytes(0) == 0
     per_sample = h.nerf_mlp_stash_bytes(262144) / 262144
-    assert 5000 < per_sample < 6000          # ~5.3 KB of bf16 activations + relu bits per sample
+    assert 3000 < per_sample < 3300          # 2.5 KB of e4m3 layer inputs + 0.6 KB of relu bits per sample
+    h.nerf_set_option(b"chain_legacy", 1)
+    try:
+        per_sample = h.nerf_mlp_stash_bytes(262144) / 262144
+        assert 5000 < per_sample < 6000      # compiler-scheduled family: bf16 images
+    finally:
+        h.nerf_set_option(b"chain_legacy", 0)
 
 
 def test_ops_refuse_cpu_tensors(lib):

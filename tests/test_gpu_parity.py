@@ -251,9 +251,47 @@ class _Q(torch.autograd.Function):
         return (g.to(torch.bfloat16).to(torch.float32) if ctx.bwd else g), None, None
 
 
-def bf16_param_grads(params, pts, dirs, d_rgb, d_sigma):
+def q8(x, dtype, scale=1.0):
+    """x -> 8-bit float (e4m3fn / e5m2, round to nearest even, saturating as MODE.FP16_OVFL makes the
+    kernels' conversions) -> fp32, around a power-of-two divisor."""
+    lim = 448.0 if dtype is torch.float8_e4m3fn else 57344.0
+    return (x / scale).clamp(-lim, lim).to(dtype).to(torch.float32) * scale
+
+
+def grad_image_scale(amax):
+    """mlp_stash.h::grad_image_scale: the power of two that puts amax in [64, 128)."""
+    import math
+    if amax <= 0:
+        return 2.0 ** -126
+    return 2.0 ** (math.floor(math.log2(amax)) - 6)
+
+
+class _Lin8(torch.autograd.Function):
+    """Linear layer whose WEIGHT gradient is formed from the 8-bit training images of the asm-stream
+    kernels: e4m3 of the (bf16) layer input, e5m2 of the (bf16) pre-activation gradient divided by the
+    launch's gradient scale; the input gradient (dgrad chain) keeps the bf16 values."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gscale):
+        ctx.save_for_backward(x, w)
+        ctx.gscale = gscale          # a one-element list: filled in once the output derivatives are known
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dyb = dy.to(torch.bfloat16).to(torch.float32)            # the chain's bf16 pre-activation gradient
+        dy8 = q8(dyb, torch.float8_e5m2, ctx.gscale[0])
+        x8 = q8(x, torch.float8_e4m3fn)
+        return dyb @ w, dy8.t() @ x8, dy8.sum(0), None
+
+
+def bf16_param_grads(params, pts, dirs, d_rgb, d_sigma, fp8_images=False):
     """Autograd through the oracle decoder with the product's rounding points: bf16 weights,
-    bf16 activations forward, bf16 pre-activation gradients backward, fp32 accumulation."""
+    bf16 activations forward, bf16 pre-activation gradients backward, fp32 accumulation; with
+    ``fp8_images`` the weight gradients additionally see the 8-bit images (asm-stream family)."""
+    if fp8_images:
+        return fp8_param_grads(params, pts, dirs, d_rgb, d_sigma)
     lin = torch.nn.functional.linear
     ps = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     W = lambda k: _Q.apply(ps[k], True, False)
@@ -270,6 +308,32 @@ def bf16_param_grads(params, pts, dirs, d_rgb, d_sigma):
     zv = _Q.apply(lin(torch.cat([feat, d], -1), W("view_layer.weight"), ps["view_layer.bias"]), False, True)
     hv = _Q.apply(torch.relu(zv), True, False)
     rgb = torch.sigmoid(_Q.apply(lin(hv, W("rgb_layer.weight"), ps["rgb_layer.bias"]), False, True))
+    ((rgb * d_rgb).sum() + (sigma[:, 0] * d_sigma).sum()).backward()
+    return {k: v.grad for k, v in ps.items()}
+
+
+def fp8_param_grads(params, pts, dirs, d_rgb, d_sigma):
+    """As bf16_param_grads, with every weight gradient contracted from the 8-bit images (_Lin8).  The
+    gradient scale comes from the largest output-layer derivative, as bwd_amax_kernel computes it."""
+    qb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    ps = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    W = lambda k: _Q.apply(ps[k], True, False)
+    gs = [1.0]
+    lin = lambda x, wk, bk: _Lin8.apply(x, W(wk), ps[bk], gs)
+    x, d = qb(O.fourier_encode(pts, 10)), qb(O.fourier_encode(dirs, 4))
+    ones = torch.ones(x.shape[0], 1)
+    h = x
+    for i in range(8):
+        if i == 4:
+            h = torch.cat([h, x], -1)
+        h = _Q.apply(torch.relu(lin(h, f"pts_layers.{i}.weight", f"pts_layers.{i}.bias")), True, False)
+    sigma = torch.relu(lin(h, "sigma_layer.weight", "sigma_layer.bias"))
+    feat = _Q.apply(lin(h, "feature_layer.weight", "feature_layer.bias"), True, False)
+    hv = _Q.apply(torch.relu(lin(torch.cat([feat, d], -1), "view_layer.weight", "view_layer.bias")), True, False)
+    rgb = torch.sigmoid(lin(hv, "rgb_layer.weight", "rgb_layer.bias"))
+    with torch.no_grad():
+        g_out = torch.cat([d_rgb * rgb * (1 - rgb), (d_sigma * (sigma[:, 0] > 0))[:, None]], -1)
+        gs[0] = grad_image_scale(float(g_out.abs().max()))
     ((rgb * d_rgb).sum() + (sigma[:, 0] * d_sigma).sum()).backward()
     return {k: v.grad for k, v in ps.items()}
 
@@ -320,15 +384,16 @@ def test_decoder_training_families_agree_over_multiple_passes(ops, monkeypatch):
         cnt = int(np.prod(shape))
         ga, gb = a[2][off:off + cnt], b[2][off:off + cnt]
         off += cnt
-        assert float((ga - gb).norm() / (ga.norm() + 1e-12)) < 2e-2, name
+        assert float((ga - gb).norm() / (ga.norm() + 1e-12)) < 0.12, name   # 8-bit vs bf16 training images, random upstream gradients
 
 
 @pytest.mark.parametrize("chain_family", ["asm-stream", "compiler-scheduled"], indirect=True)
 @pytest.mark.parametrize("R,S", [(2, 64), (40, 64), (9, 128)])
 def test_decoder_backward_vs_oracle_autograd(ops, R, S, chain_family):
     """dgrad chain + wgrad vs autograd of the oracle, for both families of chain kernels.
-    * against the oracle evaluated with the SAME rounding points (bf16 operands, fp32 accumulate):
-      per-tensor relative L2 error <= 2e-2 -- this is the correctness bar;
+    * against the oracle evaluated with the SAME rounding points (bf16 operands, fp32 accumulate; for the
+      asm-stream family also the 8-bit training images): per-tensor relative L2 error <= 2e-2 -- this is
+      the correctness bar;
     * against the pure fp32 oracle: bf16 rounding and the ReLU masks it flips accumulate over the
       10 chained layers, stated tolerance: cosine >= 0.98 and relative L2 error <= 0.2 per tensor."""
     params = O.nerf_init_params(seed=3)
@@ -346,7 +411,8 @@ def test_decoder_backward_vs_oracle_autograd(ops, R, S, chain_family):
     grads = ops.mlp_bwd(packed, stash, rgb, sigma, dev(d_rgb), dev(d_sigma)).cpu()
     pts, dirs = O.ray_points(o, d, z)
     ref32 = oracle_param_grads(params, pts, dirs, d_rgb, d_sigma)
-    ref16 = bf16_param_grads(params, pts, dirs, d_rgb, d_sigma)
+    # the asm-stream family contracts the weight gradients from 8-bit images, the compiler-scheduled one from bf16
+    ref16 = bf16_param_grads(params, pts, dirs, d_rgb, d_sigma, fp8_images=chain_family == "asm-stream")
     off = 0
     for name, shape in O.nerf_param_shapes():
         cnt = int(np.prod(shape))

@@ -12,9 +12,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
 
-__global__ void cvt_kernel(const uint32_t* in, const float* scale, uint32_t* out, int n) {
+__global__ void cvt_kernel(const uint32_t* in, const float* scale, uint32_t* out, int n, int ovfl) {
   const int i = threadIdx.x;
   if (i >= n) return;
+  if (ovfl) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");   // MODE.FP16_OVFL
   uint32_t a = 0xAAAAAAAAu, b = 0xAAAAAAAAu, c = 0xAAAAAAAAu, d = 0xAAAAAAAAu;
   asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(a) : "v"(in[i]), "v"(scale[i]));
   asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(b) : "v"(in[i]), "v"(scale[i]));
@@ -65,19 +66,22 @@ int main() {
   const float vals[][3] = {{1.0f, 2.0f, 1.0f}, {0.3f, -0.7f, 1.0f}, {1.0f, 2.0f, 2.0f}, {1.0f, 2.0f, 0.5f}, {448.f, 500.f, 1.0f},
                            {1e6f, -1e6f, 1.0f}, {0.001f, 0.003f, 1.0f}, {0.0009765625f, 0.001953125f, 1.0f}, {1.0625f, 1.1875f, 1.0f},
                            {1.125f, 1.375f, 1.0f}, {60000.f, 70000.f, 1.0f}, {1e-5f, 3e-5f, 1.0f}, {1e-5f, 3e-5f, 1.52587890625e-05f},
-                           {0.0f, -0.0f, 1.0f}, {17.0f, 19.0f, 1.0f}, {1.0f, 2.0f, 65536.0f}};
+                           {0.0f, -0.0f, 1.0f}, {17.0f, 19.0f, 1.0f}, {1.0f, 2.0f, 65536.0f}, {__builtin_inff(), -__builtin_inff(), 1.0f}, {__builtin_nanf(""), 3.0f, 1.0f},
+                           {3e38f, -3e38f, 5.9604644775390625e-08f}};
   const int n = sizeof(vals) / sizeof(vals[0]);
   uint32_t hin[64]; float hsc[64];
   for (int i = 0; i < n; ++i) { hin[i] = f2bf(vals[i][0]) | ((uint32_t)f2bf(vals[i][1]) << 16); hsc[i] = vals[i][2]; }
   uint32_t *din, *dout; float* dsc;
   hipMalloc(&din, 256); hipMalloc(&dsc, 256); hipMalloc(&dout, 64 * 16);
   hipMemcpy(din, hin, 4 * n, hipMemcpyHostToDevice); hipMemcpy(dsc, hsc, 4 * n, hipMemcpyHostToDevice);
-  cvt_kernel<<<1, 64>>>(din, dsc, dout, n);
   uint32_t hout[256];
-  hipMemcpy(hout, dout, 16 * n, hipMemcpyDeviceToHost);
-  printf("== cvt_scalef32_pk_{fp8,bf8}_bf16: in (lo, hi) scale -> fp8 / fp8 op_sel / bf8 / bf8 op_sel (dst preset 0xAAAAAAAA)\n");
-  for (int i = 0; i < n; ++i)
-    printf("(%g, %g) scale %g -> %08x %08x %08x %08x\n", vals[i][0], vals[i][1], vals[i][2], hout[4 * i], hout[4 * i + 1], hout[4 * i + 2], hout[4 * i + 3]);
+  for (int ovfl = 0; ovfl < 2; ++ovfl) {
+    cvt_kernel<<<1, 64>>>(din, dsc, dout, n, ovfl);
+    hipMemcpy(hout, dout, 16 * n, hipMemcpyDeviceToHost);
+    printf("== cvt_scalef32_pk_{fp8,bf8}_bf16, MODE.FP16_OVFL=%d: in (lo, hi) scale -> fp8 / fp8 op_sel / bf8 / bf8 op_sel (dst preset 0xAAAAAAAA)\n", ovfl);
+    for (int i = 0; i < n; ++i)
+      printf("(%g, %g) scale %g -> %08x %08x %08x %08x\n", vals[i][0], vals[i][1], vals[i][2], hout[4 * i], hout[4 * i + 1], hout[4 * i + 2], hout[4 * i + 3]);
+  }
 
   // ---- 2. transposing 8-bit read ----
   uint32_t* dtr; hipMalloc(&dtr, 2 * 64 * 8);
