@@ -181,7 +181,10 @@ int nerf_mlp_pack(const float* params_f32, void* packed, nerf_stream_t stream);
  *                dirs are used as given (NeuralField.forward takes unit view dirs).
  * Outputs rgb [n,3], sigma [n] fp32.
  * stash: NULL for inference; for training a workspace of nerf_mlp_stash_bytes(n)
- * that nerf_mlp_bwd consumes (bf16 activations per layer + relu bitmasks). */
+ * that nerf_mlp_bwd consumes: an image of every layer input + relu bitmasks.  The default (asm-stream)
+ * kernels write 8-bit images (e4m3, 2.5 KB + 0.6 KB of mask words per sample); the compiler-scheduled
+ * family (option chain_legacy, launches above 2^22 samples) writes bf16.  Forward and backward of one
+ * step must run under the same option. */
 size_t nerf_mlp_stash_bytes(int64_t n);
 int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* z,
                  int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
@@ -190,8 +193,10 @@ int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, c
 /* Backward of nerf_mlp_fwd (autograd of src/decoders.py:68-87; the loss.backward() of
  * run.py:337 for the decoder).  rgb/sigma are the forward outputs, d_rgb [n,3] / d_sigma [n]
  * the upstream gradients; grads_f32 [595844] (same layout as the parameter vector) is
- * OVERWRITTEN.  Two kernels: a dgrad chain (transposed weight stream, pre-activation
- * gradients kept as bf16 in `workspace`) and a split-K weight-gradient pass over the stash.
+ * OVERWRITTEN.  Two kernels: a dgrad chain (transposed weight stream; pre-activation gradients kept
+ * in `workspace` as e5m2 images divided by a power of two derived from the launch's largest
+ * output-layer derivative -- bf16 in the compiler-scheduled family) and a split-K weight-gradient
+ * pass over the stash (v_mfma_f32_32x32x16_bf8_fp8 / _bf16).
  * workspace: nerf_mlp_bwd_workspace_bytes(n), 256-byte aligned. */
 size_t nerf_mlp_bwd_workspace_bytes(int64_t n);
 int nerf_mlp_bwd(const void* packed, const void* stash, const float* rgb, const float* sigma,
@@ -201,6 +206,12 @@ int nerf_mlp_bwd(const void* packed, const void* stash, const float* rgb, const 
 int nerf_mlp_bwd_dgrad(const void* packed, const void* stash, const float* rgb, const float* sigma,
                        const float* d_rgb, const float* d_sigma, int64_t n, void* workspace,
                        nerf_stream_t stream);
+/* nerf_mlp_bwd_dgrad with the largest output-layer derivative supplied by the caller (one device fp32:
+ * max over samples of |d_rgb rgb (1 - rgb)| and of |d_sigma| where sigma > 0, e.g. from
+ * nerf_composite_mse_bwd) instead of a pass of its own; amax_dev NULL = nerf_mlp_bwd_dgrad. */
+int nerf_mlp_bwd_dgrad_ex(const void* packed, const void* stash, const float* rgb, const float* sigma,
+                          const float* d_rgb, const float* d_sigma, int64_t n, void* workspace,
+                          const float* amax_dev, nerf_stream_t stream);
 /* nerf_mlp_bwd_wgrad_part: the weight-gradient pass in two launches for a data-parallel caller that
  * all-reduces one parameter range while the other is still being computed.  part 1 writes
  * grads_f32[split, 595844) (pts_layers.4 .. rgb_layer), part 2 writes grads_f32[0, split)
@@ -253,6 +264,20 @@ int nerf_imlp_fwd(const void* packed, void* workspace, const float* dirs, int64_
 int nerf_imlp_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma,
                   const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
                   float* d_feat, nerf_stream_t stream);
+
+/* ---- a9 + a14: compositing fused with the MSE loss and its backward --------------------------
+ * replaces, for one training step, volume_render (src/renderer.py:204-237), nn.MSELoss
+ * (run.py:308,334; run.py:598) and the compositing part of loss.backward() (run.py:337,619):
+ *   pixel = composite(rgb, sigma, z) (+ background), loss += loss_weight * sum (pixel - target)^2,
+ *   d_rgb / d_sigma = gradients of loss_weight * sum (pixel - target)^2.
+ * loss_weight = 1 / (3 n_rays) gives the reference's mean.  slot_of_sample NULL: dense [R,S] inputs;
+ * otherwise compact inputs as in nerf_composite_fwd_indexed.  loss_accum (device fp32) is ADDED to;
+ * amax_accum (optional device fp32, max-accumulated; caller zeroes both) receives the vanilla decoder's
+ * largest output-layer derivative for nerf_mlp_bwd_dgrad_ex.  pred_out [R,3] optional. */
+int nerf_composite_mse_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
+                           const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
+                           float loss_weight, int64_t n_rays, int n_samples, float* pred_out, float* loss_accum,
+                           float* d_rgb, float* d_sigma, float* amax_accum, nerf_stream_t stream);
 
 /* ---- a14: optimiser ---------------------------------------------------------
  * replaces torch.optim.Adam / AdamW .step() (run.py:307,338; run.py:546,629) for

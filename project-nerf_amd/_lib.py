@@ -46,6 +46,9 @@ PROTOTYPES = {
     "nerf_mlp_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_bwd_dgrad": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
     "nerf_mlp_bwd_wgrad": (i32, [c_ptr, c_ptr, i64, c_ptr, c_ptr]),
+    "nerf_mlp_bwd_dgrad_ex": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
+    "nerf_composite_mse_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, f32, i64, i32, c_ptr, c_ptr,
+                                     c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_wgrad_part_split": (i64, []),
     "nerf_mlp_bwd_wgrad_part": (i32, [c_ptr, c_ptr, i64, c_ptr, i32, c_ptr]),
     "nerf_hash_encode_fwd": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr, c_ptr]),

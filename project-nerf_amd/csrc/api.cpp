@@ -22,6 +22,8 @@ static const OptionSlot kSlots[] = {
     {"chain_legacy", "NERF_CHAIN_LEGACY", &Options::chain_legacy},
     {"fwd_cycles", "NERF_FWD_CYCLES", &Options::fwd_cycles},
     {"wgrad_overhead", "NERF_WGRAD_OVH", &Options::wgrad_overhead},
+    {"wgrad_bw_x16", "NERF_WGRAD_BW", &Options::wgrad_bw_x16},
+    {"wgrad_fixed", "NERF_WGRAD_FIXED", &Options::wgrad_fixed},
     {"wgrad_debug", "NERF_WGRAD_DEBUG", &Options::wgrad_debug},
     {"wgrad_only", "NERF_WGRAD_ONLY", &Options::wgrad_only},
     {"hash_bwd_only_level", "NERF_HASH_BWD_ONLY_LEVEL", &Options::hash_bwd_only_level},

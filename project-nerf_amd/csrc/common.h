@@ -25,7 +25,9 @@ inline hipStream_t as_stream(nerf_stream_t s) { return reinterpret_cast<hipStrea
 struct Options {
   int chain_legacy = 0;          // compiler-scheduled chain kernels instead of the asm streams
   int fwd_cycles = 0;            // print shader cycles per pass of the forward stream kernel
-  int wgrad_overhead = 98304;    // span cost model: fixed share per ring iteration (bytes)
+  int wgrad_overhead = 98304;    // span cost model, bf16 images: fixed share per ring iteration (bytes)
+  int wgrad_bw_x16 = 192;        // span cost model, 8-bit images: DMA bytes per 16 shader cycles and CU
+  int wgrad_fixed = 2000;        // ... and the fixed cycles per ring iteration
   int wgrad_debug = 0;           // skeleton timing: 1 no compute, 2 no DMA, 4 no flush
   int wgrad_only = -1;           // keep one job kind
   int hash_bwd_only_level = -1;  // time one level's atomics

@@ -212,6 +212,109 @@ composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
   }
 }
 
+// Training step around the compositing (reference run.py:324-337: render_rays -> nn.MSELoss ->
+// loss.backward(), the compositing part): one pass per ray computes the pixel, its squared error,
+// g = 2 (pixel - target) loss_weight and the gradients of rgb / sigma -- the forward and backward kernels
+// above fused with the four elementwise / reduction launches of the loss in between.
+// amax_out (optional): running maximum of the vanilla decoder's output-layer derivatives
+// |d_rgb rgb (1 - rgb)| and |d_sigma| (sigma > 0), which nerf_mlp_bwd_dgrad_ex takes instead of its own pass.
+template <int K>
+__global__ void __launch_bounds__(256)
+composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ sigma, const float* __restrict__ z,
+                         const float* __restrict__ rays_d, const float* __restrict__ bg, int64_t bg_rows,
+                         const float* __restrict__ target, float loss_weight, const int* __restrict__ slots, int64_t R, int S,
+                         float* __restrict__ pred_out, float* __restrict__ loss_out, float* __restrict__ d_rgb,
+                         float* __restrict__ d_sigma, float* __restrict__ amax_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  float loss_local = 0.0f, amax = 0.0f;
+  for (int64_t r = wave; r < R; r += nwave) {
+    RayCtx c;
+    float sg[K];
+    int64_t row[K];
+    ray_setup<K>(sigma, z, rays_d, slots, r, S, lane, c, sg, row);
+    float col[K][3], w[K];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, aw = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int s = lane * K + k;
+      w[k] = 0.0f;
+      col[k][0] = col[k][1] = col[k][2] = 0.0f;
+      if (s < S) {
+        w[k] = c.alpha[k] * c.T[k];
+        if (row[k] >= 0) {
+          const float* p = rgb + row[k] * 3;
+          col[k][0] = p[0]; col[k][1] = p[1]; col[k][2] = p[2];
+          a0 += w[k] * p[0]; a1 += w[k] * p[1]; a2 += w[k] * p[2];
+        }
+        aw += w[k];
+      }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); aw = wave_sum(aw);
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (bg != nullptr) {
+      const float* b = bg + (bg_rows > 1 ? r * 3 : 0);
+      b0 = b[0]; b1 = b[1]; b2 = b[2];
+      const float rest = 1.0f - aw;
+      a0 += rest * b0; a1 += rest * b1; a2 += rest * b2;
+    }
+    const float e0 = a0 - target[r * 3 + 0], e1 = a1 - target[r * 3 + 1], e2 = a2 - target[r * 3 + 2];
+    if (lane == 0) {
+      loss_local += (e0 * e0 + e1 * e1 + e2 * e2) * loss_weight;
+      if (pred_out != nullptr) { pred_out[r * 3 + 0] = a0; pred_out[r * 3 + 1] = a1; pred_out[r * 3 + 2] = a2; }
+    }
+    const float gr0 = 2.0f * e0 * loss_weight, gr1 = 2.0f * e1 * loss_weight, gr2 = 2.0f * e2 * loss_weight;
+    const float ga = -(gr0 * b0 + gr1 * b1 + gr2 * b2);
+    float G[K], local = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int s = lane * K + k;
+      G[k] = 0.0f;
+      if (s < S) {
+        float g = ga;
+        if (row[k] >= 0) {
+          g += gr0 * col[k][0] + gr1 * col[k][1] + gr2 * col[k][2];
+          float* o = d_rgb + row[k] * 3;
+          const float d0 = w[k] * gr0, d1 = w[k] * gr1, d2 = w[k] * gr2;
+          o[0] = d0; o[1] = d1; o[2] = d2;
+          if (amax_out != nullptr)
+            amax = fmaxf(amax, fmaxf(fabsf(d0 * col[k][0] * (1.0f - col[k][0])),
+                                     fmaxf(fabsf(d1 * col[k][1] * (1.0f - col[k][1])), fabsf(d2 * col[k][2] * (1.0f - col[k][2])))));
+        }
+        G[k] = g;
+        local += g * w[k];
+      }
+    }
+    float after = wave_exclusive_suffix_sum(local);
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+      const int s = lane * K + k;
+      if (s < S && row[k] >= 0) {
+        const float dalpha = G[k] * c.T[k] - after / c.q[k];
+        const float ds = dalpha * c.delta[k] * c.e[k];
+        d_sigma[row[k]] = ds;
+        if (amax_out != nullptr && sg[k] > 0.0f) amax = fmaxf(amax, fabsf(ds));
+      }
+      after += G[k] * w[k];
+    }
+  }
+  // one atomic per workgroup for the loss and for the maximum (same-address atomics serialise in L2)
+  __shared__ float part[8];
+  loss_local = wave_sum(loss_local);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if (lane == 0) { part[threadIdx.x >> 6] = loss_local; part[4 + (threadIdx.x >> 6)] = amax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(loss_out, (part[0] + part[1]) + (part[2] + part[3]));
+    if (amax_out != nullptr) {
+      const float m = fmaxf(fmaxf(part[4], part[5]), fmaxf(part[6], part[7]));
+      if (m == m && m < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, m));
+    }
+  }
+}
+
 static int per_lane(int S) { return (S + 63) / 64; }
 
 }  // namespace nerf
@@ -302,4 +405,21 @@ extern "C" int nerf_composite_bwd_indexed(const float* rgb_compact, const float*
   NERF_REQUIRE(n_rays == 0 || slot_of_sample != nullptr, "nerf_composite_bwd_indexed: slot map is NULL");
   return composite_bwd_impl(rgb_compact, sigma_compact, z, rays_d, bg, bg_rows, nullptr, g_rgb, g_depth, g_acc, nullptr,
                             slot_of_sample, n_rays, n_samples, d_rgb_compact, d_sigma_compact, nullptr, stream);
+}
+
+extern "C" int nerf_composite_mse_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
+                                      const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
+                                      float loss_weight, int64_t n_rays, int n_samples, float* pred_out, float* loss_accum,
+                                      float* d_rgb, float* d_sigma, float* amax_accum, nerf_stream_t stream) {
+  NERF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 64 * kMaxPerLane,
+               "nerf_composite_mse_bwd: n_rays=%lld n_samples=%d (max %d)", (long long)n_rays, n_samples, 64 * kMaxPerLane);
+  if (n_rays == 0) return NERF_OK;
+  NERF_REQUIRE(rgb && sigma && z && rays_d && target && loss_accum && d_rgb && d_sigma, "nerf_composite_mse_bwd: NULL pointer");
+  NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_mse_bwd: bg_rows=%lld", (long long)bg_rows);
+  int64_t blocks = (n_rays + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const dim3 grid((int)blocks);
+  DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
+             slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, amax_accum);
+  return check_launch("nerf_composite_mse_bwd");
 }

@@ -25,7 +25,8 @@ struct BwdArgs {
   __bf16* dhv;            // blocked [n_pad,128]
   __bf16* dfeat;          // blocked [n_pad,256]
   __bf16* dh;             // 8 x blocked [n_pad,256]
-  float* amax;            // 8-bit images: max |output-layer derivative| of the launch (bwd_amax_kernel)
+  float* amax;            // 8-bit images: max |output-layer derivative| of the launch (workspace slot read by wgrad)
+  const float* amax_src;  // where the dgrad kernel reads it: == amax (bwd_amax_kernel ran) or the caller's value
 };
 
 // output-layer derivatives of one sample: sigmoid' and relu' applied to the upstream gradients
@@ -183,7 +184,9 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const 
   // e5m2 gradient images, divided by a power of two that puts the launch's largest output-layer
   // derivative in [64, 128) (the chain itself runs on unscaled bf16; wgrad multiplies the scale back)
   set_fp8_saturate();
-  const float gscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, grad_image_scale(*a.amax))));
+  const float amax_in = *a.amax_src;
+  if (a.amax_src != a.amax && blockIdx.x == 0 && tid == 0) *a.amax = amax_in;   // the wgrad pass reads the workspace slot
+  const float gscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, grad_image_scale(amax_in))));
   const int64_t n_tiles = a.n_pad / kTileSamples;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t wave_tile = tile * 8 + wave;
@@ -224,7 +227,7 @@ extern "C" size_t nerf_mlp_bwd_workspace_bytes(int64_t n) { return n > 0 ? bwd_l
 
 static int launch_dgrad(const void* packed, const void* stash, const float* rgb, const float* sigma,
                         const float* d_rgb, const float* d_sigma, int64_t n, void* workspace,
-                        nerf_stream_t stream) {
+                        const float* amax_dev, nerf_stream_t stream) {
   NERF_REQUIRE(n > 0 && n < (int64_t)1 << 31, "nerf_mlp_bwd: n=%lld out of range", (long long)n);
   NERF_REQUIRE(packed && stash && rgb && sigma && d_rgb && d_sigma && workspace, "nerf_mlp_bwd: NULL pointer");
   NERF_REQUIRE(((uintptr_t)packed & 255) == 0 && ((uintptr_t)stash & 255) == 0 && ((uintptr_t)workspace & 255) == 0,
@@ -242,6 +245,7 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
   a.dfeat = reinterpret_cast<__bf16*>(w + bl.dfeat);
   a.dh = reinterpret_cast<__bf16*>(w + bl.dh);
   a.amax = reinterpret_cast<float*>(w + bl.amax);
+  a.amax_src = amax_dev != nullptr ? amax_dev : a.amax;
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
   const bool stream_family = chain_use_stream(n, true);
@@ -249,7 +253,7 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
                                   "nerf_mlp_bwd"); rc != NERF_OK) return rc;
   const int64_t tiles = bl.n_pad / kTileSamples;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
-  if (bl.fp8) {
+  if (bl.fp8 && amax_dev == nullptr) {
     if (hipMemsetAsync(a.amax, 0, sizeof(float), as_stream(stream)) != hipSuccess)
       return fail(NERF_ELAUNCH, "nerf_mlp_bwd: memset failed");
     const int64_t want = (n + 1023) / 1024;
@@ -279,7 +283,14 @@ extern "C" int nerf_mlp_bwd_dgrad(const void* packed, const void* stash, const f
                                   const float* d_rgb, const float* d_sigma, int64_t n, void* workspace,
                                   nerf_stream_t stream) {
   if (n == 0) return NERF_OK;
-  return launch_dgrad(packed, stash, rgb, sigma, d_rgb, d_sigma, n, workspace, stream);
+  return launch_dgrad(packed, stash, rgb, sigma, d_rgb, d_sigma, n, workspace, nullptr, stream);
+}
+
+extern "C" int nerf_mlp_bwd_dgrad_ex(const void* packed, const void* stash, const float* rgb, const float* sigma,
+                                     const float* d_rgb, const float* d_sigma, int64_t n, void* workspace,
+                                     const float* amax_dev, nerf_stream_t stream) {
+  if (n == 0) return NERF_OK;
+  return launch_dgrad(packed, stash, rgb, sigma, d_rgb, d_sigma, n, workspace, amax_dev, stream);
 }
 
 extern "C" int nerf_mlp_bwd_wgrad(const void* stash, const void* workspace, int64_t n, float* grads_f32,
@@ -299,7 +310,7 @@ extern "C" int nerf_mlp_bwd(const void* packed, const void* stash, const float* 
                             void* workspace, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0, "nerf_mlp_bwd: n=%lld", (long long)n);
   if (n > 0) {
-    const int rc = launch_dgrad(packed, stash, rgb, sigma, d_rgb, d_sigma, n, workspace, stream);
+    const int rc = launch_dgrad(packed, stash, rgb, sigma, d_rgb, d_sigma, n, workspace, nullptr, stream);
     if (rc != NERF_OK) return rc;
   }
   return launch_wgrad(stash, workspace, n, grads_f32, 0, stream);

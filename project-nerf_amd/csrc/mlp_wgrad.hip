@@ -63,6 +63,161 @@ __device__ __forceinline__ long tr_frag8(const char* p) {
 // lane-half r>>4 is 16 consecutive accumulator registers); natural-order operands are the identity
 __device__ __forceinline__ int phi8(int r) { return (r & 3) + 8 * ((r & 15) >> 2) + 4 * (r >> 4); }
 
+// Partial sums of one span -> float atomics.  C layout: row = (r&3) + 8(r>>2) + 4(lane>>5) of the wave's
+// 32-row tile, column = lane&31 of column tile k (two 128-byte segments per wave instruction).
+template <int NT_ACC, int NT_NAT, bool ONES, bool SPLIT, bool FP8, int NT>
+__device__ __forceinline__ void flush_tiles(const WgradArgs& args, const WgradJob& job, const f32x16 (&acc)[NT], const LaneGeo g,
+                                            bool active) {
+  const int wave = g.wave, lane = g.lane;
+  if (!active || (args.debug & 4)) return;
+  const int c32 = lane & 31, hrow = lane >> 5;
+  const int m_tile = SPLIT ? 0 : wave;
+  // 8-bit images: acc-type operands carry their tile's rows in the order phi8; the sums come back in
+  // units of (gradient scale) x (activation scale), bias sums (all-ones operand) of the gradient scale alone
+  const int c_acc = FP8 ? phi8(c32) : c32;
+  float w_scale = 1.0f, b_scale = 1.0f;
+  if constexpr (FP8) {
+    b_scale = grad_image_scale(*args.amax);
+    w_scale = b_scale * kActScale;
+  }
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    int col = -1, bias_here = 0;
+    bool use = true;
+    if constexpr (SPLIT) {
+      if (k == 0) { use = wave < NT_ACC; const int i = wave * 32 + c_acc; if (i < job.acc_valid) col = job.acc_col0 + i; }
+      else { use = ONES && wave == NT_ACC % 8; bias_here = (c32 == 0); }
+    } else {
+      if (k < NT_ACC) { const int i = k * 32 + c_acc; if (i < job.acc_valid) col = job.acc_col0 + i; }
+      else if (k < NT_ACC + NT_NAT) {
+        const int i = (k - NT_ACC) * 32 + c32;
+        if (i < job.nat_valid) col = job.nat_col0 + i;
+        bias_here = (i == job.bias_nat_col);
+      } else bias_here = (c32 == 0);
+    }
+    if (!use) continue;
+    const bool ones_tile = SPLIT ? k == 1 : k == NT_ACC + NT_NAT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hrow;
+      const int o = 32 * m_tile + ((FP8 && !SPLIT) ? phi8(row) : row) - job.o_row0;
+      if (o >= 0 && o < job.o_valid) {
+        if (col >= 0) atomicAdd(args.grads + job.w_off + o * job.w_ld + col, acc[k][r] * w_scale);
+        if (bias_here) atomicAdd(args.grads + job.bias_off + o, acc[k][r] * (ones_tile ? b_scale : w_scale));
+      }
+    }
+  }
+}
+
+// 8-bit images, owner mode: the same span loop, software-pipelined inside the wave.  The fragments of
+// k-step s+1 (or of the next stage's first k-step: the stage barrier already covers stage wt+1) are read
+// while the MFMAs of k-step s run, so the matrix pipe is not left waiting for LDS at every k-step
+// (compute-only time of the unpipelined loop: 0.30 ms against a 0.17-0.20 ms MFMA floor at 4096 x 64).
+template <int NT_ACC, int NT_NAT, bool ONES>
+__device__ __forceinline__ void run_job8(const WgradArgs& args, const WgradJob job, int wt0, int wt1,
+                                         char* smem, const LaneGeo g) {
+  constexpr int NB = NT_ACC + NT_NAT, NT = NB + (ONES ? 1 : 0);
+  const int wave = g.wave, lane = g.lane;
+  const bool active = wave < job.mt_a;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+  const int pieces_a = job.a_bytes >> 10, pieces_b = job.b_acc_bytes >> 10, pieces_n = job.b_nat_bytes >> 10;
+  const int pieces = pieces_a + pieces_b + pieces_n;
+  const int per_wave = (pieces + 7) >> 3;    // every wave issues exactly this many (tail duplicates)
+  const unsigned smem_lds = lds_addr(smem);
+  auto issue = [&](int wt) {
+    const unsigned stage = smem_lds + (wt & (kWgStages - 1)) * kWgStageBytes;
+    for (int i = 0; i < per_wave; ++i) {
+      int pc = wave + 8 * i;
+      pc = pc < pieces ? pc : pieces - 1;
+      const char* src;
+      unsigned dst;
+      if (pc < pieces_a) {
+        src = job.a + (size_t)wt * job.a_bytes + pc * 1024;
+        dst = stage + pc * 1024;
+      } else if (pc < pieces_a + pieces_b) {
+        const int o = pc - pieces_a;
+        src = job.b_acc + (size_t)wt * job.b_acc_bytes + o * 1024;
+        dst = stage + kWgStageA + o * 1024;
+      } else {
+        const int o = pc - pieces_a - pieces_b;
+        src = job.b_nat + (size_t)wt * job.b_nat_bytes + o * 1024;
+        dst = stage + kWgStageA + kWgStageB + o * 1024;
+      }
+      dma_1k(src + lane * 16, __builtin_amdgcn_readfirstlane(dst));
+    }
+  };
+  auto wait_in_flight = [&](int stages) {   // all but `stages` newest stages of this wave have landed
+    const int outstanding = stages * per_wave;
+    if (outstanding >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (outstanding >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (outstanding >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (outstanding >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (outstanding >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (outstanding >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (outstanding >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  const int half_a = job.a_bytes >> 1, half_b = job.b_acc_bytes >> 1, half_n = job.b_nat_bytes >> 1;
+  // fragments of k-step s (0..3) of the stage at `stage`: A tile of this wave, NB column tiles
+  auto load = [&](const char* stage, int s, long& a, long (&b)[NB > 0 ? NB : 1]) {
+    const int t = s >> 1, ss = s & 1;
+    a = tr_frag8(stage + wave * 1024 + g.off_acc8 + t * half_a + 512 * ss);
+#pragma unroll
+    for (int k = 0; k < NT_ACC; ++k) b[k] = tr_frag8(stage + kWgStageA + g.off_acc8 + t * half_b + k * 1024 + 512 * ss);
+#pragma unroll
+    for (int k = 0; k < NT_NAT; ++k)
+      b[NT_ACC + k] = tr_frag8(stage + kWgStageA + kWgStageB + g.off_nat8 + t * half_n + k * 1024 + 256 * ss);
+  };
+  const long ones8 = 0x3838383838383838L;   // 8 x e4m3 1.0
+  const bool compute = active && !(args.debug & 1);
+
+  __builtin_amdgcn_s_barrier();   // previous span's readers are done with the ring
+  if (wt0 + 0 < wt1) issue(wt0 + 0);
+  if (wt0 + 1 < wt1) issue(wt0 + 1);
+  if (wt0 + 2 < wt1) issue(wt0 + 2);
+  wait_in_flight((wt0 + 1 < wt1) + (wt0 + 2 < wt1));
+  __builtin_amdgcn_s_barrier();   // stage wt0 has landed for every wave
+  asm volatile("" ::: "memory");
+  long a_cur = 0, b_cur[NB > 0 ? NB : 1];
+  if (compute) load(smem + (wt0 & (kWgStages - 1)) * kWgStageBytes, 0, a_cur, b_cur);
+  for (int wt = wt0; wt < wt1; ++wt) {
+    // stage wt+1 must be visible before this iteration's last k-step prefetches from it; the same
+    // barrier says every wave has finished reading stage wt-1, whose slot the next DMA refills
+    wait_in_flight(wt + 2 < wt1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wt + 3 < wt1 && !(args.debug & 2)) issue(wt + 3);
+    if (!compute) continue;
+    const char* stage = smem + (wt & (kWgStages - 1)) * kWgStageBytes;
+    const char* next = smem + ((wt + 1) & (kWgStages - 1)) * kWgStageBytes;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      long a_nxt = 0, b_nxt[NB > 0 ? NB : 1];
+      if (s < 3) load(stage, s + 1, a_nxt, b_nxt);
+      else if (wt + 1 < wt1) load(next, 0, a_nxt, b_nxt);
+#pragma unroll
+      for (int k = 0; k < NB; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a_cur, b_cur[k], acc[k], 0, 0, 0);
+      if constexpr (ONES) acc[NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a_cur, ones8, acc[NB], 0, 0, 0);
+      // interleave: the next k-step's reads ride in the gaps of this k-step's MFMAs
+      static_for<NT>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, reads = NB + 1;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, reads / NT + (k < reads % NT ? 1 : 0), 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      a_cur = a_nxt;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) b_cur[k] = b_nxt[k];
+    }
+  }
+  flush_tiles<NT_ACC, NT_NAT, ONES, false, true, NT>(args, job, acc, g, active);
+}
+
 // One job span [wt0, wt1) of one layer.  OWNER mode (SPLIT = false): wave w owns output rows
 // 32w.. x all NT = NT_ACC + NT_NAT + ONES column tiles.  SPLIT mode (single 16-row natural A
 // block, dsmall): wave w owns column tile w (w < NT_ACC) and wave NT_ACC % 8 the ones tile.
@@ -194,45 +349,7 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
     }
   }
 
-  // ---- flush: row o = 32*m_tile + (r&3) + 8*(r>>2) + 4*hrow, column = 32*nt + (lane&31) ----
-  if (!active || (args.debug & 4)) return;
-  const int c32 = lane & 31, hrow = lane >> 5;
-  const int m_tile = SPLIT ? 0 : wave;
-  // 8-bit images: acc-type operands carry their tile's rows in the order phi8; the sums come back in
-  // units of (gradient scale) x (activation scale), bias sums (all-ones operand) of the gradient scale alone
-  const int c_acc = FP8 ? phi8(c32) : c32;
-  float w_scale = 1.0f, b_scale = 1.0f;
-  if constexpr (FP8) {
-    b_scale = grad_image_scale(*args.amax);
-    w_scale = b_scale * kActScale;
-  }
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    int col = -1, bias_here = 0;
-    bool use = true;
-    if constexpr (SPLIT) {
-      if (k == 0) { use = wave < NT_ACC; const int i = wave * 32 + c_acc; if (i < job.acc_valid) col = job.acc_col0 + i; }
-      else { use = ONES && wave == NT_ACC % 8; bias_here = (c32 == 0); }
-    } else {
-      if (k < NT_ACC) { const int i = k * 32 + c_acc; if (i < job.acc_valid) col = job.acc_col0 + i; }
-      else if (k < NT_ACC + NT_NAT) {
-        const int i = (k - NT_ACC) * 32 + c32;
-        if (i < job.nat_valid) col = job.nat_col0 + i;
-        bias_here = (i == job.bias_nat_col);
-      } else bias_here = (c32 == 0);
-    }
-    if (!use) continue;
-    const bool ones_tile = SPLIT ? k == 1 : k == NT_ACC + NT_NAT;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * hrow;
-      const int o = 32 * m_tile + ((FP8 && !SPLIT) ? phi8(row) : row) - job.o_row0;
-      if (o >= 0 && o < job.o_valid) {
-        if (col >= 0) atomicAdd(args.grads + job.w_off + o * job.w_ld + col, acc[k][r] * w_scale);
-        if (bias_here) atomicAdd(args.grads + job.bias_off + o, acc[k][r] * (ones_tile ? b_scale : w_scale));
-      }
-    }
-  }
+  flush_tiles<NT_ACC, NT_NAT, ONES, SPLIT, FP8, NT>(args, job, acc, g, active);
 }
 
 __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args) {
@@ -268,10 +385,10 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
     if (wt0 >= wt1) continue;
     if (args.amax != nullptr) {   // 8-bit images (vanilla decoder, asm-stream family)
       switch (job.kind) {
-        case 0: run_job<8, 0, true, false, true>(args, job, wt0, wt1, smem, g); break;
-        case 1: run_job<8, 2, false, false, true>(args, job, wt0, wt1, smem, g); break;
-        case 2: run_job<0, 2, false, false, true>(args, job, wt0, wt1, smem, g); break;
-        case 3: run_job<8, 1, false, false, true>(args, job, wt0, wt1, smem, g); break;
+        case 0: run_job8<8, 0, true>(args, job, wt0, wt1, smem, g); break;
+        case 1: run_job8<8, 2, false>(args, job, wt0, wt1, smem, g); break;
+        case 2: run_job8<0, 2, false>(args, job, wt0, wt1, smem, g); break;
+        case 3: run_job8<8, 1, false>(args, job, wt0, wt1, smem, g); break;
         case 4: run_job<8, 0, true, true, true>(args, job, wt0, wt1, smem, g); break;
         default: run_job<4, 0, true, true, true>(args, job, wt0, wt1, smem, g); break;
       }
@@ -384,8 +501,20 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   // 0.88 ms, 16 KB -> 0.64, 96 KB -> 0.53); with byte-only costs the workgroups owning the narrow
   // layers (rgb: 9 KB per wave tile) ran 3x more iterations and finished last (1.11 ms).
   const int overhead = options().wgrad_overhead;
-  for (int j = 0; j < nj; ++j)
-    args.jobs[j].cost = args.jobs[j].a_bytes + args.jobs[j].b_acc_bytes + args.jobs[j].b_nat_bytes + overhead;
+  for (int j = 0; j < nj; ++j) {
+    WgradJob& jb = args.jobs[j];
+    const int bytes = jb.a_bytes + jb.b_acc_bytes + jb.b_nat_bytes;
+    jb.cost = bytes + overhead;
+    if (args.amax != nullptr) {
+      // 8-bit images: a stage costs max(DMA time, MFMA time) + a fixed share, in shader cycles.  DMA: the
+      // CU's share of the HBM stream (wgrad_bw_x16 bytes per 16 cycles); MFMA: 32 cycles each on the
+      // busiest SIMD (waves w and w+4 share one; four k-steps per stage)
+      const int nt = jb.nt_acc + jb.nt_nat + jb.ones;
+      const int per_simd = jb.split_n ? (jb.nt_acc > 4 ? 3 : 2) : (jb.mt_a > 4 ? 2 : 1) * nt;
+      const int t_mfma = 32 * 4 * per_simd, t_dma = bytes * 16 / options().wgrad_bw_x16;
+      jb.cost = (t_mfma > t_dma ? t_mfma : t_dma) + options().wgrad_fixed;
+    }
+  }
   args.wave_tiles = args.amax != nullptr ? (int)((n + 63) / 64) : (int)((n + 31) / 32);   // ring stages per job
   long long c = 0;
   for (int j = 0; j < nj; ++j) {

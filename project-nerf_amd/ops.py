@@ -240,6 +240,27 @@ def composite_bwd(rgb, sigma, z, rays_d, bg, extra, g_rgb, g_depth, g_acc, g_ext
     return d_rgb, d_sigma, d_extra
 
 
+def composite_mse_bwd(rgb: Tensor, sigma: Tensor, z: Tensor, rays_d: Tensor, bg: Optional[Tensor], target: Tensor,
+                      loss_accum: Tensor, slots: Optional[Tensor] = None, amax_accum: Optional[Tensor] = None,
+                      loss_weight: Optional[float] = None, want_pred: bool = False):
+    """One kernel for compositing + MSE + their backward (reference run.py:324-337): returns
+    (d_rgb, d_sigma, pred or None); the loss is ADDED to ``loss_accum`` (a zeroed device scalar)."""
+    lib = _lib.load()
+    rgb, sigma, z, rays_d, target = _dev(rgb, "rgb"), _dev(sigma, "sigma"), _dev(z, "z"), _dev(rays_d, "rays_d"), _dev(target, "target")
+    R, S = z.shape
+    bg_rows = 0
+    if bg is not None:
+        bg = _dev(bg, "bg")
+        bg_rows = 1 if bg.dim() == 1 else bg.shape[0]
+    d_rgb, d_sigma = torch.empty_like(rgb), torch.empty_like(sigma)
+    pred = torch.empty(R, 3, device=z.device) if want_pred else None
+    w = 1.0 / (3 * R) if loss_weight is None else loss_weight
+    _lib.check(lib.nerf_composite_mse_bwd(_p(rgb), _p(sigma), _p(slots), _p(z), _p(rays_d), _p(bg), bg_rows, _p(target), w, R, S,
+                                          _p(pred), _p(loss_accum), _p(d_rgb), _p(d_sigma), _p(amax_accum), _stream()),
+               "nerf_composite_mse_bwd")
+    return d_rgb, d_sigma, pred
+
+
 class _Composite(torch.autograd.Function):
     """volume_render (reference src/renderer.py:204-237) as one fused kernel per direction."""
 
@@ -313,8 +334,9 @@ def mlp_bwd_workspace_bytes(n: int) -> int:
 
 
 def mlp_bwd(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Tensor, d_sigma: Tensor,
-            grads: Optional[Tensor] = None, workspace: Optional[Tensor] = None) -> Tensor:
-    """Parameter gradients [595844] (reference state_dict order) of the fused decoder."""
+            grads: Optional[Tensor] = None, workspace: Optional[Tensor] = None, amax: Optional[Tensor] = None) -> Tensor:
+    """Parameter gradients [595844] (reference state_dict order) of the fused decoder.  ``amax``: the
+    largest output-layer derivative as a device scalar (from composite_mse_bwd), else computed here."""
     lib = _lib.load()
     rgb, sigma = _dev(rgb, "rgb"), _dev(sigma, "sigma")
     d_rgb, d_sigma = _dev(d_rgb, "d_rgb"), _dev(d_sigma, "d_sigma")
@@ -323,20 +345,25 @@ def mlp_bwd(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Te
         grads = torch.empty(MLP_PARAM_COUNT, device=rgb.device, dtype=torch.float32)
     if workspace is None:
         workspace = torch.empty(lib.nerf_mlp_bwd_workspace_bytes(n), device=rgb.device, dtype=torch.uint8)
-    _lib.check(lib.nerf_mlp_bwd(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
-                                _p(grads), _p(workspace), _stream()), "nerf_mlp_bwd")
+    if amax is None:
+        _lib.check(lib.nerf_mlp_bwd(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
+                                    _p(grads), _p(workspace), _stream()), "nerf_mlp_bwd")
+    else:
+        _lib.check(lib.nerf_mlp_bwd_dgrad_ex(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
+                                             _p(workspace), _p(amax), _stream()), "nerf_mlp_bwd_dgrad_ex")
+        _lib.check(lib.nerf_mlp_bwd_wgrad(_p(stash), _p(workspace), n, _p(grads), _stream()), "nerf_mlp_bwd_wgrad")
     return grads
 
 
 def mlp_bwd_overlapped(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Tensor, d_sigma: Tensor,
-                       grads: Tensor, workspace: Tensor, reduce_async) -> None:
+                       grads: Tensor, workspace: Tensor, reduce_async, amax: Optional[Tensor] = None) -> None:
     """mlp_bwd for data-parallel training: dgrad, then the weight gradients in two launches;
     ``reduce_async(view)`` starts the all-reduce of a finished parameter range and returns a
     handle (``.wait()``) or None -- the first range is on the wire while the second is computed."""
     lib = _lib.load()
     n = sigma.numel()
-    _lib.check(lib.nerf_mlp_bwd_dgrad(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
-                                      _p(workspace), _stream()), "nerf_mlp_bwd_dgrad")
+    _lib.check(lib.nerf_mlp_bwd_dgrad_ex(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
+                                         _p(workspace), _p(amax), _stream()), "nerf_mlp_bwd_dgrad")
     split = lib.nerf_mlp_wgrad_part_split()
     handles = []
     for part, view in ((1, grads[split:]), (2, grads[:split])):

@@ -156,6 +156,36 @@ def test_composite_far_sample_absorbs_remainder(ops):
     np.testing.assert_allclose(acc.cpu().numpy(), 1.0, atol=1e-6)
 
 
+@pytest.mark.parametrize("S,bg_kind", [(64, "vec"), (128, "ray"), (17, "none")])
+def test_composite_mse_bwd_equals_separate_kernels_and_torch_mse(ops, S, bg_kind):
+    """nerf_composite_mse_bwd == volume_render -> nn.MSELoss -> backward (reference run.py:324-337), i.e. the
+    golden-pinned composite kernels chained with torch's MSE; the reported maximum is the largest
+    output-layer derivative of the vanilla decoder."""
+    gen = torch.Generator().manual_seed(S)
+    R = 41
+    z = torch.sort(torch.rand(R, S, generator=gen) * 4 + 2, dim=-1).values
+    sig = torch.relu(torch.randn(R, S, generator=gen)) * 3          # exact zeros included (relu'd density)
+    rgb = torch.rand(R, S, 3, generator=gen)
+    target = torch.rand(R, 3, generator=gen)
+    _, d = synth_rays(R, S)
+    bg = {"vec": torch.ones(3), "ray": torch.rand(R, 3, generator=gen), "none": None}[bg_kind]
+    bgd = None if bg is None else dev(bg)
+    r1, s1 = dev(rgb).requires_grad_(True), dev(sig).requires_grad_(True)
+    c, _, _, _ = ops.composite(r1, s1, dev(z), dev(d), bgd)
+    loss_ref = torch.nn.functional.mse_loss(c, dev(target))
+    loss_ref.backward()
+    scal = torch.zeros(2, device="cuda")
+    d_rgb, d_sigma, pred = ops.composite_mse_bwd(dev(rgb), dev(sig), dev(z), dev(d), bgd, dev(target), scal[0:1],
+                                                 amax_accum=scal[1:2], want_pred=True)
+    np.testing.assert_allclose(pred.cpu().numpy(), c.detach().cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(float(scal[0]), float(loss_ref), rtol=1e-5)
+    np.testing.assert_allclose(d_rgb.cpu().numpy(), r1.grad.cpu().numpy(), rtol=1e-5, atol=1e-10)
+    ref = s1.grad.cpu().numpy()
+    assert np.max(np.abs(d_sigma.cpu().numpy() - ref) / (np.abs(ref).max(axis=1, keepdims=True) + 1e-20)) < 2e-5
+    g_out = torch.cat([(r1.grad * r1 * (1 - r1)).detach().abs().flatten(), (s1.grad * (s1 > 0)).detach().abs().flatten()])
+    np.testing.assert_allclose(float(scal[1]), float(g_out.max()), rtol=1e-4)
+
+
 # ------------------------------------------------------------------ a6
 def bf16_decoder(params, pts, dirs):
     """The oracle decoder with the product's numerics: bf16 weights/activations, fp32 accumulate."""

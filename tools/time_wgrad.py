@@ -26,11 +26,6 @@ for dbg in (0, 1, 2, 3):
     ms = t()
     print(f"debug={dbg}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s", flush=True)
 ops._lib.set_option("wgrad_debug", 0)
-for ovh in (49152, 65536, 98304, 131072, 262144, 1048576):
-    ops._lib.set_option("wgrad_overhead", ovh); print('ovh', ovh, f'{t():.3f} ms', flush=True)
-for kind, nb in ():
-    ops._lib.set_option("wgrad_only", kind)
-    for dbg in (0, 1, 2):
-        ops._lib.set_option("wgrad_debug", dbg)
-        ms = t()
-        print(f"kind {kind} debug={dbg}: {ms:.3f} ms  {nb*1024*8192e-9/ms*1e3:.0f} GB/s", flush=True)
+for bw, fixed in ((192, 400), (128, 400), (256, 400), (384, 400), (192, 0), (192, 1000), (192, 2000), (100000, 400), (100000, 0), (96, 400)):
+    ops._lib.set_option("wgrad_bw_x16", bw); ops._lib.set_option("wgrad_fixed", fixed)
+    print(f"bw_x16 {bw} fixed {fixed}: {t():.3f} ms", flush=True)

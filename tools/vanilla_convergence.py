@@ -1,3 +1,5 @@
+"""PSNR-vs-steps of the vanilla engine on the synthetic scene (development aid); argument `bf16` selects the
+compiler-scheduled kernels with bf16 training images, default = asm-stream kernels with 8-bit images."""
 import os
 import sys, numpy as np, torch, tempfile, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -6,6 +8,10 @@ from project_nerf_amd.engine import VanillaNerfEngine
 root = write_synthetic_scene(tempfile.mkdtemp() + "/scene", n_train=20, n_test=2, size=100)
 ds = BlenderDataset(root, "train", 1, True, 1.0).to("cuda")
 test = BlenderDataset(root, "test", 1, True, 1.0)
+from project_nerf_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1] == "bf16":      # compiler-scheduled family: bf16 training images (A/B reference)
+    _lib.set_option("chain_legacy", 1)
+print("training images:", "bf16 (compiler-scheduled kernels)" if _lib.get_option("chain_legacy") else "8-bit (asm-stream kernels)")
 eng = VanillaNerfEngine(seed=0, lr=5e-4)
 torch.manual_seed(0)
 o_t, d_t, tgt = test.get_image_rays(0, "cuda")
