@@ -3,7 +3,8 @@
 Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 
 Imports the read-only reference at /root/reference (pure-PyTorch CPU half; the
-tinycudann half is not importable offline) and stores inputs + expected outputs
+tinycudann half is not importable offline -- g13 runs the reference's instant GLUE around
+the stand-in tests/golden/tinycudann_shim.py) and stores inputs + expected outputs
 as small ``.npz`` files next to this script.  The reference never travels to
 the GPU box; these vectors do.  Only data is stored here (SURVEY.md section 8c,
 G1-G8, G11).
@@ -253,6 +254,79 @@ def g12_part1():
     save("g12_part1", coords=coords, rgb=rgb, **{"w:" + k: v for k, v in model.state_dict().items()})
 
 
+def instant_test_params(n_table):
+    """Deterministic parameters of the instant goldens (the same formulas rebuild them in the tests, so the
+    131,072-float table need not be stored): table = 0.5 sin(0.37 i + 0.11 (i mod 7)); nets: seeded uniform."""
+    i = torch.arange(n_table, dtype=torch.float64)
+    return (0.5 * torch.sin(0.37 * i + 0.11 * (i % 7))).float()
+
+
+def g13_instant_glue():
+    """The reference's own instant GLUE around a stand-in tinycudann (tests/golden/tinycudann_shim.py):
+    NeuralField('part2_instant').forward, masked render_rays (+ autograd of an MSE loss), DensityGrid.update."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tinycudann", os.path.join(HERE, "tinycudann_shim.py"))
+    shim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shim)
+    sys.modules["tinycudann"] = shim
+    cfg = {"mode": "part2_instant", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 12,
+           "base_resolution": 16, "per_level_scale": 1.5, "scene_bound": 1.5, "L_embed_dir": 4, "hidden_dim": 64}
+    torch.manual_seed(13)
+    model = NeuralField(cfg)
+    assert sorted(model.state_dict()) == ["decoder.color_net.params", "decoder.sigma_net.params",
+                                          "dir_representation.freq_bands", "representation.encoding.params"]
+    with torch.no_grad():
+        t = model.representation.encoding.params
+        t.copy_(instant_test_params(t.numel()))
+        # visible densities: only the density row of the sigma head is enlarged (h0 - 5 reaches positive
+        # values); the other 15 geometry channels and the colour net keep their initial scale
+        model.decoder.sigma_net.params[:2048].mul_(1.5)
+        model.decoder.sigma_net.params[2048:2048 + 64].mul_(24.0)
+    gen = torch.Generator().manual_seed(31)
+    # ---- field forward: points inside, on and outside the box (clamp path), unit directions
+    pts = (torch.rand(700, 3, generator=gen) - 0.5) * 3.3
+    pts[:4] = torch.tensor([[1.5, -1.5, 0.0], [-1.5, 1.5, 1.5], [1.6, 0.0, -1.7], [0.0, 0.0, 0.0]])
+    dirs = torch.nn.functional.normalize(torch.randn(700, 3, generator=gen), dim=-1)
+    with torch.no_grad():
+        rgb, sigma = model(pts, dirs)
+        x_enc = model.representation(pts)
+    # ---- masked render_rays + MSE backward through the reference's scatter
+    o, d = synth_rays(160, gen)
+    u = torch.rand(160, 64, generator=gen)
+    target = torch.rand(160, 3, generator=gen)
+    grid = DensityGrid(resolution=64, bound=1.5, threshold=0.01)
+    ax = torch.linspace(-1.5, 1.5, 64)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    grid.binary_grid = (gx ** 2 + gy ** 2 + gz ** 2) < 1.1 ** 2
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    with torch.no_grad():
+        c0, dep0, acc0 = render_rays(model, o, d, 2.0, 6.0, 64, False, density_grid=grid, bg_color=bg)
+    import src.renderer as R
+    orig = torch.rand
+    torch.rand = lambda *a, **k: u.clone()                # the reference draws its jitter with torch.rand
+    try:
+        c1, dep1, acc1 = render_rays(model, o, d, 2.0, 6.0, 64, True, density_grid=grid, bg_color=bg)
+    finally:
+        torch.rand = orig
+    loss = torch.nn.functional.mse_loss(c1, target)
+    model.zero_grad()
+    loss.backward()
+    g_table = model.representation.encoding.params.grad
+    nz = torch.nonzero(g_table).flatten()
+    # ---- DensityGrid.update around the instant field (eval mode, zero view directions)
+    model.eval()
+    dg = DensityGrid(resolution=32, bound=1.5, threshold=0.05)
+    ratio = dg.update(model, device="cpu")
+    save("g13_instant_glue", sigma_net=model.decoder.sigma_net.params, color_net=model.decoder.color_net.params,
+         table_probe=model.representation.encoding.params[::4099], pts=pts, dirs=dirs, rgb=rgb, sigma=sigma, x_enc=x_enc,
+         rays_o=o, rays_d=d, u=u, target=target, bg=bg, radius=np.float32(1.1),
+         rgb_plain=c0, depth_plain=dep0, acc_plain=acc0, rgb_jitter=c1, depth_jitter=dep1, acc_jitter=acc1, loss=loss,
+         g_sigma_net=model.decoder.sigma_net.params.grad, g_color_net=model.decoder.color_net.params.grad,
+         g_table_index=nz[::7], g_table_value=g_table[nz[::7]], g_table_norm=g_table.norm(), g_table_nonzero=np.int64(nz.numel()),
+         grid=dg.grid, binary=dg.binary_grid, ratio=np.float64(ratio))
+    del sys.modules["tinycudann"]
+
+
 def g11_psnr():
     mse = np.array([1e-4, 3.3e-3, 0.02, 0.25])
     save("g11_psnr", mse=mse, psnr=np.array([compute_psnr(m) for m in mse]))
@@ -278,3 +352,4 @@ if __name__ == "__main__":
     g10_optim()
     g11_psnr()
     g12_part1()
+    g13_instant_glue()

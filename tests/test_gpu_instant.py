@@ -269,3 +269,96 @@ def test_instant_engine_trains_and_renders(tmp_path):
     img = eng.render_image(o, d, 64)
     psnr = -10 * np.log10(float(((img - tgt) ** 2).mean()))
     assert psnr > 18.0, psnr
+
+
+# ------------------------------------------------------------------ glue pinned by the reference's own code
+def _glue_model():
+    """This build's NeuralField('part2_instant') carrying the parameters of golden g13 (the reference's
+    NeuralField around the stand-in tinycudann of tests/golden/tinycudann_shim.py)."""
+    from conftest import golden
+    from src.core import NeuralField
+    g = golden("g13_instant_glue")
+    cfg = {"mode": "part2_instant", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 12,
+           "base_resolution": 16, "per_level_scale": 1.5, "scene_bound": 1.5, "L_embed_dir": 4, "hidden_dim": 64}
+    model = NeuralField(cfg)
+    n_table = model.representation.encoding.params.numel()
+    i = torch.arange(n_table, dtype=torch.float64)
+    table = (0.5 * torch.sin(0.37 * i + 0.11 * (i % 7))).float()      # tests/golden/make_golden.py::instant_test_params
+    np.testing.assert_array_equal(table[::4099].numpy(), g["table_probe"])
+    sd = model.state_dict()
+    assert sorted(sd) == ["decoder.color_net.params", "decoder.sigma_net.params", "dir_representation.freq_bands",
+                          "representation.encoding.params"]          # the reference's checkpoint keys
+    sd["representation.encoding.params"] = table
+    sd["decoder.sigma_net.params"] = torch.from_numpy(g["sigma_net"])
+    sd["decoder.color_net.params"] = torch.from_numpy(g["color_net"])
+    model.load_state_dict(sd)
+    return model.cuda(), g
+
+
+def test_instant_field_glue_vs_reference_golden():
+    """NeuralField('part2_instant').forward against the reference's own forward (src/core.py:57-77, 354-359;
+    src/embeddings.py:75-89 normalise + clamp; src/decoders.py:136-162 softplus(h0 - 5), cat([h16, d_enc]))."""
+    model, g = _glue_model()
+    pts, dirs = torch.from_numpy(g["pts"]).cuda(), torch.from_numpy(g["dirs"]).cuda()
+    with torch.no_grad():
+        x_enc = model.representation(pts)
+        rgb, sigma = model(pts, dirs)
+    np.testing.assert_allclose(x_enc.cpu().numpy(), g["x_enc"], rtol=1e-5, atol=1e-6)     # incl. the clamped outside points
+    assert rgb.shape == (700, 3) and sigma.shape == (700, 1)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb"], atol=4e-2)                   # bf16 MFMA vs fp32 reference
+    ref = g["sigma"]
+    np.testing.assert_allclose(sigma.cpu().numpy(), ref, rtol=0.1, atol=2e-2 * ref.max())
+
+
+def test_instant_masked_render_and_gradients_vs_reference_golden():
+    """render_rays(model, ..., density_grid=grid, bg_color=bg) -- occupancy mask, compaction, field query,
+    scatter, compositing (src/renderer.py:303-343) -- and the gradients of an MSE loss through all of it,
+    against the reference's own outputs and autograd."""
+    from src.renderer import DensityGrid, render_rays
+    model, g = _glue_model()
+    grid = DensityGrid(resolution=64, bound=1.5, threshold=0.01).cuda()
+    ax = torch.linspace(-1.5, 1.5, 64)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    grid.binary_grid = ((gx ** 2 + gy ** 2 + gz ** 2) < float(g["radius"]) ** 2).cuda()
+    o, d, bg = (torch.from_numpy(g[k]).cuda() for k in ("rays_o", "rays_d", "bg"))
+    with torch.no_grad():
+        c, dep, acc = render_rays(model, o, d, 2.0, 6.0, 64, False, density_grid=grid, bg_color=bg)
+    np.testing.assert_allclose(c.cpu().numpy(), g["rgb_plain"], atol=2e-2)
+    np.testing.assert_allclose(acc.cpu().numpy(), g["acc_plain"], atol=2e-2)
+    np.testing.assert_allclose(dep.cpu().numpy(), g["depth_plain"], atol=6e-2)
+    u = torch.from_numpy(g["u"]).cuda()
+    orig = torch.rand
+    torch.rand = lambda *a, **k: u.clone()                    # render_rays draws its jitter with torch.rand
+    try:
+        c, dep, acc = render_rays(model, o, d, 2.0, 6.0, 64, True, density_grid=grid, bg_color=bg)
+    finally:
+        torch.rand = orig
+    np.testing.assert_allclose(c.detach().cpu().numpy(), g["rgb_jitter"], atol=2e-2)
+    loss = torch.nn.functional.mse_loss(c, torch.from_numpy(g["target"]).cuda())
+    assert abs(loss.item() - float(g["loss"])) < 3e-3
+    model.zero_grad()
+    loss.backward()
+    for name, got, want in (("sigma_net", model.decoder.sigma_net.params.grad.cpu(), torch.from_numpy(g["g_sigma_net"])),
+                            ("color_net", model.decoder.color_net.params.grad.cpu(), torch.from_numpy(g["g_color_net"])),
+                            ("table", model.representation.encoding.params.grad.cpu()[torch.from_numpy(g["g_table_index"])],
+                             torch.from_numpy(g["g_table_value"]))):
+        rel = float((got - want).norm() / (want.norm() + 1e-20))
+        cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-30))
+        assert cos > 0.98 and rel < 0.2, (name, rel, cos)      # bf16 chain vs the reference's fp32 autograd
+    tg = model.representation.encoding.params.grad
+    assert abs(float(tg.norm()) - float(g["g_table_norm"])) < 0.1 * float(g["g_table_norm"])
+
+
+def test_density_grid_update_around_instant_field_vs_reference_golden():
+    """DensityGrid.update(model) with the instant field in eval mode, zero view directions, 2^18-point
+    batches (src/renderer.py:35-132) against the reference's result."""
+    from src.renderer import DensityGrid
+    model, g = _glue_model()
+    model.eval()
+    dg = DensityGrid(resolution=32, bound=1.5, threshold=0.05).cuda()
+    ratio = dg.update(model, device="cuda")
+    ref = g["grid"]
+    np.testing.assert_allclose(dg.grid.cpu().numpy(), ref, rtol=0.1, atol=2e-2 * ref.max())
+    flips = int((dg.binary_grid.cpu().numpy() != g["binary"]).sum())
+    assert flips <= 0.01 * g["binary"].sum(), flips            # cells whose sigma sits at the threshold (bf16)
+    assert abs(ratio - float(g["ratio"])) < 0.005

@@ -1,0 +1,196 @@
+"""The north-star tolerance measured on TRAINED weights, and configs[1] at full size (pytest -m gpu).
+
+north_star: "Output matches the reference's own renderer on identical rays/poses within a stated fp
+tolerance (PSNR delta <= 0.05 dB on test views)".  Random-init weights say little about that: trained
+fields have sharp densities, where the bf16 rounding of the last hidden layer moves alpha most.  Here the
+engines are trained on the synthetic Blender-format scene (NeRF-Synthetic itself is not available offline),
+then the SAME weights are rendered twice -- HIP kernels (bf16 MFMA) and the fp32 CPU oracle (a restatement
+of reference src/renderer.py:387-418, pinned by the reference's own goldens) -- and both PSNRs against the
+ground-truth views are compared."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import ROOT, golden
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def psnr(img, tgt):
+    return -10.0 * np.log10(float(((img.clamp(0, 1) - tgt) ** 2).mean()))
+
+
+@pytest.fixture(scope="module")
+def scene(tmp_path_factory):
+    from src.dataset import write_synthetic_scene
+    return write_synthetic_scene(str(tmp_path_factory.mktemp("scene") / "s"), n_train=16, n_test=2, size=64)
+
+
+@pytest.fixture(scope="module")
+def trained_vanilla(scene):
+    """VanillaNerfEngine after 1500 steps of 4096 rays x 64 samples on the synthetic scene (~27 dB)."""
+    from src.dataset import BlenderDataset
+    from project_nerf_amd.engine import VanillaNerfEngine
+    ds = BlenderDataset(scene, "train", 1, True, 1.0).to("cuda")
+    # The reference's density head is a bare ReLU (src/decoders.py:78): on a mostly-white scene the first
+    # steps can push every density below zero, after which all gradients are exactly zero ("dead sigma").
+    # Which way a run goes is decided by rounding-level noise (measured here: 4 of 10 runs of the bf16
+    # kernels and 6 of 10 of the 8-bit-image kernels die within 100 steps, same seed, same box), so the
+    # fixture restarts from the next seed until the loss has left the all-white plateau.
+    for seed in range(8):
+        eng = VanillaNerfEngine(seed=seed, lr=5e-4)
+        torch.manual_seed(seed)
+        for step in range(1500):
+            o, d, rgba = ds.sample_random_rays(4096, "cuda")
+            loss = eng.train_step(o, d, rgba[:, :3] * rgba[:, 3:4] + (1 - rgba[:, 3:4]), 64)
+            if step == 150 and float(loss) > 0.1:
+                break
+        else:
+            return eng, {k[len("decoder."):]: v.cpu() for k, v in eng.state_dict().items()}
+    pytest.fail("no seed escaped the dead-density plateau")
+
+
+def test_vanilla_trained_weights_psnr_delta_vs_fp32_oracle(scene, trained_vanilla):
+    from src.dataset import BlenderDataset
+    test = BlenderDataset(scene, "test", 1, True, 1.0)
+    eng, params = trained_vanilla
+    field = lambda p, v: O.nerf_field(params, p, v)
+    deltas, worst = [], 0.0
+    for view in range(len(test)):
+        o, d, tgt = test.get_image_rays(view, "cpu")
+        hip = eng.render_image(o.cuda(), d.cuda(), 64, chunk=4096).cpu()
+        with torch.no_grad():
+            ref = O.render_image(field, o, d, 2.0, 6.0, 64, 4096, True)
+        p_hip, p_ref = psnr(hip, tgt), psnr(ref, tgt)
+        assert p_ref > 24.0, p_ref                       # the field really is trained (sharp densities)
+        deltas.append(p_hip - p_ref)
+        worst = max(worst, float((hip - ref).abs().max()))
+    print(f"vanilla trained: PSNR(hip) - PSNR(fp32 oracle) = {deltas} dB, max |d rgb| = {worst:.4f}")
+    assert max(abs(x) for x in deltas) <= 0.05, deltas      # the north-star tolerance
+    assert worst < 0.06, worst
+
+
+def test_instant_trained_weights_psnr_delta_vs_fp32_oracle(scene):
+    from src.dataset import BlenderDataset
+    from project_nerf_amd.engine import InstantNgpEngine
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    cfg["train_iters"] = 1500
+    ds = BlenderDataset(scene, "train", 1, True, 1.0).to("cuda")
+    test = BlenderDataset(scene, "test", 1, True, 1.0)
+    eng = InstantNgpEngine(cfg, seed=0)
+    torch.manual_seed(0)
+    for step in range(1, 1501):
+        o, d, rgba = ds.sample_random_rays(8192, "cuda")
+        eng.train_step(o, d, rgba[:, :3] * rgba[:, 3:4] + (1 - rgba[:, 3:4]), 64)
+        if step >= 256 and step % 128 == 0 and step < 1350:
+            eng.update_grid()
+    lv = O.hash_grid_levels(16, 19, 16, 1.5)
+    table, net = eng.table.view(-1, 2).cpu(), eng.net.cpu()
+    sw = [net[0:2048].view(64, 32), net[2048:3072].view(16, 64)]
+    cw = [net[3072:6144].view(64, 48)[:, :43], net[6144:10240].view(64, 64), net[10240:11264].view(16, 64)[:3]]
+
+    def field(p, v):
+        rgb, sigma = O.instant_decoder(sw, cw, O.hash_encode(lv, table, O.hash_normalise(p, eng.bound)), O.fourier_encode(v, 4))
+        return rgb, sigma
+
+    grid = eng.binary_grid.cpu()
+    deltas, worst = [], 0.0
+    for view in range(len(test)):
+        o, d, tgt = test.get_image_rays(view, "cpu")
+        hip = eng.render_image(o.cuda(), d.cuda(), 64).cpu()
+        with torch.no_grad():
+            ref = O.render_rays(field, o.reshape(-1, 3), d.reshape(-1, 3), 2.0, 6.0, 64, False, binary_grid=grid,
+                                grid_bound=eng.bound)[0].view(*tgt.shape)
+        p_hip, p_ref = psnr(hip, tgt), psnr(ref, tgt)
+        assert p_ref > 21.0, p_ref                       # 16 views of 64 x 64 pixels: ~23 dB on unseen views
+        deltas.append(p_hip - p_ref)
+        worst = max(worst, float((hip - ref).abs().max()))
+    print(f"instant trained: PSNR(hip) - PSNR(fp32 oracle) = {deltas} dB, max |d rgb| = {worst:.4f}")
+    assert max(abs(x) for x in deltas) <= 0.05, deltas
+    assert worst < 0.06, worst
+
+
+def _oracle_subset(params, rays_o, rays_d, idx, n_samples):
+    field = lambda p, v: O.nerf_field(params, p, v)
+    with torch.no_grad():
+        return O.render_rays(field, rays_o[idx], rays_d[idx], 2.0, 6.0, n_samples, False)
+
+
+def test_full_size_800x800_render_vs_oracle_on_strided_rays(trained_vanilla):
+    """BASELINE configs[1] at its full size: one 800 x 800 x 128 render (640,000 rays, ten 65,536-ray chunks)
+    of the TRAINED field through engine.render_image, checked on every 2003rd ray against the fp32 oracle
+    with the same weights."""
+    from src.dataset import look_at_pose
+    eng, params = trained_vanilla
+    H = W = 800
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
+    c2w = torch.tensor(look_at_pose(4.0311 * np.array([0.6, 0.5, 0.62])), dtype=torch.float32)
+    o, d = O.camera_rays(c2w, H, W, focal)
+    img = eng.render_image(o.cuda(), d.cuda(), 128).cpu()
+    assert img.shape == (H, W, 3) and torch.isfinite(img).all()
+    idx = torch.arange(0, H * W, 2003)
+    ref, _, _ = _oracle_subset(params, o.reshape(-1, 3), d.reshape(-1, 3), idx, 128)
+    err = (img.reshape(-1, 3)[idx] - ref).abs()
+    print(f"800x800x128: max |d rgb| on {idx.numel()} rays = {float(err.max()):.4f}, mean {float(err.mean()):.5f}")
+    assert float(err.max()) < 4e-2 and float(err.mean()) < 2e-3
+    # the row-band split of the data-parallel evaluation reproduces the single-GPU image bit for bit
+    band = eng.render_image(o[300:400].cuda(), d[300:400].cuda(), 128).cpu()
+    assert torch.equal(band, img[300:400])
+
+
+def test_full_size_64_coarse_128_fine_render_vs_oracle_on_strided_rays(trained_vanilla):
+    """The "64 coarse + 128 fine" render of BASELINE configs[1] (opt-in extension; the reference has one
+    stratified pass only) at 800 x 800 with the trained field, against the same pipeline assembled from
+    oracle pieces."""
+    from src.dataset import look_at_pose
+    eng, params = trained_vanilla
+    H = W = 800
+    focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
+    c2w = torch.tensor(look_at_pose(4.0311 * np.array([-0.5, 0.6, 0.62])), dtype=torch.float32)
+    o, d = O.camera_rays(c2w, H, W, focal)
+    img = eng.render_image(o.cuda(), d.cuda(), 64, n_fine=128).cpu()
+    assert img.shape == (H, W, 3) and torch.isfinite(img).all()
+    idx = torch.arange(0, H * W, 4001)
+    oo, dd = o.reshape(-1, 3)[idx], d.reshape(-1, 3)[idx]
+    field = lambda p, v: O.nerf_field(params, p, v)
+    n = idx.numel()
+    with torch.no_grad():
+        z = O.stratified_depths(2.0, 6.0, 64, n, False)
+        pts, dirs = O.ray_points(oo, dd, z)
+        rgb, sig = field(pts, dirs)
+        w = O.composite(rgb.view(n, 64, 3), sig.view(n, 64), z, dd, torch.ones(3), return_weights=True)[3]
+        z_all = O.sample_pdf(z, w, 128)
+        pts, dirs = O.ray_points(oo, dd, z_all)
+        rgb, sig = field(pts, dirs)
+        ref = O.composite(rgb.view(n, 192, 3), sig.view(n, 192), z_all, dd, torch.ones(3))[0]
+    err = (img.reshape(-1, 3)[idx] - ref).abs()
+    print(f"800x800 64c+128f: max |d rgb| on {n} rays = {float(err.max()):.4f}, mean {float(err.mean()):.5f}")
+    # the fine depths are resampled from bf16-field weights: a ray whose inverse-CDF draw lands in another
+    # interval moves more than one that does not, hence a percentile bound next to the maximum
+    assert float(torch.quantile(err.flatten(), 0.99)) < 2e-2 and float(err.max()) < 0.1
+
+
+def test_dynamic_grid_running_max_vs_reference_golden():
+    """ops.grid_threshold(prev=..., decay) -- the running-max branch of DensityGrid.update for dynamic
+    fields, grid = max(grid * decay, current) (reference src/renderer.py:122-125) -- driven through the
+    reference's own two-update sequence (t = 0, then t = 1; tests/golden/make_golden.py::g7_grid)."""
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import ops
+    g = golden("g7_grid_dynamic_res32")
+    decay = float(g["decay"])
+    pts = ops.grid_lattice(1.5, 32, "cuda")
+    grid = torch.zeros(32, 32, 32, device="cuda")
+    ratios = []
+    for t in (0.0, 1.0):
+        # the golden's field on the CPU in fp32 (bit-identical inputs to the kernel under test)
+        x = pts.cpu() + torch.tensor([[t]]) * 0.3
+        cur = (5.0 * torch.exp(-((x - torch.tensor([0.2, -0.1, 0.3])) ** 2).sum(-1) / 0.18)).view(32, 32, 32).cuda()
+        binary, ratio = ops.grid_threshold(cur, 0.12, prev=grid, decay=decay)      # updates `grid` in place
+        ratios.append(ratio)
+    np.testing.assert_allclose(grid.cpu().numpy(), g["grid"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(binary.cpu().numpy(), g["binary"])
+    np.testing.assert_allclose(ratios, g["ratios"], atol=1e-9)

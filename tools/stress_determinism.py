@@ -1,0 +1,57 @@
+"""Race screen for the training kernels (development aid): the same step is recomputed many times on fixed
+inputs; the forward's stash image and the dgrad workspace must be BIT-identical across runs (no atomics
+write them), the weight gradients identical up to the order of float atomics."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import project_nerf_amd  # noqa
+from project_nerf_amd import ops
+from project_nerf_amd.engine import default_init
+
+R, S = int(os.environ.get("R", 4096)), 64
+n = R * S
+torch.manual_seed(1)
+packed = ops.mlp_pack((default_init(0) * 1.5).cuda())
+o = torch.randn(R, 3, device="cuda"); o = o / o.norm(dim=-1, keepdim=True) * 4.03
+d = torch.nn.functional.normalize(-o + 0.4 * torch.randn(R, 3, device="cuda"), dim=-1)
+u = torch.rand(R, S, device="cuda")
+target = torch.rand(R, 3, device="cuda")
+bg = torch.ones(3, device="cuda")
+z = ops.sample_rays(o, d, 2.0, 6.0, S, u=u)
+stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
+ws = torch.empty(ops.mlp_bwd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+grads = torch.empty(ops.MLP_PARAM_COUNT, device="cuda")
+ref = None
+bad = {"stash": 0, "ws": 0, "rgb": 0, "grads": 0}
+worst = 0.0
+for it in range(int(os.environ.get("ITERS", 300))):
+    stash.fill_(0x5A if it % 2 else 0xA5); ws.fill_(0x3C if it % 2 else 0xC3)       # poison: stale bytes cannot pass for fresh ones
+    scal = torch.zeros(2, device="cuda")
+    rgb, sigma = ops.mlp_fwd(packed, o, d, z, stash)
+    d_rgb, d_sigma, _ = ops.composite_mse_bwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, bg, target, scal[0:1], amax_accum=scal[1:2])
+    ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb.view(n, 3), d_sigma.view(n), grads, ws, amax=scal[1:2])
+    torch.cuda.synchronize()
+    cur = (stash.clone(), ws.clone(), rgb.clone(), grads.clone())
+    if ref is None:
+        ref = cur
+        continue
+    if not torch.equal(cur[0], ref[0]):
+        bad["stash"] += 1
+        if bad["stash"] <= 3:
+            idx = torch.nonzero(cur[0] != ref[0]).flatten()
+            print(f"it {it}: stash differs in {idx.numel()} bytes, first at {int(idx[0])}, last {int(idx[-1])}")
+    if not torch.equal(cur[1], ref[1]):
+        bad["ws"] += 1
+        if bad["ws"] <= 3:
+            idx = torch.nonzero(cur[1] != ref[1]).flatten()
+            print(f"it {it}: workspace differs in {idx.numel()} bytes, first at {int(idx[0])}, last {int(idx[-1])}")
+    if not torch.equal(cur[2], ref[2]):
+        bad["rgb"] += 1
+    rel = float((cur[3] - ref[3]).norm() / ref[3].norm())
+    worst = max(worst, rel)
+    if rel > 1e-4 or not torch.isfinite(cur[3]).all():
+        bad["grads"] += 1
+        if bad["grads"] <= 5:
+            print(f"it {it}: grads rel diff {rel:.3e}")
+print("mismatching runs:", bad, "worst grads rel diff", worst)
