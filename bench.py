@@ -4,15 +4,19 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one training step of the hot path on one batch of synthetic rays: 4096 rays x 64
-stratified samples (configs/part2.yaml.example: batch_size 4096, n_samples 64) through
-sample -> fused bf16-MFMA decoder fwd -> composite -> MSE -> composite bwd -> dgrad chain ->
-wgrad -> (RCCL all-reduce) -> Adam -> weight repack, inputs resident in HBM.  Rays shard across
-ranks (weak scaling: every rank owns its own 4096-ray batch; one gradient all-reduce per step).
-``value`` = rays/s summed over ranks.  The same run also times the 800x800, 128-samples/ray
-render (640,000 rays; FPS reported as ``render_fps``), each kernel of the step on its own with
-HIP events (``kernels``), the roofline of the dominant kernel, and -- on rank 0 at N=1 -- the
-CPU oracle on a bounded sample of the same step (``cpu_baseline``).
+A "step" is one training step of the hot path (reference run.py:312-338) on one batch of synthetic
+rays: 4096 rays x 64 stratified samples (configs/part2.yaml.example: batch_size 4096, n_samples 64):
+batch sampling from 100 GPU-resident 800x800 frames (one index draw + nerf_gather_batch: rays and
+composited targets) -> jitter draw + sample depths -> fused bf16-MFMA decoder fwd (+ 8-bit stash) ->
+composite + MSE + backward (one kernel) -> dgrad chain -> wgrad -> (RCCL all-reduce) -> Adam -> weight
+repack, inputs resident in HBM.  Rays shard across ranks (weak scaling: every rank owns its own
+4096-ray batch; one gradient all-reduce per step).  ``value`` = rays/s summed over ranks.  The same run
+also reports: the 800x800, 128-samples/ray render (``render_fps``); every phase of the step timed INSIDE
+the step with HIP events on the launch stream (``kernels_in_step``, what rocprofv3's per-kernel averages
+in profiles/ show) and each kernel launched back to back on its own (``kernels``); the roofline of the
+dominant kernel from its in-step time; the step against the MFMA roof SURVEY 8(d) binds configs[1] to
+(``step_frac_of_binding_roofline``); on rank 0 at N=1 the CPU oracle on a bounded sample of the same step
+(``cpu_baseline``) and a shortened Instant-NGP run (configs[2]: ``instant``).
 """
 import argparse
 import json
@@ -82,24 +86,28 @@ def cpu_baseline(rays, samples, threads):
             "sample": f"train step on {rays} rays x {samples} samples (1 warm-up + 2 timed), oracle/nerf_oracle.py fp32"}
 
 
-def bench_instant(args, device):
-    """Secondary line: Instant-NGP variant (BASELINE.json configs[2]) on the flat-parameter engine
-    (same kernels as NeuralField + DensityGrid + render_rays + AdamW), synthetic Blender-format scene:
-    wall time to PSNR, train rays/s in steady state (occupancy grid active), 800x800 render FPS."""
-    import tempfile
+def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=False):
+    """Instant-NGP variant (BASELINE.json configs[2]) on the flat-parameter engine (same kernels as
+    NeuralField + DensityGrid + render_rays + AdamW): analytic scene rendered at 800 x 800 on the GPU
+    (ground truth only), wall time to PSNR, steady-state train rays/s with the occupancy grid active,
+    per-kernel times and rooflines, 800 x 800 render FPS at the trained field."""
     import numpy as np
     import yaml
-    from src.dataset import BlenderDataset, look_at_pose, write_synthetic_scene
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
-    root = write_synthetic_scene(tempfile.mkdtemp() + "/scene", n_train=40, n_test=4, size=200)
-    ds = BlenderDataset(root, "train", 1, True, 1.0).to(device)
-    test = BlenderDataset(root, "test", 1, True, 1.0)
+    from src.dataset import BlenderDataset, SYNTHETIC_CAMERA_ANGLE, look_at_pose, synthetic_frames
     from project_nerf_amd import ops
     from project_nerf_amd.engine import InstantNgpEngine
-    iters, batch, S = 1000, 16384, 128
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    batch, S = 16384, 128
     cfg["train_iters"] = iters
+    t_gen = time.perf_counter()
+    images, poses = synthetic_frames(n_train + 2, size, device, n_samples=192)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    ds = BlenderDataset.from_tensors(images[:n_train], poses[:n_train], SYNTHETIC_CAMERA_ANGLE)
+    test = BlenderDataset.from_tensors(images[n_train:], poses[n_train:], SYNTHETIC_CAMERA_ANGLE)
     torch.manual_seed(0)
     eng = InstantNgpEngine(cfg, device=str(device), seed=0)
+    bg = eng.bg
 
     def psnr():
         vals = []
@@ -110,8 +118,7 @@ def bench_instant(args, device):
         return float(np.mean(vals))
 
     def step():
-        o, d, rgba = ds.sample_random_rays(batch, device)
-        target = rgba[:, :3] * rgba[:, 3:4] + (1 - rgba[:, 3:4])
+        o, d, target = ds.sample_batch(batch, bg)
         return eng.train_step(o, d, target, S)
 
     torch.cuda.synchronize()
@@ -122,7 +129,7 @@ def bench_instant(args, device):
         interval = 32 if it < iters * 0.1 else (128 if it < iters * 0.5 else 512)      # run.py:636-641
         if it < iters * 0.9 and it >= 256 and it % interval == 0:
             active = eng.update_grid()
-        if it in (300, 600, 1000):
+        if it in (300, 600, iters):
             torch.cuda.synchronize()
             curve.append({"step": it, "train_seconds": time.perf_counter() - t0, "test_psnr_db": psnr()})
     torch.cuda.synchronize()
@@ -134,7 +141,7 @@ def bench_instant(args, device):
     # ---- per-kernel timings of one steady-state batch (rows a7 / a8 of SURVEY 8) ----
     lib = ops._lib.load()
     P = lambda t: t.data_ptr()
-    o, d, _ = ds.sample_random_rays(batch, device)
+    o, d, _ = ds.sample_batch(batch, bg)
     uu = torch.rand(batch, S, device=device)
     z, slots, pts, dirs = ops.sample_compact(o, d, eng.near, eng.far, S, eng.binary_grid, eng.bound, u=uu)
     n = pts.shape[0]
@@ -144,6 +151,7 @@ def bench_instant(args, device):
     d_rgb, d_sigma, d_feat = torch.randn_like(rgb), torch.randn_like(sigma), torch.empty(n, 2 * L, device=device)
     stv = ops._stream()
     k = {
+        "batch_sampling": event_ms(lambda: ds.sample_batch(batch, bg), 20),
         "sample_compact": event_ms(lambda: ops.sample_compact(o, d, eng.near, eng.far, S, eng.binary_grid, eng.bound, u=uu), 20),
         "hash_fwd": event_ms(lambda: ops.hash_encode_fwd(pts, eng.table.view(-1, 2), eng.levels, eng.bound, want_f32=False, out_nat=ws), 20),
         "imlp_fwd": event_ms(lambda: lib.nerf_imlp_fwd(P(eng.packed), P(ws), P(dirs), n, P(rgb), P(sigma), 1, stv), 20),
@@ -162,8 +170,7 @@ def bench_instant(args, device):
         "hash_fwd": {"bound": "hbm", "kernel": "hash_fwd_kernel", "achieved": (gather + n * (12 + 2 * L * 2)) / k["hash_fwd"] * 1e-6,
                      "note": "table gathers (mostly L2 / Infinity Cache hits: the 52 MB table is re-read by every batch)"},
         "hash_bwd": {"bound": "hbm", "kernel": "hash_bwd_kernel", "achieved": (gather + n * (12 + 2 * L * 4)) / k["hash_bwd"] * 1e-6,
-                     "note": "fp32 atomics, 4 lanes per (point, level) so that one instruction carries 16 adjacent bytes per point: "
-                             "the chip retires ~21 G atomic LINE requests/s; levels <= 16384 entries reduced in LDS first"},
+                     "note": "fp32 atomics: the chip retires ~21 G atomic LINE requests/s (tools/probe/atomic_rate.hip)"},
         "tv_clip_adamw(table)": {"bound": "hbm", "kernel": "tv_normsq_kernel + adamw_clip_kernel",
                                  "achieved": n_tab * 4 * 9 / k["tv_clip_adamw(table)"] * 1e-6},
         "imlp_fwd": {"bound": "hbm", "kernel": "imlp_fwd_kernel<true>", "achieved": n * (64 + 12 + 16 + 2 * (64 + 16 + 64 + 64 + 48)) / k["imlp_fwd"] * 1e-6,
@@ -172,7 +179,7 @@ def bench_instant(args, device):
     for v in roof.values():
         v.update({"peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": v["achieved"] / HBM_PEAK_GBS, "traffic": None})
     H = W = 800
-    focal = 0.5 * W / np.tan(0.5 * 0.6911112070083618)
+    focal = 0.5 * W / np.tan(0.5 * SYNTHETIC_CAMERA_ANGLE)
     c2w = torch.tensor(look_at_pose(4.0311 * np.array([0.6, 0.5, 0.62])), dtype=torch.float32)
     j, i = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     dd = torch.stack([(i - W * .5) / focal, -(j - H * .5) / focal, -torch.ones_like(i)], -1).reshape(-1, 3).float() @ c2w[:3, :3].T
@@ -185,15 +192,35 @@ def bench_instant(args, device):
         eng.render_image(oo, dd, S)
     torch.cuda.synchronize()
     rt = (time.perf_counter() - t1) / args.render_frames
-    print(json.dumps({
+    out = {
         "metric": "train rays/sec + 800x800 render FPS, NeRF-Synthetic Lego; PSNR parity", "value": batch * args.steps / dt,
         "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": iters, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "Part 2 Instant-NGP (L16 F2 T2^19 hash grid + tiny MLPs, 128^3 occupancy grid), steady-state train step",
-                   "rays_per_gpu": batch, "samples_per_ray": S, "active_ratio": active, "scene": "synthetic 200x200 x 40 views"},
+                   "rays_per_gpu": batch, "samples_per_ray": S, "active_ratio": active,
+                   "scene": f"analytic scene, {n_train} training frames of {size}x{size} rendered on the GPU ({t_gen:.1f} s, not timed)"},
         "kernels": {kk: {"ms": v} for kk, v in k.items()}, "active_samples": n, "rooflines": roof,
         "render_fps": 1.0 / rt, "render_ms_per_frame": rt * 1e3, "psnr_curve": curve,
-        "reference_headline": "26+ dB in 5 min, 10+ FPS (RTX 4060 Laptop, Lego; README.md:12,136)"}))
+        "reference_headline": "26+ dB in 5 min, 10+ FPS (RTX 4060 Laptop, Lego; README.md:12,136)"}
+    if standalone:
+        print(json.dumps(out))
+    return out
+
+
+def bench_instant_dp(args, device, rank, world, dist):
+    raise SystemExit("bench.py --workload instant on several ranks: see InstantNgpEngine data-parallel path")
+
+
+def hemisphere_poses(n, seed):
+    import numpy as np
+    from src.dataset import look_at_pose
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        th, ph = rng.uniform(0, 2 * np.pi), rng.uniform(0.15, 1.2)
+        out.append(torch.tensor(look_at_pose(4.0311 * np.array([np.cos(th) * np.cos(ph), np.sin(th) * np.cos(ph), np.sin(ph)])),
+                                dtype=torch.float32))
+    return torch.stack(out, 0)
 
 
 def main():
@@ -206,9 +233,11 @@ def main():
     ap.add_argument("--render-samples", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--no-instant", action="store_true", help="skip the shortened Instant-NGP block of the default run")
     ap.add_argument("--render-frames", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=100, help="GPU-resident 800x800 training frames the batches are drawn from")
     ap.add_argument("--workload", choices=["vanilla", "instant"], default="vanilla",
-                    help="vanilla = BASELINE.json configs[1] (default, the judged line); instant = configs[2], secondary")
+                    help="vanilla = BASELINE.json configs[1] (default, the judged line); instant = configs[2] / configs[3]")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,16 +252,23 @@ def main():
     import project_nerf_amd  # noqa: F401
     from project_nerf_amd import ops, parallel
     from project_nerf_amd.engine import VanillaNerfEngine
-    if args.workload == "instant":
-        return bench_instant(args, device)
+    from src.dataset import BlenderDataset, SYNTHETIC_CAMERA_ANGLE
+    if args.workload == "instant" and world == 1:
+        return bench_instant(args, device, standalone=True)
     dist = None
     if world > 1:
         import torch.distributed as dist
         parallel.init_distributed("cuda")       # backend nccl == RCCL over xGMI
+    if args.workload == "instant":
+        return bench_instant_dp(args, device, rank, world, dist)
 
     eng = VanillaNerfEngine(seed=0, world_size=world, device=str(device))
     R, S = args.rays, args.samples
-    o, d, target = synth_rays(R, 100 + rank, device)
+    # synthetic data of the benchmark's shape: `frames` RGBA frames of 800 x 800 resident in HBM (uniform noise:
+    # the step's cost does not depend on the pixel values), cameras on the NeRF-Synthetic hemisphere
+    torch.manual_seed(100 + rank)
+    ds = BlenderDataset.from_tensors(torch.rand(args.frames, 800, 800, 4, device=device), hemisphere_poses(args.frames, 7).to(device),
+                                     SYNTHETIC_CAMERA_ANGLE)
     # the flat 2.38 MB gradient is all-reduced in two ranges, the first while the second is still being
     # computed (NERF_BENCH_SYNC_ALLREDUCE=1: one blocking collective after the backward pass instead)
     blocking = os.environ.get("NERF_BENCH_SYNC_ALLREDUCE") is not None
@@ -244,12 +280,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step(mark=None):
+        o, d, target = ds.sample_batch(R, eng.bg)                # batch sampling is part of the step (run.py:314-322)
+        if mark is not None:
+            mark("batch_sampling")
+        return eng.train_step(o, d, target, S, sync_grads=sync, sync_grads_async=sync_async, mark=mark)
+
     for _ in range(args.warmup):
-        eng.train_step(o, d, target, S, sync_grads=sync, sync_grads_async=sync_async)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = eng.train_step(o, d, target, S, sync_grads=sync, sync_grads_async=sync_async)
+        loss = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -264,23 +306,46 @@ def main():
         "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "Part 2 vanilla NeRF train step (L10/L4 Fourier, 8x256 skip-4 MLP, view 128)",
+        "config": {"workload": "Part 2 vanilla NeRF train step (L10/L4 Fourier, 8x256 skip-4 MLP, view 128), batch sampling included",
                    "rays_per_gpu": R, "samples_per_ray": S, "global_rays": R * world,
                    "parallelism": f"ray-dp{world}", "weights": "random init (seed 0)",
+                   "frames": f"{args.frames} x 800x800 RGBA resident in HBM (uniform noise)",
+                   "training_images": "8-bit (e4m3 layer inputs, e5m2 gradients); arithmetic bf16 MFMA, fp32 accumulate",
                    "render": f"800x800 x {args.render_samples} samples/ray"},
         "final_loss": float(loss.item()),
     }
 
     if rank == 0:
-        # ---- per-kernel timing with HIP events on the launch stream (torch's current stream) ----
         n = R * S
+        # ---- every phase timed INSIDE the step: a HIP event on the launch stream after each phase ----
+        phases = ["batch_sampling", "sample", "fwd", "loss", "dgrad", "wgrad", "adam+pack"]
+        acc = {p: 0.0 for p in phases}
+        reps = max(10, min(args.steps, 30))
+        for _ in range(reps):
+            evs = [("start", torch.cuda.Event(enable_timing=True))]
+            evs[0][1].record()
+
+            def mark(name):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append((name, e))
+            step(mark)
+            torch.cuda.synchronize()
+            for (_, e0), (name, e1) in zip(evs[:-1], evs[1:]):
+                acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
+        in_step = {p: acc[p] / reps for p in acc}
+        out["kernels_in_step"] = {p: {"ms": v} for p, v in in_step.items()}
+        out["kernels_in_step_note"] = ("HIP events on the launch stream between the phases of the timed step; "
+                                       "fwd = mlp_fwd_stream_kernel<true>, loss = composite_mse_bwd_kernel, dgrad = mlp_bwd_stream_kernel, "
+                                       "wgrad = memset + mlp_wgrad_kernel, sample = jitter draw + sample_rays_kernel")
+        # ---- the same kernels launched back to back on their own (warm caches) ----
+        o, d, target = ds.sample_batch(R, eng.bg)
         u = torch.rand(R, S, device=device)
         z = ops.sample_rays(o, d, 2.0, 6.0, S, u=u)
         stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device=device)
         rgb, sigma = ops.mlp_fwd(eng.packed, o, d, z, stash)
-        pred, _, _, _, _ = ops.composite_fwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg)
-        g_pred = (pred - target) * (2.0 / pred.numel())
-        d_rgb, d_sigma, _ = ops.composite_bwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg, None, g_pred, None, None, None)
+        scal = torch.zeros(2, device=device)
+        d_rgb, d_sigma, _ = ops.composite_mse_bwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg, target, scal[0:1], amax_accum=scal[1:2])
         ws = torch.empty(ops.mlp_bwd_workspace_bytes(n), dtype=torch.uint8, device=device)
         grads = torch.empty_like(eng.params)
         lib = ops._lib.load()
@@ -289,56 +354,63 @@ def main():
         k = {}
         k["mlp_fwd_train"] = event_ms(lambda: ops.mlp_fwd(eng.packed, o, d, z, stash), 20)
         k["mlp_fwd_infer"] = event_ms(lambda: ops.mlp_fwd(eng.packed, o, d, z), 20)
-        k["mlp_bwd_dgrad"] = event_ms(lambda: lib.nerf_mlp_bwd_dgrad(P(eng.packed), P(stash), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(ws), st), 20)
+        k["mlp_bwd_dgrad"] = event_ms(lambda: lib.nerf_mlp_bwd_dgrad_ex(P(eng.packed), P(stash), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(ws), P(scal[1:2]), st), 20)
         k["mlp_bwd_wgrad"] = event_ms(lambda: lib.nerf_mlp_bwd_wgrad(P(stash), P(ws), n, P(grads), st), 20)
-        k["composite_fwd"] = event_ms(lambda: ops.composite_fwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg), 20)
-        k["composite_bwd"] = event_ms(lambda: ops.composite_bwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg, None, g_pred, None, None, None), 20)
+        k["composite_mse_bwd"] = event_ms(lambda: ops.composite_mse_bwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg, target, scal[0:1]), 20)
         tp, tm, tv = eng.params.clone(), torch.zeros_like(grads), torch.zeros_like(grads)
         k["adam+pack"] = event_ms(lambda: (ops.adam_step(tp, grads, tm, tv, 1, 5e-4), ops.mlp_pack(eng.params, eng.packed)), 20)
-        stash_b, ws_b = ops.mlp_stash_bytes(n), ops.mlp_bwd_workspace_bytes(n)
+        k["batch_sampling"] = event_ms(lambda: ds.sample_batch(R, eng.bg), 20)
+        stash_b = ops.mlp_stash_bytes(n)
         image_bytes = 1 if stash_b < 4000 * n else 2      # 8-bit images (asm-stream family) or bf16
-        WGRAD_BYTES = WGRAD_ELEMS * image_bytes
+        n_pad = (n + 255) // 256 * 256
+        wgrad_bytes = WGRAD_ELEMS * image_bytes * n_pad
         kern = {
             "mlp_fwd_train": {"ms": k["mlp_fwd_train"], "tflops": n * FWD_FLOP / k["mlp_fwd_train"] * 1e-9},
             "mlp_fwd_infer": {"ms": k["mlp_fwd_infer"], "tflops": n * FWD_FLOP / k["mlp_fwd_infer"] * 1e-9},
             "mlp_bwd_dgrad": {"ms": k["mlp_bwd_dgrad"], "tflops": n * DGRAD_FLOP / k["mlp_bwd_dgrad"] * 1e-9},
             "mlp_bwd_wgrad": {"ms": k["mlp_bwd_wgrad"], "tflops": n * WGRAD_FLOP / k["mlp_bwd_wgrad"] * 1e-9,
-                              "gbs": WGRAD_BYTES * ((n + 255) // 256 * 256) / k["mlp_bwd_wgrad"] * 1e-6},
-            "composite_fwd": {"ms": k["composite_fwd"], "gbs": (n * 20 + R * 32) / k["composite_fwd"] * 1e-6},
-            "composite_bwd": {"ms": k["composite_bwd"], "gbs": (n * 36 + R * 32) / k["composite_bwd"] * 1e-6},
-            "adam+pack": {"ms": k["adam+pack"]},
+                              "gbs": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6},
+            "composite_mse_bwd": {"ms": k["composite_mse_bwd"], "gbs": (n * 36 + R * 44) / k["composite_mse_bwd"] * 1e-6},
+            "adam+pack": {"ms": k["adam+pack"]}, "batch_sampling": {"ms": k["batch_sampling"]},
         }
         out["kernels"] = kern
-        # ---- rooflines: algorithmic work per launch / live launch time; PMC traffic from the committed
-        # rocprofv3 --pmc summary of this same command (profiles/, FETCH_SIZE doubled as the gfx950
-        # guide prescribes); the step's dominant kernel (largest launch time) is reported as `roofline`
+        # ---- rooflines: algorithmic work per launch / launch time.  `achieved` and `frac` come from the IN-STEP time
+        # (what the rocprofv3 averages of profiles/ reproduce); the back-to-back figure is kept beside it.  PMC traffic
+        # from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE doubled, separate passes).
         pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
                 pmc = json.load(f)
         except OSError:
             pass
         traffic = lambda name: (pmc.get(name, {}).get("hbm_bytes_per_launch_corrected") if (R, S) == (4096, 64) else None)
-        # wgrad reads every stashed image exactly once (not the ReLU mask words):
-        # activations 64+8*256+256+128+32 and gradients 16+128+256+8*256 bf16 per sample
-        wgrad_bytes = WGRAD_BYTES * ((n + 255) // 256 * 256)
+
+        def mfma_roof(kernel, phase, iso, work):
+            a, b = work / in_step[phase] * 1e-9, work / k[iso] * 1e-9
+            return {"bound": "mfma", "kernel": kernel, "achieved": a, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_PEAK_TFLOPS,
+                    "traffic": traffic(kernel), "work_per_launch": work, "launch_ms": in_step[phase],
+                    "achieved_back_to_back": b, "launch_ms_back_to_back": k[iso]}
         roofs = {
-            "mlp_fwd_train": {"bound": "mfma", "kernel": "mlp_fwd_stream_kernel<true>", "achieved": kern["mlp_fwd_train"]["tflops"],
-                              "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kern["mlp_fwd_train"]["tflops"] / MFMA_PEAK_TFLOPS,
-                              "traffic": traffic("mlp_fwd_stream_kernel<true>"), "work_per_launch": n * FWD_FLOP, "launch_ms": k["mlp_fwd_train"]},
-            "mlp_bwd_dgrad": {"bound": "mfma", "kernel": "mlp_bwd_stream_kernel", "achieved": kern["mlp_bwd_dgrad"]["tflops"],
-                              "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kern["mlp_bwd_dgrad"]["tflops"] / MFMA_PEAK_TFLOPS,
-                              "traffic": traffic("mlp_bwd_stream_kernel"), "work_per_launch": n * DGRAD_FLOP, "launch_ms": k["mlp_bwd_dgrad"]},
-            "mlp_bwd_wgrad": {"bound": "hbm", "kernel": "mlp_wgrad_kernel", "achieved": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6 / HBM_PEAK_GBS,
-                              "traffic": traffic("mlp_wgrad_kernel"), "work_per_launch": wgrad_bytes, "launch_ms": k["mlp_bwd_wgrad"]},
+            "mlp_fwd_train": mfma_roof("mlp_fwd_stream_kernel<true>", "fwd", "mlp_fwd_train", n * FWD_FLOP),
+            "mlp_bwd_dgrad": mfma_roof("mlp_bwd_stream_kernel", "dgrad", "mlp_bwd_dgrad", n * DGRAD_FLOP),
+            "mlp_bwd_wgrad": {"bound": "hbm", "kernel": "mlp_wgrad_kernel", "achieved": wgrad_bytes / in_step["wgrad"] * 1e-6,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wgrad_bytes / in_step["wgrad"] * 1e-6 / HBM_PEAK_GBS,
+                              "traffic": traffic("mlp_wgrad_kernel"), "work_per_launch": wgrad_bytes, "launch_ms": in_step["wgrad"],
+                              "achieved_back_to_back": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6, "launch_ms_back_to_back": k["mlp_bwd_wgrad"],
+                              "mfma_tflops": n * WGRAD_FLOP / in_step["wgrad"] * 1e-9,
+                              "note": "reads every training image once (8-bit: 4976 B/sample); also within 2x of its MFMA time"},
         }
-        dom = max(roofs, key=lambda name: k[name])
+        dom = max(roofs, key=lambda name: roofs[name]["launch_ms"])
         out["roofline"] = roofs[dom]
         out["rooflines"] = roofs
         step_ach = R * S * TRAIN_FLOP / (ms_per_step * 1e-3) * 1e-12
         out["step_tflops"] = step_ach
         out["step_frac_of_mfma_peak"] = step_ach / MFMA_PEAK_TFLOPS
+        # configs[1] is bound by the MFMA roof (negligible compulsory bytes): the step against it
+        out["step_frac_of_binding_roofline"] = {"bound": "mfma", "achieved": step_ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": step_ach / MFMA_PEAK_TFLOPS, "work_per_step": R * S * TRAIN_FLOP}
+        step_traffic = [traffic(roofs[r]["kernel"]) for r in roofs]
+        out["step_hbm_traffic_bytes"] = sum(step_traffic) if all(t is not None for t in step_traffic) else None
 
     # ---- render: 800x800 rays, 128 samples, rays split into row bands across ranks ----
     if not args.no_render:
@@ -381,6 +453,13 @@ def main():
             cores = os.cpu_count() or 1
         out["cpu_baseline"] = cpu_baseline(1024, S, min(cores, 16))   # the box's CPU share for one GPU is 16
         out["gpu_over_cpu"] = rays_per_s / out["cpu_baseline"]["value"]
+
+    if rank == 0 and world == 1 and not args.no_instant:
+        del ds
+        torch.cuda.empty_cache()
+        inst = bench_instant(args, device)
+        out["instant"] = {key: inst[key] for key in ("value", "unit", "ms_per_step", "render_fps", "render_ms_per_frame", "psnr_curve",
+                                                     "kernels", "rooflines", "active_samples", "config", "reference_headline")}
 
     if rank == 0:
         print(json.dumps(out))

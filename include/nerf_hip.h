@@ -70,6 +70,14 @@ int nerf_gather_rays(const float* images, const float* poses, const int64_t* img
                      const int64_t* pix_x, int64_t batch, int n_images, int H, int W, float focal,
                      float scene_scale, float* rays_o, float* rays_d, float* rgba, nerf_stream_t stream);
 
+/* the same with ONE index per ray, drawn uniformly over all pixels of all frames (flat_idx in
+ * [0, n_images*H*W): image = idx / (H*W), row = idx / W % H, column = idx % W), and with the training
+ * target formed in the same pass: target = rgb * a + bg * (1 - a) (run.py:317-322, run.py:588-594);
+ * bg [3] and target [batch,3] go together (both NULL: no target); rgba [batch,4] optional. */
+int nerf_gather_batch(const float* images, const float* poses, const int64_t* flat_idx, int64_t batch, int n_images,
+                      int H, int W, float focal, float scene_scale, const float* bg, float* rays_o, float* rays_d,
+                      float* rgba, float* target, nerf_stream_t stream);
+
 /* ---- a3: occupancy lookup ---------------------------------------------------
  * replaces DensityGrid.get_active_mask (src/renderer.py:134-166).
  *   pts [N,3]; binary_grid [res,res,res] bytes (torch.bool storage);

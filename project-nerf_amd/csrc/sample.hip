@@ -91,9 +91,13 @@ __global__ void __launch_bounds__(256)
 gather_rays_kernel(const float* __restrict__ images, const float* __restrict__ poses, const int64_t* __restrict__ img_idx,
                    const int64_t* __restrict__ pix_y, const int64_t* __restrict__ pix_x, int64_t batch, int H, int W,
                    float half_w, float half_h, float focal, float scene_scale, float* __restrict__ rays_o,
-                   float* __restrict__ rays_d, float* __restrict__ rgba) {
+                   float* __restrict__ rays_d, float* __restrict__ rgba, const float* __restrict__ bg,
+                   float* __restrict__ target) {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < batch; r += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t im = img_idx[r], py = pix_y[r], px = pix_x[r];
+    // pix_y == NULL: img_idx holds ONE flat draw over all pixels of all frames (image, row, column)
+    int64_t im = img_idx[r], py, px;
+    if (pix_y != nullptr) { py = pix_y[r]; px = pix_x[r]; }
+    else { px = im % W; py = (im / W) % H; im = im / ((int64_t)W * H); }
     const float* c2w = poses + im * 16;
     const float x = sub_rn((float)px, half_w) / focal;
     const float y = -(sub_rn((float)py, half_h) / focal);
@@ -110,7 +114,14 @@ gather_rays_kernel(const float* __restrict__ images, const float* __restrict__ p
       rays_o[r * 3 + i] = scene_scale != 1.0f ? mul_rn(o, scene_scale) : o;
     }
     const float4 c = *reinterpret_cast<const float4*>(images + ((im * H + py) * W + px) * 4);
-    *reinterpret_cast<float4*>(rgba + r * 4) = c;
+    if (rgba != nullptr) *reinterpret_cast<float4*>(rgba + r * 4) = c;
+    if (target != nullptr) {
+      // target = rgb * a + bg * (1 - a), every product and sum rounded on its own (run.py:317-322)
+      const float rest = sub_rn(1.0f, c.w);
+      target[r * 3 + 0] = add_rn(mul_rn(c.x, c.w), mul_rn(bg[0], rest));
+      target[r * 3 + 1] = add_rn(mul_rn(c.y, c.w), mul_rn(bg[1], rest));
+      target[r * 3 + 2] = add_rn(mul_rn(c.z, c.w), mul_rn(bg[2], rest));
+    }
   }
 }
 
@@ -162,6 +173,21 @@ extern "C" int nerf_gather_rays(const float* images, const float* poses, const i
   NERF_REQUIRE(images && poses && img_idx && pix_y && pix_x && rays_o && rays_d && rgba, "nerf_gather_rays: NULL pointer");
   NERF_REQUIRE((((uintptr_t)images | (uintptr_t)rgba) & 15) == 0, "nerf_gather_rays: images / rgba must be 16-byte aligned");
   hipLaunchKernelGGL(gather_rays_kernel, dim3(grid_for(batch, 256)), dim3(256), 0, as_stream(stream), images, poses, img_idx,
-                     pix_y, pix_x, batch, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, rays_o, rays_d, rgba);
+                     pix_y, pix_x, batch, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, rays_o, rays_d, rgba,
+                     nullptr, nullptr);
   return check_launch("nerf_gather_rays");
+}
+
+extern "C" int nerf_gather_batch(const float* images, const float* poses, const int64_t* flat_idx, int64_t batch, int n_images,
+                                 int H, int W, float focal, float scene_scale, const float* bg, float* rays_o, float* rays_d,
+                                 float* rgba, float* target, nerf_stream_t stream) {
+  NERF_REQUIRE(batch >= 0 && n_images > 0 && H > 0 && W > 0 && focal > 0.0f, "nerf_gather_batch: bad sizes");
+  if (batch == 0) return NERF_OK;
+  NERF_REQUIRE(images && poses && flat_idx && rays_o && rays_d && (rgba || target), "nerf_gather_batch: NULL pointer");
+  NERF_REQUIRE((target == nullptr) == (bg == nullptr), "nerf_gather_batch: target and bg go together");
+  NERF_REQUIRE((((uintptr_t)images | (uintptr_t)rgba) & 15) == 0, "nerf_gather_batch: images / rgba must be 16-byte aligned");
+  hipLaunchKernelGGL(gather_rays_kernel, dim3(grid_for(batch, 256)), dim3(256), 0, as_stream(stream), images, poses, flat_idx,
+                     nullptr, nullptr, batch, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, rays_o, rays_d, rgba,
+                     bg, target);
+  return check_launch("nerf_gather_batch");
 }

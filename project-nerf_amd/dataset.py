@@ -67,6 +67,29 @@ class BlenderDataset:
         self._directions = self._directions.to(device)
         return self
 
+    def sample_batch(self, batch_size, bg):
+        """Training batch from GPU-resident frames: one uniform draw over all pixels of all frames (the same
+        distribution as the reference's three draws, dataset.py:147-150) and one kernel that forms the rays
+        AND the composited target rgb * a + bg * (1 - a) (run.py:317-322)."""
+        from . import ops
+        idx = torch.randint(0, len(self) * self.H * self.W, (batch_size,), device=self.images.device)
+        o, d, target, _ = ops.gather_batch(self.images, self.poses, idx, self.focal, self.scene_scale, bg=bg)
+        return o, d, target
+
+    @classmethod
+    def from_tensors(cls, images, poses, camera_angle_x, white_bkgd=True, scene_scale=1.0):
+        """Dataset over frames that are already tensors ([n,H,W,4] RGBA in [0,1], [n,4,4] camera-to-world)."""
+        self = cls.__new__(cls)
+        self.root_dir, self.split, self.downscale = None, "memory", 1
+        self.white_bkgd, self.scene_scale = white_bkgd, float(scene_scale)
+        self.camera_angle_x = float(camera_angle_x)
+        self.frames = [None] * images.shape[0]
+        self.images, self.poses = images, poses
+        self.H, self.W = images.shape[1:3]
+        self.focal = 0.5 * self.W / np.tan(0.5 * self.camera_angle_x)
+        self._directions = self._build_directions().to(images.device)
+        return self
+
     def sample_random_rays(self, batch_size, device):
         dev = self.images.device
         img = torch.randint(0, len(self), (batch_size,), device=dev)
@@ -115,35 +138,66 @@ def analytic_scene(pts):
     return rgb, sigma
 
 
+def render_analytic_frame(c2w, size, focal, n_samples=256, device="cpu", chunk=32768):
+    """RGBA ground truth [size,size,4] of ``analytic_scene`` from camera ``c2w`` by plain quadrature
+    (ground truth only; not a product path).  ``device`` may be a GPU: the bench's 800 x 800 frames."""
+    c2w = c2w.to(device)
+    j, i = torch.meshgrid(torch.arange(size, device=device), torch.arange(size, device=device), indexing="ij")
+    d = torch.stack([(i - size * 0.5) / focal, -(j - size * 0.5) / focal, -torch.ones_like(i)], -1).reshape(-1, 3).float()
+    d = d @ c2w[:3, :3].T
+    d = d / d.norm(dim=-1, keepdim=True)
+    t = torch.linspace(2.0, 6.0, n_samples, device=device)
+    out = []
+    for k in range(0, d.shape[0], chunk):
+        dd = d[k:k + chunk]
+        pts = c2w[:3, 3][None, None] + dd[:, None] * t[None, :, None]
+        rgb, sigma = analytic_scene(pts.reshape(-1, 3))
+        rgb, sigma = rgb.view(-1, n_samples, 3), sigma.view(-1, n_samples)
+        alpha = 1 - torch.exp(-sigma * (4.0 / (n_samples - 1)))
+        T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)[:, :-1]
+        w = alpha * T
+        acc = w.sum(-1, keepdim=True)
+        col = (w[..., None] * rgb).sum(1) / acc.clamp_min(1e-6)
+        out.append(torch.cat([col.clamp(0, 1), acc.clamp(0, 1)], -1))
+    return torch.cat(out, 0).view(size, size, 4)
+
+
+def synthetic_poses(count, rng):
+    """Cameras on the upper hemisphere at the NeRF-Synthetic radius, looking at the origin."""
+    poses = []
+    for _ in range(count):
+        th, ph = rng.uniform(0, 2 * np.pi), rng.uniform(0.15, 1.2)
+        eye = 4.0311 * np.array([np.cos(th) * np.cos(ph), np.sin(th) * np.cos(ph), np.sin(ph)])
+        poses.append(torch.tensor(look_at_pose(eye), dtype=torch.float32))
+    return poses
+
+
+SYNTHETIC_CAMERA_ANGLE = 0.6911112070083618
+
+
+def synthetic_frames(count, size, device, seed=2025, n_samples=192):
+    """``count`` RGBA frames of the analytic scene rendered ON ``device`` (no PNG round trip): images
+    [count,size,size,4] in [0,1] (8-bit quantised like the files would be), poses [count,4,4]."""
+    rng = np.random.default_rng(seed)
+    focal = 0.5 * size / np.tan(0.5 * SYNTHETIC_CAMERA_ANGLE)
+    poses = synthetic_poses(count, rng)
+    frames = [torch.round(render_analytic_frame(p, size, focal, n_samples, device) * 255.0) / 255.0 for p in poses]
+    return torch.stack(frames, 0), torch.stack(poses, 0).to(device)
+
+
 def write_synthetic_scene(root, n_train=20, n_test=4, size=100, seed=2025, n_samples=256):
     """Writes transforms_{train,test}.json + RGBA PNGs rendered from ``analytic_scene`` by plain
     quadrature on the host (ground truth only; not a product path)."""
     from PIL import Image
     rng = np.random.default_rng(seed)
-    angle = 0.6911112070083618
+    angle = SYNTHETIC_CAMERA_ANGLE
     focal = 0.5 * size / np.tan(0.5 * angle)
     os.makedirs(root, exist_ok=True)
     for split, count in (("train", n_train), ("test", n_test)):
         frames = []
         os.makedirs(os.path.join(root, split), exist_ok=True)
-        for k in range(count):
-            th, ph = rng.uniform(0, 2 * np.pi), rng.uniform(0.15, 1.2)
-            eye = 4.0311 * np.array([np.cos(th) * np.cos(ph), np.sin(th) * np.cos(ph), np.sin(ph)])
-            c2w = torch.tensor(look_at_pose(eye), dtype=torch.float32)
-            j, i = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
-            d = torch.stack([(i - size * 0.5) / focal, -(j - size * 0.5) / focal, -torch.ones_like(i)], -1).reshape(-1, 3).float()
-            d = d @ c2w[:3, :3].T
-            d = d / d.norm(dim=-1, keepdim=True)
-            t = torch.linspace(2.0, 6.0, n_samples)
-            pts = c2w[:3, 3][None, None] + d[:, None] * t[None, :, None]
-            rgb, sigma = analytic_scene(pts.reshape(-1, 3))
-            rgb, sigma = rgb.view(-1, n_samples, 3), sigma.view(-1, n_samples)
-            alpha = 1 - torch.exp(-sigma * (4.0 / (n_samples - 1)))
-            T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], -1), -1)[:, :-1]
-            w = alpha * T
-            acc = w.sum(-1, keepdim=True)
-            col = (w[..., None] * rgb).sum(1) / acc.clamp_min(1e-6)
-            rgba = torch.cat([col.clamp(0, 1), acc.clamp(0, 1)], -1).view(size, size, 4)
+        for k, c2w in enumerate(synthetic_poses(count, rng)):
+            rgba = render_analytic_frame(c2w, size, focal, n_samples)
             Image.fromarray((rgba.numpy() * 255 + 0.5).astype(np.uint8), "RGBA").save(os.path.join(root, split, f"r_{k}.png"))
             frames.append({"file_path": f"./{split}/r_{k}", "transform_matrix": c2w.tolist()})
         with open(os.path.join(root, f"transforms_{split}.json"), "w") as f:

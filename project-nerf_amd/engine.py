@@ -105,14 +105,19 @@ class VanillaNerfEngine:
 
     # -- training step (reference run.py:314-338) ------------------------------
     def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 64,
-                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None) -> Tensor:
+                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, mark=None) -> Tensor:
+        """``mark(name)`` (optional) is called after each phase has been enqueued -- bench.py records a HIP
+        event there, which times the kernels inside the step without serialising anything."""
+        mark = mark or (lambda name: None)
         R = rays_o.shape[0]
         n = R * n_samples
         if u is None:
             u = torch.rand(R, n_samples, device=self.device)
         z = ops.sample_rays(rays_o, rays_d, self.near, self.far, n_samples, u=u)
+        mark("sample")
         stash = self._buf("stash", ops.mlp_stash_bytes(n))
         rgb, sigma = ops.mlp_fwd(self.packed, rays_o, rays_d, z, stash)
+        mark("fwd")
         slot = self.step_count % self._scalars.shape[1]
         if slot == 0:
             self._scalars.zero_()
@@ -121,6 +126,7 @@ class VanillaNerfEngine:
         # largest output-layer derivative, from which the e5m2 gradient images take their scale
         d_rgb, d_sigma, _ = ops.composite_mse_bwd(rgb.view(R, n_samples, 3), sigma.view(R, n_samples), z, rays_d, self.bg,
                                                   target, loss, amax_accum=amax)
+        mark("loss")
         if sync_grads_async is not None:
             # weight gradients in two launches: the late layers' range is all-reduced (RCCL) while the
             # early layers' is still being computed; both are averaged by grad_scale below
@@ -128,13 +134,15 @@ class VanillaNerfEngine:
                                    self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)), sync_grads_async, amax=amax)
         else:
             ops.mlp_bwd(self.packed, stash, rgb, sigma, d_rgb.view(n, 3), d_sigma.view(n), self.grads,
-                        self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)), amax=amax)
+                        self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)), amax=amax, mark=mark)
+        mark("wgrad")
         if sync_grads is not None:
             sync_grads(self.grads)            # RCCL all-reduce (sum); averaged by grad_scale below
         self.step_count += 1
         ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                       grad_scale=self.grad_scale if self.world_size > 1 else None)
         self.repack()
+        mark("adam+pack")
         return loss[0]
 
     # -- inference (reference render_image, src/renderer.py:387-418) ------------

@@ -85,6 +85,24 @@ def gather_rays(images: Tensor, poses: Tensor, img_idx: Tensor, pix_y: Tensor, p
     return o, d, rgba
 
 
+def gather_batch(images: Tensor, poses: Tensor, flat_idx: Tensor, focal: float, scene_scale: float = 1.0,
+                 bg: Optional[Tensor] = None, want_rgba: bool = False):
+    """One draw per ray over all pixels of all frames -> (rays_o, rays_d, target or None, rgba or None);
+    ``bg`` [3] asks for the composited training target rgb * a + bg * (1 - a)."""
+    lib = _lib.load()
+    images, poses = _dev(images, "images"), _dev(poses, "poses")
+    n_img, H, W, _ = images.shape
+    flat_idx = _dev(flat_idx, "flat_idx", torch.int64)
+    B = flat_idx.numel()
+    o, d = torch.empty(B, 3, device=images.device), torch.empty(B, 3, device=images.device)
+    rgba = torch.empty(B, 4, device=images.device) if (want_rgba or bg is None) else None
+    target = torch.empty(B, 3, device=images.device) if bg is not None else None
+    _lib.check(lib.nerf_gather_batch(_p(images), _p(poses), _p(flat_idx), B, n_img, H, W, float(focal), float(scene_scale),
+                                     _p(None if bg is None else _dev(bg, "bg")), _p(o), _p(d), _p(rgba), _p(target), _stream()),
+               "nerf_gather_batch")
+    return o, d, target, rgba
+
+
 # --------------------------------------------------------------------------- a1-a4 fused
 def sample_compact(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_samples: int,
                    binary_grid: Tensor, bound: float, u: Optional[Tensor] = None):
@@ -334,7 +352,8 @@ def mlp_bwd_workspace_bytes(n: int) -> int:
 
 
 def mlp_bwd(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Tensor, d_sigma: Tensor,
-            grads: Optional[Tensor] = None, workspace: Optional[Tensor] = None, amax: Optional[Tensor] = None) -> Tensor:
+            grads: Optional[Tensor] = None, workspace: Optional[Tensor] = None, amax: Optional[Tensor] = None,
+            mark=None) -> Tensor:
     """Parameter gradients [595844] (reference state_dict order) of the fused decoder.  ``amax``: the
     largest output-layer derivative as a device scalar (from composite_mse_bwd), else computed here."""
     lib = _lib.load()
@@ -351,6 +370,8 @@ def mlp_bwd(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Te
     else:
         _lib.check(lib.nerf_mlp_bwd_dgrad_ex(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
                                              _p(workspace), _p(amax), _stream()), "nerf_mlp_bwd_dgrad_ex")
+        if mark is not None:
+            mark("dgrad")
         _lib.check(lib.nerf_mlp_bwd_wgrad(_p(stash), _p(workspace), n, _p(grads), _stream()), "nerf_mlp_bwd_wgrad")
     return grads
 
