@@ -6,8 +6,8 @@
 
 A "step" is one training step of the hot path (reference run.py:312-338) on one batch of synthetic
 rays: 4096 rays x 64 stratified samples (configs/part2.yaml.example: batch_size 4096, n_samples 64):
-batch sampling from 100 GPU-resident 800x800 frames (one index draw + nerf_gather_batch: rays and
-composited targets) -> jitter draw + sample depths -> fused bf16-MFMA decoder fwd (+ 8-bit stash) ->
+batch sampling from 100 GPU-resident 800x800 frames + jittered stratified depths (nerf_train_batch: pixel
+draws, rays, composited targets and depths in one kernel) -> fused bf16-MFMA decoder fwd (+ 8-bit stash) ->
 composite + MSE + backward (one kernel) -> dgrad chain -> wgrad -> (RCCL all-reduce) -> Adam -> weight
 repack, inputs resident in HBM.  Rays shard across ranks (weak scaling: every rank owns its own
 4096-ray batch; one gradient all-reduce per step).  ``value`` = rays/s summed over ranks.  The same run
@@ -280,11 +280,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    counter = [0]
+
     def step(mark=None):
-        o, d, target = ds.sample_batch(R, eng.bg)                # batch sampling is part of the step (run.py:314-322)
+        # the data side of the step (run.py:314-322 + the jitter of render_rays): one kernel
+        o, d, target, z = ds.train_batch(R, S, eng.near, eng.far, eng.bg, seed=100 + rank, counter=counter[0])
+        counter[0] += 1
         if mark is not None:
             mark("batch_sampling")
-        return eng.train_step(o, d, target, S, sync_grads=sync, sync_grads_async=sync_async, mark=mark)
+        return eng.train_step(o, d, target, S, sync_grads=sync, sync_grads_async=sync_async, mark=mark, z=z)
 
     for _ in range(args.warmup):
         step()
@@ -318,7 +322,7 @@ def main():
     if rank == 0:
         n = R * S
         # ---- every phase timed INSIDE the step: a HIP event on the launch stream after each phase ----
-        phases = ["batch_sampling", "sample", "fwd", "loss", "dgrad", "wgrad", "adam+pack"]
+        phases = ["batch_sampling", "fwd", "loss", "dgrad", "wgrad", "adam+pack"]
         acc = {p: 0.0 for p in phases}
         reps = max(10, min(args.steps, 30))
         for _ in range(reps):
@@ -337,7 +341,7 @@ def main():
         out["kernels_in_step"] = {p: {"ms": v} for p, v in in_step.items()}
         out["kernels_in_step_note"] = ("HIP events on the launch stream between the phases of the timed step; "
                                        "fwd = mlp_fwd_stream_kernel<true>, loss = composite_mse_bwd_kernel, dgrad = mlp_bwd_stream_kernel, "
-                                       "wgrad = memset + mlp_wgrad_kernel, sample = jitter draw + sample_rays_kernel")
+                                       "wgrad = memset + mlp_wgrad_kernel, batch_sampling = train_batch_kernel (pixel draws, rays, targets, jittered depths)")
         # ---- the same kernels launched back to back on their own (warm caches) ----
         o, d, target = ds.sample_batch(R, eng.bg)
         u = torch.rand(R, S, device=device)
@@ -359,7 +363,7 @@ def main():
         k["composite_mse_bwd"] = event_ms(lambda: ops.composite_mse_bwd(rgb.view(R, S, 3), sigma.view(R, S), z, d, eng.bg, target, scal[0:1]), 20)
         tp, tm, tv = eng.params.clone(), torch.zeros_like(grads), torch.zeros_like(grads)
         k["adam+pack"] = event_ms(lambda: (ops.adam_step(tp, grads, tm, tv, 1, 5e-4), ops.mlp_pack(eng.params, eng.packed)), 20)
-        k["batch_sampling"] = event_ms(lambda: ds.sample_batch(R, eng.bg), 20)
+        k["batch_sampling"] = event_ms(lambda: ds.train_batch(R, S, eng.near, eng.far, eng.bg, seed=1, counter=3), 20)
         stash_b = ops.mlp_stash_bytes(n)
         image_bytes = 1 if stash_b < 4000 * n else 2      # 8-bit images (asm-stream family) or bf16
         n_pad = (n + 255) // 256 * 256

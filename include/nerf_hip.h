@@ -78,6 +78,19 @@ int nerf_gather_batch(const float* images, const float* poses, const int64_t* fl
                       int H, int W, float focal, float scene_scale, const float* bg, float* rays_o, float* rays_d,
                       float* rgba, float* target, nerf_stream_t stream);
 
+/* ---- f1 + a1: the data side of one training step in one kernel --------------------------
+ * replaces sample_random_rays (src/dataset.py:140-171: the three index draws and everything after
+ * them), the target compositing (run.py:317-322) and sample_stratified with perturb (src/renderer.py:
+ * 186-201, its torch.rand included): per ray one uniform draw over all pixels of all frames, per
+ * sample one uniform jitter draw, both from a counter-based generator keyed by (seed, counter) --
+ * same distributions as the reference's torch.randint / torch.rand, different streams; pass a new
+ * `counter` (< 2^24) every step.  perturb 0: plain stratified depths.  Outputs rays_o / rays_d [batch,3],
+ * z [batch,n_samples], target [batch,3] (with bg [3]) and/or rgba [batch,4]. */
+int nerf_train_batch(const float* images, const float* poses, int n_images, int H, int W, float focal,
+                     float scene_scale, const float* bg, uint64_t seed, uint64_t counter, int64_t batch,
+                     int n_samples, float near_plane, float far_plane, int perturb, float* rays_o, float* rays_d,
+                     float* rgba, float* target, float* z_out, nerf_stream_t stream);
+
 /* ---- a3: occupancy lookup ---------------------------------------------------
  * replaces DensityGrid.get_active_mask (src/renderer.py:134-166).
  *   pts [N,3]; binary_grid [res,res,res] bytes (torch.bool storage);

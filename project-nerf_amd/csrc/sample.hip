@@ -18,15 +18,19 @@ __device__ __forceinline__ float plain_depth(int i, int n, float step, float nea
   return add_rn(mul_rn(near_p, sub_rn(1.0f, t)), mul_rn(far_p, t));
 }
 
-__device__ __forceinline__ float sample_depth(int i, int n, float step, float near_p, float far_p,
-                                              const float* u_row) {
+// jittered depth of sample i given its uniform draw u (src/renderer.py:195-199: mids / upper / lower)
+__device__ __forceinline__ float jitter_depth(int i, int n, float step, float near_p, float far_p, float u) {
   const float zi = plain_depth(i, n, step, near_p, far_p);
-  if (u_row == nullptr) return zi;
-  // mids / upper / lower (src/renderer.py:195-199)
   float lo = zi, hi = zi;
   if (i > 0) lo = mul_rn(0.5f, add_rn(zi, plain_depth(i - 1, n, step, near_p, far_p)));
   if (i < n - 1) hi = mul_rn(0.5f, add_rn(plain_depth(i + 1, n, step, near_p, far_p), zi));
-  return add_rn(lo, mul_rn(sub_rn(hi, lo), u_row[i]));
+  return add_rn(lo, mul_rn(sub_rn(hi, lo), u));
+}
+
+__device__ __forceinline__ float sample_depth(int i, int n, float step, float near_p, float far_p,
+                                              const float* u_row) {
+  if (u_row == nullptr) return plain_depth(i, n, step, near_p, far_p);
+  return jitter_depth(i, n, step, near_p, far_p, u_row[i]);
 }
 
 __global__ void __launch_bounds__(256)
@@ -87,17 +91,30 @@ active_mask_kernel(const float* __restrict__ pts, int64_t n, const uint8_t* __re
 // -- camera-space direction of the pixel (no +0.5 centre offset, -y, -z), rotation by c2w[:3,:3],
 // normalisation, origin = c2w[:3,3] * scene_scale, RGBA fetch -- as one kernel instead of a
 // batched 3x3 GEMM plus a dozen elementwise launches.
-__global__ void __launch_bounds__(256)
-gather_rays_kernel(const float* __restrict__ images, const float* __restrict__ poses, const int64_t* __restrict__ img_idx,
-                   const int64_t* __restrict__ pix_y, const int64_t* __restrict__ pix_x, int64_t batch, int H, int W,
-                   float half_w, float half_h, float focal, float scene_scale, float* __restrict__ rays_o,
-                   float* __restrict__ rays_d, float* __restrict__ rgba, const float* __restrict__ bg,
-                   float* __restrict__ target) {
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < batch; r += (int64_t)gridDim.x * blockDim.x) {
-    // pix_y == NULL: img_idx holds ONE flat draw over all pixels of all frames (image, row, column)
-    int64_t im = img_idx[r], py, px;
-    if (pix_y != nullptr) { py = pix_y[r]; px = pix_x[r]; }
-    else { px = im % W; py = (im / W) % H; im = im / ((int64_t)W * H); }
+struct GatherArgs {
+  const float* images;
+  const float* poses;
+  int H, W;
+  float half_w, half_h, focal, scene_scale;
+  const float* bg;
+  float* rays_o;
+  float* rays_d;
+  float* rgba;
+  float* target;
+};
+
+// ray r <- pixel (im, py, px): direction, origin, RGBA and (optionally) the composited target
+__device__ __forceinline__ void gather_one(const GatherArgs& a, int64_t r, int64_t im, int64_t py, int64_t px) {
+  const float* __restrict__ images = a.images;
+  const float* __restrict__ poses = a.poses;
+  float* __restrict__ rays_o = a.rays_o;
+  float* __restrict__ rays_d = a.rays_d;
+  float* __restrict__ rgba = a.rgba;
+  float* __restrict__ target = a.target;
+  const float* __restrict__ bg = a.bg;
+  const int H = a.H, W = a.W;
+  const float half_w = a.half_w, half_h = a.half_h, focal = a.focal, scene_scale = a.scene_scale;
+  {
     const float* c2w = poses + im * 16;
     const float x = sub_rn((float)px, half_w) / focal;
     const float y = -(sub_rn((float)py, half_h) / focal);
@@ -121,6 +138,56 @@ gather_rays_kernel(const float* __restrict__ images, const float* __restrict__ p
       target[r * 3 + 0] = add_rn(mul_rn(c.x, c.w), mul_rn(bg[0], rest));
       target[r * 3 + 1] = add_rn(mul_rn(c.y, c.w), mul_rn(bg[1], rest));
       target[r * 3 + 2] = add_rn(mul_rn(c.z, c.w), mul_rn(bg[2], rest));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gather_rays_kernel(const GatherArgs a, const int64_t* __restrict__ img_idx, const int64_t* __restrict__ pix_y,
+                   const int64_t* __restrict__ pix_x, int64_t batch) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < batch; r += (int64_t)gridDim.x * blockDim.x) {
+    // pix_y == NULL: img_idx holds ONE flat draw over all pixels of all frames (image, row, column)
+    int64_t im = img_idx[r], py, px;
+    if (pix_y != nullptr) { py = pix_y[r]; px = pix_x[r]; }
+    else { px = im % a.W; py = (im / a.W) % a.H; im = im / ((int64_t)a.W * a.H); }
+    gather_one(a, r, im, py, px);
+  }
+}
+
+// Counter-based generator ("squares", Widynski 2020: four rounds of squaring a 64-bit counter x key): every
+// (step, element) pair owns its draw, so one kernel can draw the batch's pixels AND the stratified jitter
+// without any state -- the reference draws them with torch.randint / torch.rand (dataset.py:147-150,
+// renderer.py:198); the distributions are the same, the streams are not.
+__device__ __forceinline__ uint32_t squares32(uint64_t ctr, uint64_t key) {
+  uint64_t x = ctr * key, y = x, z = y + key;
+  x = x * x + y; x = (x >> 32) | (x << 32);
+  x = x * x + z; x = (x >> 32) | (x << 32);
+  x = x * x + y; x = (x >> 32) | (x << 32);
+  return (uint32_t)((x * x + z) >> 32);
+}
+
+// One kernel for the data side of a training step (reference run.py:314-322 + renderer.py:186-201):
+// per ray one uniform draw over all pixels of all frames -> origin, direction, composited target; per sample
+// one uniform draw -> jittered stratified depth.  Thread per (ray, sample); sample 0 also forms the ray.
+__global__ void __launch_bounds__(256)
+train_batch_kernel(const GatherArgs a, uint64_t n_pixels, uint64_t key, uint64_t counter, int64_t batch, int n_samples,
+                   float near_p, float far_p, float step, int perturb, float* __restrict__ z_out) {
+  const int64_t total = batch * (int64_t)n_samples;
+  for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = g / n_samples;
+    const int s = (int)(g - r * n_samples);
+    if (perturb) {
+      const float u = (float)(squares32((counter << 40) + (uint64_t)g, key) >> 8) * 5.9604644775390625e-08f;   // [0, 1), 24 bits
+      z_out[g] = jitter_depth(s, n_samples, step, near_p, far_p, u);
+    } else {
+      z_out[g] = plain_depth(s, n_samples, step, near_p, far_p);
+    }
+    if (s == 0) {
+      const uint64_t c0 = (counter << 40) + ((uint64_t)1 << 39) + 2 * (uint64_t)r;
+      const uint64_t r64 = ((uint64_t)squares32(c0, key) << 32) | squares32(c0 + 1, key);
+      const uint64_t idx = __umul64hi(r64, n_pixels);            // uniform over [0, n_pixels)
+      const int64_t px = (int64_t)(idx % (uint64_t)a.W), py = (int64_t)((idx / (uint64_t)a.W) % (uint64_t)a.H);
+      gather_one(a, r, (int64_t)(idx / ((uint64_t)a.W * a.H)), py, px);
     }
   }
 }
@@ -172,9 +239,8 @@ extern "C" int nerf_gather_rays(const float* images, const float* poses, const i
   if (batch == 0) return NERF_OK;
   NERF_REQUIRE(images && poses && img_idx && pix_y && pix_x && rays_o && rays_d && rgba, "nerf_gather_rays: NULL pointer");
   NERF_REQUIRE((((uintptr_t)images | (uintptr_t)rgba) & 15) == 0, "nerf_gather_rays: images / rgba must be 16-byte aligned");
-  hipLaunchKernelGGL(gather_rays_kernel, dim3(grid_for(batch, 256)), dim3(256), 0, as_stream(stream), images, poses, img_idx,
-                     pix_y, pix_x, batch, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, rays_o, rays_d, rgba,
-                     nullptr, nullptr);
+  const GatherArgs a{images, poses, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, nullptr, rays_o, rays_d, rgba, nullptr};
+  hipLaunchKernelGGL(gather_rays_kernel, dim3(grid_for(batch, 256)), dim3(256), 0, as_stream(stream), a, img_idx, pix_y, pix_x, batch);
   return check_launch("nerf_gather_rays");
 }
 
@@ -186,8 +252,28 @@ extern "C" int nerf_gather_batch(const float* images, const float* poses, const 
   NERF_REQUIRE(images && poses && flat_idx && rays_o && rays_d && (rgba || target), "nerf_gather_batch: NULL pointer");
   NERF_REQUIRE((target == nullptr) == (bg == nullptr), "nerf_gather_batch: target and bg go together");
   NERF_REQUIRE((((uintptr_t)images | (uintptr_t)rgba) & 15) == 0, "nerf_gather_batch: images / rgba must be 16-byte aligned");
-  hipLaunchKernelGGL(gather_rays_kernel, dim3(grid_for(batch, 256)), dim3(256), 0, as_stream(stream), images, poses, flat_idx,
-                     nullptr, nullptr, batch, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, rays_o, rays_d, rgba,
-                     bg, target);
+  const GatherArgs a{images, poses, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, bg, rays_o, rays_d, rgba, target};
+  hipLaunchKernelGGL(gather_rays_kernel, dim3(grid_for(batch, 256)), dim3(256), 0, as_stream(stream), a, flat_idx, nullptr, nullptr, batch);
   return check_launch("nerf_gather_batch");
+}
+
+extern "C" int nerf_train_batch(const float* images, const float* poses, int n_images, int H, int W, float focal,
+                                float scene_scale, const float* bg, uint64_t seed, uint64_t counter, int64_t batch,
+                                int n_samples, float near_plane, float far_plane, int perturb, float* rays_o, float* rays_d,
+                                float* rgba, float* target, float* z_out, nerf_stream_t stream) {
+  NERF_REQUIRE(batch >= 0 && n_images > 0 && H > 0 && W > 0 && focal > 0.0f && n_samples >= 2, "nerf_train_batch: bad sizes");
+  NERF_REQUIRE(counter < ((uint64_t)1 << 24) && batch * (int64_t)n_samples < ((int64_t)1 << 39), "nerf_train_batch: counter / batch out of range");
+  if (batch == 0) return NERF_OK;
+  NERF_REQUIRE(images && poses && rays_o && rays_d && z_out && (rgba || target), "nerf_train_batch: NULL pointer");
+  NERF_REQUIRE((target == nullptr) == (bg == nullptr), "nerf_train_batch: target and bg go together");
+  NERF_REQUIRE((((uintptr_t)images | (uintptr_t)rgba) & 15) == 0, "nerf_train_batch: images / rgba must be 16-byte aligned");
+  uint64_t key = seed + 0x9E3779B97F4A7C15ull;                   // splitmix64 of the seed, forced odd
+  key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull;
+  key = (key ^ (key >> 27)) * 0x94D049BB133111EBull;
+  key = (key ^ (key >> 31)) | 1ull;
+  const GatherArgs a{images, poses, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, bg, rays_o, rays_d, rgba, target};
+  const float step = 1.0f / (float)(n_samples - 1);
+  hipLaunchKernelGGL(train_batch_kernel, dim3(grid_for(batch * (int64_t)n_samples, 256)), dim3(256), 0, as_stream(stream), a,
+                     (uint64_t)n_images * H * W, key, counter, batch, n_samples, near_plane, far_plane, step, perturb, z_out);
+  return check_launch("nerf_train_batch");
 }

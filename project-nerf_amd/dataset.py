@@ -76,6 +76,13 @@ class BlenderDataset:
         o, d, target, _ = ops.gather_batch(self.images, self.poses, idx, self.focal, self.scene_scale, bg=bg)
         return o, d, target
 
+    def train_batch(self, batch_size, n_samples, near, far, bg, seed, counter, perturb=True):
+        """(rays_o, rays_d, target, z) of one training step from one kernel (ops.train_batch): pixel draws,
+        rays, composited targets and jittered stratified depths."""
+        from . import ops
+        return ops.train_batch(self.images, self.poses, self.focal, batch_size, n_samples, near, far, seed, counter, bg=bg,
+                               scene_scale=self.scene_scale, perturb=perturb)
+
     @classmethod
     def from_tensors(cls, images, poses, camera_angle_x, white_bkgd=True, scene_scale=1.0):
         """Dataset over frames that are already tensors ([n,H,W,4] RGBA in [0,1], [n,4,4] camera-to-world)."""

@@ -105,16 +105,20 @@ class VanillaNerfEngine:
 
     # -- training step (reference run.py:314-338) ------------------------------
     def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 64,
-                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, mark=None) -> Tensor:
-        """``mark(name)`` (optional) is called after each phase has been enqueued -- bench.py records a HIP
+                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, mark=None,
+                   z: Optional[Tensor] = None) -> Tensor:
+        """``z`` [R, n_samples]: jittered depths the caller already has (BlenderDataset.train_batch draws them
+        together with the rays); otherwise they are drawn here (``u`` or torch.rand).
+        ``mark(name)`` (optional) is called after each phase has been enqueued -- bench.py records a HIP
         event there, which times the kernels inside the step without serialising anything."""
         mark = mark or (lambda name: None)
         R = rays_o.shape[0]
         n = R * n_samples
-        if u is None:
-            u = torch.rand(R, n_samples, device=self.device)
-        z = ops.sample_rays(rays_o, rays_d, self.near, self.far, n_samples, u=u)
-        mark("sample")
+        if z is None:
+            if u is None:
+                u = torch.rand(R, n_samples, device=self.device)
+            z = ops.sample_rays(rays_o, rays_d, self.near, self.far, n_samples, u=u)
+            mark("sample")
         stash = self._buf("stash", ops.mlp_stash_bytes(n))
         rgb, sigma = ops.mlp_fwd(self.packed, rays_o, rays_d, z, stash)
         mark("fwd")
