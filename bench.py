@@ -208,7 +208,68 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
 
 
 def bench_instant_dp(args, device, rank, world, dist):
-    raise SystemExit("bench.py --workload instant on several ranks: see InstantNgpEngine data-parallel path")
+    """BASELINE.json configs[3]: Instant-NGP training with the ray batch data-parallel over the ranks (weak scaling:
+    16,384 rays per rank), gradients summed over RCCL/xGMI.  The tiny-MLP gradients go on the wire first, the 52 MB
+    table gradient follows level group by level group while the next group's scatter runs (bf16 on the wire unless
+    NERF_BENCH_REDUCE_FP32 is set); TV + clip + AdamW run replicated.  800 x 800 evaluation in row bands, gathered
+    on rank 0."""
+    import numpy as np
+    import yaml
+    from src.dataset import BlenderDataset, SYNTHETIC_CAMERA_ANGLE, synthetic_frames
+    from project_nerf_amd import parallel
+    from project_nerf_amd.engine import InstantNgpEngine
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    batch, S, iters = 16384, 128, 600
+    cfg["train_iters"] = iters
+    images, poses = synthetic_frames(12, 400, device, n_samples=128)          # every rank renders the same frames (same seed)
+    ds = BlenderDataset.from_tensors(images, poses, SYNTHETIC_CAMERA_ANGLE)
+    torch.manual_seed(1000 + rank)                                          # ... and draws its own rays
+    eng = InstantNgpEngine(cfg, device=str(device), seed=0, world_size=world)
+    wire = None if os.environ.get("NERF_BENCH_REDUCE_FP32") else torch.bfloat16
+
+    def step():
+        o, d, target = ds.sample_batch(batch, eng.bg)
+        return eng.train_step(o, d, target, S, sync_grads_async=parallel.allreduce_sum_async, reduce_dtype=wire)
+
+    for it in range(1, iters + 1):
+        step()
+        if it >= 256 and it % 64 == 0 and it < iters * 0.9:
+            eng.update_grid()                                               # replicated: a pure function of the replicated weights
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    # replicas must still agree after hundreds of steps of summed gradients
+    probe = torch.stack([eng.table[::65537].double().sum(), eng.net.double().sum()])
+    lo, hi = probe.clone(), probe.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    # evaluation: row bands of one 800 x 800 view
+    H = W = 800
+    o, d, _ = BlenderDataset.from_tensors(images[:1, :1, :1].expand(1, H, W, 4).contiguous(), poses[:1], SYNTHETIC_CAMERA_ANGLE).get_image_rays(0, device)
+    r0, r1 = parallel.shard_range(H, rank, world)
+    eng.render_image(o[r0:r1].contiguous(), d[r0:r1].contiguous(), S)
+    dist.barrier(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.render_frames):
+        band = eng.render_image(o[r0:r1].contiguous(), d[r0:r1].contiguous(), S)
+        parallel.gather_row_bands(band, H, dst=0)
+    dist.barrier(); torch.cuda.synchronize()
+    rt = (time.perf_counter() - t1) / args.render_frames
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train rays/sec + 800x800 render FPS, NeRF-Synthetic Lego; PSNR parity", "value": batch * world * args.steps / dt,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": iters, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Part 2 Instant-NGP, ray batches data-parallel (BASELINE configs[3])", "rays_per_gpu": batch,
+                       "samples_per_ray": S, "parallelism": f"ray-dp{world}", "gradient_wire_dtype": "fp32" if wire is None else "bf16",
+                       "table_gradient_bytes_fp32": int(eng.g_table.numel() * 4), "level_groups": eng.level_groups()},
+            "final_loss": float(loss), "replica_divergence": float((hi - lo).abs().max()), "render_fps": 1.0 / rt}))
+    dist.destroy_process_group()
 
 
 def hemisphere_poses(n, seed):

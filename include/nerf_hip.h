@@ -265,6 +265,12 @@ int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float*
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
                          nerf_stream_t stream);
+/* the same for levels [first_level, end_level) only: a data-parallel caller all-reduces one level
+ * range of the table gradient (a contiguous slice of d_table) while the next range is computed. */
+int nerf_hash_encode_bwd_levels(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                         const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                         const unsigned* dense_host, float bound, const float* d_feat, float* d_table, int first_level, int end_level,
+                         nerf_stream_t stream);
 
 
 /* ---- a7: Instant decoder (two bias-free tiny MLPs, bf16 MFMA) -----------------------

@@ -323,7 +323,13 @@ def generate(mode):
                 need |= {("b", gi, q) for q in range(4)} & set(lds_q)
             wait_lds(need)
             c_in = vr(T, 16) if (k > 0 or g["bias"] is not None) else "0"
-            emit(f"v_mfma_f32_32x32x16_bf16 {vr(T, 16)}, %[w{j % D}], {g['bops'][k]}, {c_in}")
+            if "shape32" in ABLATE:
+                # timing probe of the 16x16x32 shape (results are wrong): the same operands feed two half-length MFMAs
+                for h in range(2):
+                    ch = vr(T + 4 * h, 4) if c_in != "0" else "0"
+                    emit(f"v_mfma_f32_16x16x32_bf16 {vr(T + 4 * h, 4)}, %[w{j % D}], {g['bops'][k]}, {ch}")
+            else:
+                emit(f"v_mfma_f32_32x32x16_bf16 {vr(T, 16)}, %[w{j % D}], {g['bops'][k]}, {c_in}")
             # ---- gap fillers ----
             if first_of_chunk and k == 0 and g["chunk"] > 0:
                 emit("s_barrier")                                   # B2 of the previous chunk

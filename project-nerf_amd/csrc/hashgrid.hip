@@ -211,10 +211,11 @@ extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* ta
   return check_launch("nerf_hash_encode_fwd");
 }
 
-extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float* scale_host,
-                                    const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
-                                    const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
-                                    nerf_stream_t stream) {
+static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                         const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                         const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                         int level0, int level1, nerf_stream_t stream) {
+  NERF_REQUIRE(level0 >= 0 && level0 <= level1 && level1 <= n_levels, "nerf_hash_encode_bwd: levels [%d, %d) of %d", level0, level1, n_levels);
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(pts && d_feat && d_table && scale_host && res_host && size_host && offset_host && dense_host,
@@ -226,23 +227,40 @@ extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, c
   if (rc != NERF_OK) return rc;
   int n_small = 0;                      // leading levels whose table fits in LDS
   while (n_small < n_levels && size_host[n_small] <= (unsigned)kLdsEntries) ++n_small;
-  if (n_small > 0) {
+  if (level0 < n_small) {
+    const int hi = level1 < n_small ? level1 : n_small;
     int64_t bx = (n + 511) / 512;
     if (bx > 128) bx = 128;             // each workgroup flushes its whole LDS table once
-    hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((int)bx, n_small), dim3(512), kLdsEntries * 8, as_stream(stream), pts, n, L, 0,
-                       d_feat, d_table);
+    hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((int)bx, hi - level0), dim3(512), kLdsEntries * 8, as_stream(stream), pts, n, L,
+                       level0, d_feat, d_table);
   }
-  if (n_small < n_levels) {
+  if (n_small < level1) {
     int64_t bx = (4 * n + 511) / 512;
     if (bx > 1024) bx = 1024;
-    int first = n_small, count = n_levels - n_small;
+    int first = level0 > n_small ? level0 : n_small, count = level1 - first;
     if (options().hash_bwd_only_level >= 0) {   // development aid: time one level's atomics
       first = options().hash_bwd_only_level;
       count = 1;
-      if (first < n_small || first >= n_levels) return check_launch("nerf_hash_encode_bwd");
+      if (first < n_small || first >= level1) return check_launch("nerf_hash_encode_bwd");
     }
     hipLaunchKernelGGL(hash_bwd_kernel<false>, dim3((int)bx, count), dim3(512), 0, as_stream(stream), pts, n, L,
                        first, d_feat, d_table);
   }
   return check_launch("nerf_hash_encode_bwd");
+}
+
+extern "C" int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                    const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                    const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                                    nerf_stream_t stream) {
+  return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table, 0,
+                       n_levels, stream);
+}
+
+extern "C" int nerf_hash_encode_bwd_levels(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                           const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                           const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                                           int first_level, int end_level, nerf_stream_t stream) {
+  return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table,
+                       first_level, end_level, stream);
 }

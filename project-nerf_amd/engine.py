@@ -104,7 +104,7 @@ class VanillaNerfEngine:
         return self._ws[key]
 
     # -- training step (reference run.py:314-338) ------------------------------
-    def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 64,
+    def compute_gradients(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 64,
                    u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, mark=None,
                    z: Optional[Tensor] = None) -> Tensor:
         """``z`` [R, n_samples]: jittered depths the caller already has (BlenderDataset.train_batch draws them
@@ -122,7 +122,8 @@ class VanillaNerfEngine:
         stash = self._buf("stash", ops.mlp_stash_bytes(n))
         rgb, sigma = ops.mlp_fwd(self.packed, rays_o, rays_d, z, stash)
         mark("fwd")
-        slot = self.step_count % self._scalars.shape[1]
+        self._grad_calls = getattr(self, "_grad_calls", -1) + 1
+        slot = self._grad_calls % self._scalars.shape[1]
         if slot == 0:
             self._scalars.zero_()
         loss, amax = self._scalars[0, slot:slot + 1], self._scalars[1, slot:slot + 1]
@@ -141,13 +142,26 @@ class VanillaNerfEngine:
                         self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)), amax=amax, mark=mark)
         mark("wgrad")
         if sync_grads is not None:
-            sync_grads(self.grads)            # RCCL all-reduce (sum); averaged by grad_scale below
+            sync_grads(self.grads)            # RCCL all-reduce (sum); averaged by grad_scale in apply_gradients
+        return loss[0]
+
+    def apply_gradients(self) -> None:
         self.step_count += 1
         ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                       grad_scale=self.grad_scale if self.world_size > 1 else None)
         self.repack()
-        mark("adam+pack")
-        return loss[0]
+
+    def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 64,
+                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, mark=None,
+                   z: Optional[Tensor] = None) -> Tensor:
+        """One step of reference run.py:314-338: gradients of the local batch (``self.grads``; summed over
+        ranks by the ``sync_grads*`` callbacks), then Adam and the weight repack."""
+        loss = self.compute_gradients(rays_o, rays_d, target, n_samples, u=u, sync_grads=sync_grads,
+                                      sync_grads_async=sync_grads_async, mark=mark, z=z)
+        self.apply_gradients()
+        if mark is not None:
+            mark("adam+pack")
+        return loss
 
     # -- inference (reference render_image, src/renderer.py:387-418) ------------
     @torch.no_grad()
@@ -246,8 +260,25 @@ class InstantNgpEngine:
                                          sigma.data_ptr(), 1 if train else 0, ops._stream()), "nerf_imlp_fwd")
         return rgb, sigma, ws
 
-    def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
-                   u: Optional[Tensor] = None, sync_grads=None) -> Tensor:
+    def level_groups(self, n_groups: int = 4):
+        """Level ranges of roughly equal table bytes: the hash backward runs group by group so that a
+        data-parallel caller can all-reduce one group's slice of the gradient while the next is computed."""
+        off = [int(o) for o in self.levels.offset] + [self.levels.entries]
+        cuts, target = [0], self.levels.entries / n_groups
+        for l in range(1, self.levels.n_levels):
+            if off[l] >= target * len(cuts) and len(cuts) < n_groups:
+                cuts.append(l)
+        cuts.append(self.levels.n_levels)
+        return [(cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1) if cuts[k] < cuts[k + 1]]
+
+    def compute_gradients(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
+                          u: Optional[Tensor] = None, sync_grads_async=None, reduce_dtype=None) -> Tensor:
+        """Forward + backward of one batch (reference run.py:579-619): fills ``g_table`` / ``g_net`` with the
+        gradients of the LOCAL mean-squared error and returns the loss.  ``sync_grads_async(view)`` (data
+        parallel) starts the all-reduce of a finished gradient range and returns a handle: the tiny-MLP
+        gradients go first, then the table gradient level group by level group, each on the wire while the
+        next group's scatter runs; ``reduce_dtype=torch.bfloat16`` halves the bytes on the wire (the table
+        gradient is 52 MB in fp32: a ring all-reduce over xGMI costs about half a step)."""
         lib = ops._lib.load()
         R = rays_o.shape[0]
         if u is None:
@@ -256,33 +287,52 @@ class InstantNgpEngine:
                                                  self.bound, u=u)
         n = pts.shape[0]
         self.g_table.zero_()
+        handles = []
+
+        def reduce(view):
+            if sync_grads_async is None:
+                return
+            if reduce_dtype is None or view.dtype == reduce_dtype:
+                handles.append((sync_grads_async(view), None, None))
+            else:
+                wire = view.to(reduce_dtype)                      # comm plumbing: narrow, sum, widen
+                handles.append((sync_grads_async(wire), wire, view))
+
         if n == 0:
             self.g_net.zero_()
             pred = self.bg.expand(R, 3)
             loss = ((pred - target) ** 2).mean()
+            reduce(self.g_net)
+            reduce(self.g_table)
         else:
             rgb, sigma, ws = self._field(pts, dirs, True)
-            bg_rows = 1
-            pred, depth, acc = (torch.empty(R, 3, device=self.device), torch.empty(R, device=self.device),
-                                torch.empty(R, device=self.device))
             P = lambda t: t.data_ptr()
-            ops._lib.check(lib.nerf_composite_fwd_indexed(P(rgb), P(sigma), P(slots), P(z), P(rays_d), P(self.bg), bg_rows,
-                                                          R, n_samples, P(pred), P(depth), P(acc), ops._stream()),
-                           "nerf_composite_fwd_indexed")
-            diff = pred - target
-            loss = (diff * diff).mean()
-            g_pred = (diff * (2.0 / diff.numel())).contiguous()
-            d_rgb, d_sigma = torch.empty_like(rgb), torch.empty_like(sigma)
-            ops._lib.check(lib.nerf_composite_bwd_indexed(P(rgb), P(sigma), P(slots), P(z), P(rays_d), P(self.bg), bg_rows,
-                                                          P(g_pred), None, None, R, n_samples, P(d_rgb), P(d_sigma),
-                                                          ops._stream()), "nerf_composite_bwd_indexed")
+            loss = torch.zeros(1, device=self.device)
+            d_rgb, d_sigma, _ = ops.composite_mse_bwd(rgb, sigma, z, rays_d, self.bg, target, loss, slots=slots)
             d_feat = torch.empty(n, 2 * self.levels.n_levels, device=self.device)
             ops._lib.check(lib.nerf_imlp_bwd(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
                                              P(self.g_net), P(d_feat), ops._stream()), "nerf_imlp_bwd")
-            ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table)
-        if sync_grads is not None:
-            sync_grads(self.g_table)
-            sync_grads(self.g_net)
+            reduce(self.g_net)
+            if sync_grads_async is None:
+                ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table)
+            else:
+                for lo, hi in self.level_groups():
+                    ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, level_range=(lo, hi))
+                    e0 = 2 * int(self.levels.offset[lo])
+                    e1 = 2 * (int(self.levels.offset[hi]) if hi < self.levels.n_levels else self.levels.entries)
+                    reduce(self.g_table[e0:e1])
+            loss = loss[0]
+        for h, wire, view in handles:
+            if h is not None:
+                h.wait()
+            if wire is not None:
+                view.copy_(wire)
+        return loss
+
+    def apply_gradients(self) -> None:
+        """TV-L1 + global-norm clip + AdamW on the table, clip + AdamW on the tiny MLPs, cosine LR
+        (reference run.py:611-630).  After a summing all-reduce the DATA gradient is averaged (1/world);
+        the TV term is added unscaled."""
         lr = self.lr()
         self.step_count += 1
         scale = 1.0 / self.world_size
@@ -291,6 +341,15 @@ class InstantNgpEngine:
         ops.tv_clip_adamw_step(self.net, self.g_net, *self.state["net"], self.step_count, lr, max_norm=1.0,
                                weight_decay=self.wd, grad_scale=scale, scratch=self._scratch)
         ops.imlp_pack(self.net, self.packed)
+
+    def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
+                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, reduce_dtype=None) -> Tensor:
+        loss = self.compute_gradients(rays_o, rays_d, target, n_samples, u=u, sync_grads_async=sync_grads_async,
+                                      reduce_dtype=reduce_dtype)
+        if sync_grads is not None:                # blocking form: two collectives after the backward pass
+            sync_grads(self.g_table)
+            sync_grads(self.g_net)
+        self.apply_gradients()
         return loss
 
     @torch.no_grad()

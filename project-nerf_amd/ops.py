@@ -487,11 +487,14 @@ def hash_encode_fwd(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: f
     return out, idx
 
 
-def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor, d_table: Tensor) -> None:
+def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor, d_table: Tensor,
+                    level_range: Optional[Tuple[int, int]] = None) -> None:
+    """Scatter-add into ``d_table`` (caller zeroes it); ``level_range`` (lo, hi) restricts the pass to those levels."""
     lib = _lib.load()
     pts, d_feat = _dev(pts, "pts"), _dev(d_feat, "d_feat")
-    _lib.check(lib.nerf_hash_encode_bwd(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
-                                        _p(d_feat), _p(d_table), _stream()), "nerf_hash_encode_bwd")
+    lo, hi = level_range if level_range is not None else (0, levels.n_levels)
+    _lib.check(lib.nerf_hash_encode_bwd_levels(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
+                                               _p(d_feat), _p(d_table), lo, hi, _stream()), "nerf_hash_encode_bwd")
 
 
 IMLP_PARAM_COUNT = 11264

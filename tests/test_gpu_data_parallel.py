@@ -1,0 +1,105 @@
+"""Data-parallel correctness on ONE GPU (pytest -m gpu): the kernels of a rank see only its ray shard, the
+all-reduce sums the shards' gradients and 1/world averages them.  Here the two "ranks" are two
+half-batches evaluated one after the other in this process -- no extra processes on the card -- and their
+summed, halved gradients must equal the gradient of the full batch, for both engines; then the
+reduce-callback protocol (asynchronous collectives per parameter range) is driven with a recording callback."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * 4.0311
+    tgt = (torch.rand(n, 3, generator=g) - 0.5) * 1.6
+    d = tgt - o
+    return o.cuda(), (d / d.norm(dim=-1, keepdim=True)).cuda(), torch.rand(n, 3, generator=g).cuda(), g
+
+
+def test_vanilla_shard_gradients_sum_to_full_batch_gradient():
+    from project_nerf_amd.engine import VanillaNerfEngine
+    from project_nerf_amd.parallel import shard_range
+    R, S, world = 512, 64, 2
+    o, d, target, g = _rays(R, 5)
+    u = torch.rand(R, S, generator=g).cuda()
+    eng = VanillaNerfEngine(seed=0)
+    loss_full = float(eng.compute_gradients(o, d, target, S, u=u))
+    full = eng.grads.clone()
+    acc, losses = torch.zeros_like(full), []
+    for rank in range(world):
+        lo, hi = shard_range(R, rank, world)
+        losses.append(float(eng.compute_gradients(o[lo:hi].contiguous(), d[lo:hi].contiguous(), target[lo:hi].contiguous(), S,
+                                                  u=u[lo:hi].contiguous())))
+        acc += eng.grads                                   # what the summing all-reduce leaves in the buffer
+    acc /= world                                           # grad_scale = 1/world in the optimiser kernel
+    assert abs(np.mean(losses) - loss_full) < 1e-5 * max(1.0, loss_full)
+    rel = float((acc - full).norm() / full.norm())
+    # not bit-identical: each launch derives its own e5m2 gradient scale from its own largest derivative, and float
+    # atomics sum in a different order
+    assert rel < 1e-2, rel
+
+
+def test_instant_shard_gradients_sum_to_full_batch_gradient():
+    from project_nerf_amd.engine import InstantNgpEngine
+    from project_nerf_amd.parallel import shard_range
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    R, S, world = 1024, 64, 2
+    o, d, target, g = _rays(R, 9)
+    u = torch.rand(R, S, generator=g).cuda()
+    eng = InstantNgpEngine(cfg, seed=0)
+    eng.table.copy_((torch.rand(eng.table.numel(), generator=g) - 0.5).cuda())      # visible densities and colours
+    eng.net[2048:2048 + 64] *= 20.0
+    from project_nerf_amd import ops
+    ops.imlp_pack(eng.net, eng.packed)
+    ax = torch.linspace(-1.5, 1.5, 128)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    eng.binary_grid = ((gx ** 2 + gy ** 2 + gz ** 2) < 1.2 ** 2).cuda()            # part of the samples skipped
+    loss_full = float(eng.compute_gradients(o, d, target, S, u=u))
+    full_t, full_n = eng.g_table.clone(), eng.g_net.clone()
+    acc_t, acc_n, losses = torch.zeros_like(full_t), torch.zeros_like(full_n), []
+    seen = []
+    for rank in range(world):
+        lo, hi = shard_range(R, rank, world)
+        # the data-parallel form: gradient ranges handed to the reduce callback as soon as they are complete
+        losses.append(float(eng.compute_gradients(o[lo:hi].contiguous(), d[lo:hi].contiguous(), target[lo:hi].contiguous(), S,
+                                                  u=u[lo:hi].contiguous(), sync_grads_async=lambda v: seen.append(v.numel()))))
+        acc_t += eng.g_table
+        acc_n += eng.g_net
+    acc_t /= world
+    acc_n /= world
+    assert abs(np.mean(losses) - loss_full) < 1e-5 * max(1.0, loss_full)
+    assert float(full_t.norm()) > 0 and float(full_n.norm()) > 0
+    assert float((acc_t - full_t).norm() / full_t.norm()) < 1e-4
+    assert float((acc_n - full_n).norm() / full_n.norm()) < 1e-3
+    # every rank handed over the tiny-MLP gradients first, then level groups that tile the whole table exactly once
+    per_rank = len(seen) // world
+    assert seen[0] == eng.g_net.numel() and sum(seen[1:per_rank]) == eng.g_table.numel() and per_rank >= 3
+
+
+def test_tv_weight_is_independent_of_world_size_in_the_engine():
+    """One step of an engine that believes it is 1 of 4 ranks, fed the gradient of 4 identical shards (sum = 4 g),
+    must equal one single-rank step with g: in particular the TV term keeps its weight (reference run.py:611-618)."""
+    from project_nerf_amd.engine import InstantNgpEngine
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    cfg["tv_loss_weight"] = 1e-2
+    o, d, target, g = _rays(256, 3)
+    u = torch.rand(256, 64, generator=g).cuda()
+    outs = []
+    for world in (1, 4):
+        eng = InstantNgpEngine(cfg, seed=0, world_size=world)
+        eng.table.copy_((torch.rand(eng.table.numel(), generator=torch.Generator().manual_seed(1)) - 0.5).cuda() * 0.1)
+        eng.compute_gradients(o, d, target, 64, u=u)
+        eng.g_table *= world
+        eng.g_net *= world                                  # the summing all-reduce over identical shards
+        eng.apply_gradients()
+        outs.append((eng.table.clone(), eng.net.clone()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-6
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-6

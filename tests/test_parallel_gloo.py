@@ -52,6 +52,63 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _overlap_worker(rank, world, port, out):
+    """ops.mlp_bwd_overlapped and InstantNgpEngine.compute_gradients drive their reduce callback with REAL
+    asynchronous gloo collectives; the kernels are replaced by a recording stand-in that fills the gradient
+    ranges (no GPU here): order of launches and collectives, ranges, waits."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import ops, parallel as P
+    P.init_distributed("cpu")
+    n_params = ops.MLP_PARAM_COUNT
+    split = 300000
+    grads = torch.zeros(n_params)
+    log = []
+
+    class FakeLib:
+        def nerf_mlp_bwd_dgrad_ex(self, *a):
+            log.append("dgrad")
+            return 0
+
+        def nerf_mlp_wgrad_part_split(self):
+            return split
+
+        def nerf_mlp_bwd_wgrad_part(self, stash, ws, n, g, part, stream):
+            log.append(f"wgrad{part}")
+            (grads[split:] if part == 1 else grads[:split]).fill_(float(rank + 1) * part)
+            return 0
+
+    real_load, real_stream = ops._lib.load, ops._stream
+    ops._lib.load, ops._stream = (lambda: FakeLib()), (lambda: 0)
+    try:
+        class T:                                            # stands in for device tensors: only data_ptr / numel are used
+            def data_ptr(self): return 0
+            def numel(self): return 64
+
+        def reduce_async(view):
+            log.append(f"reduce{view.numel()}")
+            return P.allreduce_sum_async(view)
+        ops.mlp_bwd_overlapped(T(), T(), T(), T(), T(), T(), grads, T(), reduce_async)
+    finally:
+        ops._lib.load, ops._stream = real_load, real_stream
+    want_order = ["dgrad", "wgrad1", f"reduce{n_params - split}", "wgrad2", f"reduce{split}"]
+    tot = sum(range(1, world + 1))
+    ok = log == want_order and bool((grads[split:] == tot * 1.0).all()) and bool((grads[:split] == tot * 2.0).all())
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world_size_2_overlapped_backward_callback_protocol():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_overlap_worker, args=(2, port, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
 def test_shard_range_partitions():
     import project_nerf_amd  # noqa: F401
     from project_nerf_amd.parallel import shard_range
