@@ -211,6 +211,12 @@ int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, c
                  int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
                  nerf_stream_t stream);
 
+/* The decoder as a stand-alone operator on ALREADY ENCODED inputs -- BaseDecoder.forward(x_enc, d_enc) of
+ * src/decoders.py:68-87: x_enc [n,63] = FourierRepresentation(L=10) of the positions, d_enc [n,27] =
+ * FourierRepresentation(L=4) of the view directions, fp32 row-major.  stash as in nerf_mlp_fwd. */
+int nerf_mlp_fwd_encoded(const void* packed, const float* x_enc, const float* d_enc, int64_t n, float* rgb,
+                         float* sigma, void* stash, nerf_stream_t stream);
+
 /* Backward of nerf_mlp_fwd (autograd of src/decoders.py:68-87; the loss.backward() of
  * run.py:337 for the decoder).  rgb/sigma are the forward outputs, d_rgb [n,3] / d_sigma [n]
  * the upstream gradients; grads_f32 [595844] (same layout as the parameter vector) is
@@ -288,6 +294,11 @@ size_t nerf_imlp_hash_operand_offset(int64_t n);
 int nerf_imlp_pack(const float* params_f32, void* packed, nerf_stream_t stream);
 int nerf_imlp_fwd(const void* packed, void* workspace, const float* dirs, int64_t n, float* rgb,
                   float* sigma, int train, nerf_stream_t stream);
+/* InstantNeRFDecoder.forward(x_enc, d_enc) (src/decoders.py:136-162) on already encoded inputs: x_enc [n,32]
+ * hash features, d_enc [n,27] direction codes, fp32 row-major; same workspace and backward
+ * (nerf_imlp_bwd: d_feat is then the gradient with respect to x_enc). */
+int nerf_imlp_fwd_encoded(const void* packed, void* workspace, const float* x_enc, const float* d_enc, int64_t n,
+                          float* rgb, float* sigma, int train, nerf_stream_t stream);
 int nerf_imlp_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma,
                   const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
                   float* d_feat, nerf_stream_t stream);

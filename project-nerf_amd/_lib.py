@@ -45,6 +45,7 @@ PROTOTYPES = {
     "nerf_mlp_pack": (i32, [c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_stash_bytes": (size_t, [i64]),
     "nerf_mlp_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_mlp_fwd_encoded": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_bwd_workspace_bytes": (size_t, [i64]),
     "nerf_mlp_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_bwd_dgrad": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
@@ -62,6 +63,7 @@ PROTOTYPES = {
     "nerf_imlp_hash_operand_offset": (size_t, [i64]),
     "nerf_imlp_pack": (i32, [c_ptr, c_ptr, c_ptr]),
     "nerf_imlp_fwd": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
+    "nerf_imlp_fwd_encoded": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
     "nerf_imlp_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_adam_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, c_ptr]),
     "nerf_tv_normsq": (i32, [c_ptr, c_ptr, i64, f32, f32, c_ptr, c_ptr]),

@@ -78,6 +78,9 @@ struct IArgs {
   const char* packed;
   const __bf16* hash_nat;   // nat blocks [n_pad,32] from nerf_hash_encode_fwd
   const float* dirs;        // [n,3] unit view directions
+  const float* x_enc;       // encoded entry (InstantNeRFDecoder.forward(x_enc, d_enc)): [n,32] hash features and
+  const float* d_enc;       // [n,27] direction codes given by the caller; NULL: hash_nat image + dirs
+  __bf16* hash_nat_out;     // encoded entry, training: the feature image the wgrad pass reads is written here
   int64_t n, n_pad;
   float* rgb;               // [n,3]
   float* sigma;             // [n]
@@ -117,12 +120,21 @@ __global__ void __launch_bounds__(kIThreads) imlp_fwd_kernel(const IArgs a) {
     const int64_t wt = tile * 4 + wave, n = wt * 32 + col;
     const bool live = n < a.n;
     const int64_t nc = live ? n : a.n - 1;
-    bf16x8 hin[2];
+    bf16x8 hin[2], denc[2];
+    if (a.x_enc != nullptr) {
+      // already-encoded inputs (src/decoders.py:136-162 as a stand-alone operator)
+      encoded_operand<2, 32>(a.x_enc + nc * 32, half, hin);
+      encoded_operand<2, plan::kDirDim>(a.d_enc + nc * plan::kDirDim, half, denc);
+      if constexpr (TRAIN) {
+        stash_nat(a.hash_nat_out, wt, 2, 0, col, half, hin[0]);
+        stash_nat(a.hash_nat_out, wt, 2, 1, col, half, hin[1]);
+      }
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      hin[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(a.hash_nat) + ((wt * 2 + ks) * 64 + 2 * col + half) * 16);
-    bf16x8 denc[2];
-    fourier_operand<2, plan::kDirDim>(a.dirs[nc * 3 + 0], a.dirs[nc * 3 + 1], a.dirs[nc * 3 + 2], half, denc);
+      for (int ks = 0; ks < 2; ++ks)
+        hin[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(a.hash_nat) + ((wt * 2 + ks) * 64 + 2 * col + half) * 16);
+      fourier_operand<2, plan::kDirDim>(a.dirs[nc * 3 + 0], a.dirs[nc * 3 + 1], a.dirs[nc * 3 + 2], half, denc);
+    }
     if constexpr (TRAIN) {
       stash_nat(a.denc, wt, 2, 0, col, half, denc[0]);
       stash_nat(a.denc, wt, 2, 1, col, half, denc[1]);
@@ -295,6 +307,21 @@ extern "C" int nerf_imlp_fwd(const void* packed, void* workspace, const float* d
   if (train) hipLaunchKernelGGL(imlp_fwd_kernel<true>, dim3(grid), dim3(kIThreads), kIFwdFrags * 1024, as_stream(stream), a);
   else hipLaunchKernelGGL(imlp_fwd_kernel<false>, dim3(grid), dim3(kIThreads), kIFwdFrags * 1024, as_stream(stream), a);
   return check_launch("nerf_imlp_fwd");
+}
+
+extern "C" int nerf_imlp_fwd_encoded(const void* packed, void* workspace, const float* x_enc, const float* d_enc, int64_t n,
+                                     float* rgb, float* sigma, int train, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0, "nerf_imlp_fwd_encoded: n=%lld", (long long)n);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(packed && workspace && x_enc && d_enc && rgb && sigma && ((uintptr_t)workspace & 255) == 0, "nerf_imlp_fwd_encoded: bad pointer");
+  IArgs a = iargs(packed, workspace, nullptr, n, rgb, sigma);
+  a.x_enc = x_enc; a.d_enc = d_enc;
+  a.hash_nat_out = const_cast<__bf16*>(a.hash_nat);
+  const int grid = grid_for_tiles(a.n_pad / kITile);
+  if (grid <= 0) return fail(NERF_ELAUNCH, "nerf_imlp_fwd_encoded: cannot query device");
+  if (train) hipLaunchKernelGGL(imlp_fwd_kernel<true>, dim3(grid), dim3(kIThreads), kIFwdFrags * 1024, as_stream(stream), a);
+  else hipLaunchKernelGGL(imlp_fwd_kernel<false>, dim3(grid), dim3(kIThreads), kIFwdFrags * 1024, as_stream(stream), a);
+  return check_launch("nerf_imlp_fwd_encoded");
 }
 
 extern "C" int nerf_imlp_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma,

@@ -344,4 +344,19 @@ __device__ __forceinline__ void fourier_operand(float x0, float x1, float x2, in
   }
 }
 
+// B fragments (natural k order) of an ALREADY ENCODED feature row (the BaseDecoder.forward(x_enc, d_enc)
+// entry of the reference, src/decoders.py:68-87): feature f = 16*ks + 8*half + j; column VALID carries
+// the constant 1 of the wgrad bias trick, columns beyond it are zero
+template <int KS, int VALID>
+__device__ __forceinline__ void encoded_operand(const float* __restrict__ row, int half, bf16x8 (&out)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = 16 * ks + 8 * half + j;
+      out[ks][j] = (__bf16)(f < VALID ? row[f] : (f == VALID ? 1.0f : 0.0f));
+    }
+  }
+}
+
 }  // namespace nerf

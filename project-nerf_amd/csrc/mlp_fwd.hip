@@ -38,6 +38,34 @@ struct FwdArgs {
   unsigned long long* dbg_cycles;   // development aid (NERF_FWD_CYCLES): [0] += shader cycles in passes, [1] += passes
 };
 
+// a2 + a5 of one sample: position / unit view direction (ray mode: o + d z; point mode: as given) and
+// their Fourier codes straight into MFMA B fragments; encoded mode (n_samples < 0): rays_o = x_enc [n,63],
+// rays_d = d_enc [n,27] are the codes themselves (BaseDecoder.forward(x_enc, d_enc), src/decoders.py:68)
+__device__ __forceinline__ void sample_operands(const FwdArgs& a, int64_t nc, int half, bf16x8 (&xenc)[4], bf16x8 (&denc)[2]) {
+  if (a.n_samples < 0) {
+    encoded_operand<4, kPosDim>(a.rays_o + nc * kPosDim, half, xenc);
+    encoded_operand<2, kDirDim>(a.rays_d + nc * kDirDim, half, denc);
+    return;
+  }
+  float px, py, pz, vx, vy, vz;
+  if (a.n_samples > 0) {
+    const int64_t ray = (uint32_t)nc / (uint32_t)a.n_samples;
+    const float zz = a.z[nc];
+    const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
+    const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+    px = add_rn(ox, mul_rn(dx, zz));
+    py = add_rn(oy, mul_rn(dy, zz));
+    pz = add_rn(oz, mul_rn(dz, zz));
+    const float nrm = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
+    vx = (dx / nrm); vy = (dy / nrm); vz = (dz / nrm);
+  } else {
+    px = a.rays_o[nc * 3 + 0]; py = a.rays_o[nc * 3 + 1]; pz = a.rays_o[nc * 3 + 2];
+    vx = a.rays_d[nc * 3 + 0]; vy = a.rays_d[nc * 3 + 1]; vz = a.rays_d[nc * 3 + 2];
+  }
+  fourier_operand<4, kPosDim>(px, py, pz, half, xenc);
+  fourier_operand<2, kDirDim>(vx, vy, vz, half, denc);
+}
+
 template <bool TRAIN>
 __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -61,27 +89,9 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_kernel(const FwdArgs
     const bool live = n < a.n;
     const int64_t nc = live ? n : a.n - 1;
 
-    // ---- a2: sample position and unit view direction ----
-    float px, py, pz, vx, vy, vz;
-    if (a.n_samples > 0) {
-      const int64_t ray = (uint32_t)nc / (uint32_t)a.n_samples;
-      const float zz = a.z[nc];
-      const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
-      const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
-      px = add_rn(ox, mul_rn(dx, zz));
-      py = add_rn(oy, mul_rn(dy, zz));
-      pz = add_rn(oz, mul_rn(dz, zz));
-      const float nrm = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
-      vx = (dx / nrm); vy = (dy / nrm); vz = (dz / nrm);
-    } else {
-      px = a.rays_o[nc * 3 + 0]; py = a.rays_o[nc * 3 + 1]; pz = a.rays_o[nc * 3 + 2];
-      vx = a.rays_d[nc * 3 + 0]; vy = a.rays_d[nc * 3 + 1]; vz = a.rays_d[nc * 3 + 2];
-    }
-
-    // ---- a5: Fourier codes straight into MFMA B fragments ----
+    // ---- a2 + a5: sample geometry and Fourier codes straight into MFMA B fragments ----
     bf16x8 xenc[4], denc[2];
-    fourier_operand<4, kPosDim>(px, py, pz, half, xenc);
-    fourier_operand<2, kDirDim>(vx, vy, vz, half, denc);
+    sample_operands(a, nc, half, xenc, denc);
     const int64_t wave_tile = tile * 8 + wave;
     if constexpr (TRAIN) {
 #pragma unroll
@@ -223,24 +233,8 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
     const int64_t n = tile * kTileSamples + wave * kWaveSamples + col;
     const bool live = n < a.n;
     const int64_t nc = live ? n : a.n - 1;
-    float px, py, pz, vx, vy, vz;
-    if (a.n_samples > 0) {
-      const int64_t ray = (uint32_t)nc / (uint32_t)a.n_samples;
-      const float zz = a.z[nc];
-      const float ox = a.rays_o[ray * 3 + 0], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
-      const float dx = a.rays_d[ray * 3 + 0], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
-      px = add_rn(ox, mul_rn(dx, zz));
-      py = add_rn(oy, mul_rn(dy, zz));
-      pz = add_rn(oz, mul_rn(dz, zz));
-      const float nrm = sqrtf(add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz)));
-      vx = (dx / nrm); vy = (dy / nrm); vz = (dz / nrm);
-    } else {
-      px = a.rays_o[nc * 3 + 0]; py = a.rays_o[nc * 3 + 1]; pz = a.rays_o[nc * 3 + 2];
-      vx = a.rays_d[nc * 3 + 0]; vy = a.rays_d[nc * 3 + 1]; vz = a.rays_d[nc * 3 + 2];
-    }
     bf16x8 xenc[4], denc[2];
-    fourier_operand<4, kPosDim>(px, py, pz, half, xenc);
-    fourier_operand<2, kDirDim>(vx, vy, vz, half, denc);
+    sample_operands(a, nc, half, xenc, denc);
 
     float sg, cr, cg, cb;
     if constexpr (TRAIN) {
@@ -278,14 +272,14 @@ using namespace nerf;
 
 extern "C" size_t nerf_mlp_stash_bytes(int64_t n) { return n > 0 ? stash_layout(n).total : 0; }
 
-extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* z,
-                            int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
-                            nerf_stream_t stream) {
+static int mlp_fwd_impl(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                        int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
+                        nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "nerf_mlp_fwd: n=%lld out of range", (long long)n);
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(packed && rays_o && rays_d && rgb && sigma, "nerf_mlp_fwd: NULL pointer");
-  NERF_REQUIRE((n_samples == 0) == (z == nullptr), "nerf_mlp_fwd: z must be given exactly in ray mode");
-  NERF_REQUIRE(n_samples >= 0 && (n_samples == 0 || n % n_samples == 0),
+  NERF_REQUIRE((n_samples <= 0) == (z == nullptr), "nerf_mlp_fwd: z must be given exactly in ray mode");
+  NERF_REQUIRE(n_samples <= 0 || n % n_samples == 0,
                "nerf_mlp_fwd: n=%lld is not a multiple of n_samples=%d", (long long)n, n_samples);
   NERF_REQUIRE(((uintptr_t)packed & 255) == 0 && ((uintptr_t)stash & 255) == 0,
                "nerf_mlp_fwd: packed/stash must be 256-byte aligned");
@@ -334,4 +328,16 @@ extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float
             h[1] ? (double)h[0] / (double)h[1] : 0.0, h[1]);
   }
   return check_launch("nerf_mlp_fwd");
+}
+
+extern "C" int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* z,
+                            int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
+                            nerf_stream_t stream) {
+  NERF_REQUIRE(n_samples >= 0, "nerf_mlp_fwd: n_samples=%d", n_samples);
+  return mlp_fwd_impl(packed, rays_o, rays_d, z, n, n_samples, rgb, sigma, stash, stream);
+}
+
+extern "C" int nerf_mlp_fwd_encoded(const void* packed, const float* x_enc, const float* d_enc, int64_t n, float* rgb,
+                                    float* sigma, void* stash, nerf_stream_t stream) {
+  return mlp_fwd_impl(packed, x_enc, d_enc, nullptr, n, -1, rgb, sigma, stash, stream);
 }

@@ -27,16 +27,20 @@ class StandardMLP(BaseDecoder):
 
 class NeRFDecoder(BaseDecoder):
     """8x256 MLP with skip at layer 4, sigma / feature heads, 128-wide view branch
-    (reference src/decoders.py:29-87).  The HIP kernels are specialised for the reference
-    defaults (pos 63, dir 27, hidden 256, 8 layers, skip 4, view 128)."""
+    (reference src/decoders.py:29-87).  The HIP kernels are specialised for the reference's
+    architecture (hidden 256, 8 layers, skip 4, view 128) with up to L_embed 10 / L_embed_dir 4
+    frequency bands: a narrower code is a PREFIX of the 63 / 27-wide one (src/embeddings.py:28-32), so its
+    weight matrices are zero-padded to the compiled width and the extra code columns contribute nothing."""
 
     def __init__(self, pos_dim, dir_dim, hidden_dim=256, num_layers=8, skip_layer=4, view_dim=128):
         super().__init__()
-        if (pos_dim, dir_dim, hidden_dim, num_layers, skip_layer, view_dim) != (63, 27, 256, 8, 4, 128):
+        ok_dims = lambda dim, max_l: dim in [3 + 6 * l for l in range(max_l + 1)]
+        if (hidden_dim, num_layers, skip_layer, view_dim) != (256, 8, 4, 128) or not ok_dims(pos_dim, 10) or not ok_dims(dir_dim, 4):
             raise NotImplementedError(
-                "libnerf_hip is compiled for L_embed 10 / L_embed_dir 4 / hidden 256 / 8 layers / skip 4 / "
-                f"view 128; got pos {pos_dim}, dir {dir_dim}, hidden {hidden_dim}, layers {num_layers}, "
-                f"skip {skip_layer}, view {view_dim}")
+                "libnerf_hip is compiled for hidden 256 / 8 layers / skip 4 / view 128 and Fourier codes of up to "
+                f"L_embed 10 / L_embed_dir 4 bands (3 + 6 L columns); got pos {pos_dim}, dir {dir_dim}, hidden {hidden_dim}, "
+                f"layers {num_layers}, skip {skip_layer}, view {view_dim}")
+        self.pos_dim, self.dir_dim = pos_dim, dir_dim
         self.skip_layer = skip_layer
         layers = []
         for i in range(num_layers):
@@ -53,8 +57,17 @@ class NeRFDecoder(BaseDecoder):
         self._packed_version = None
 
     def flat_parameters(self):
-        """One fp32 vector in registration (= state_dict) order; autograd splits its gradient back."""
-        return torch.cat([p.reshape(-1) for p in self.parameters()])
+        """One fp32 vector in registration (= state_dict) order with the compiled 63 / 27-wide code columns
+        (narrower codes: zero-padded columns); autograd splits / slices its gradient back."""
+        pad = torch.nn.functional.pad
+        parts = []
+        for name, p in self.named_parameters():
+            if name in ("pts_layers.0.weight", f"pts_layers.{self.skip_layer}.weight") and self.pos_dim < 63:
+                p = pad(p, (0, 63 - self.pos_dim))
+            elif name == "view_layer.weight" and self.dir_dim < 27:
+                p = pad(p, (0, 27 - self.dir_dim))
+            parts.append(p.reshape(-1))
+        return torch.cat(parts)
 
     def packed_weights(self):
         """bf16 fragment streams, rebuilt whenever any parameter was modified in place."""
@@ -70,10 +83,15 @@ class NeRFDecoder(BaseDecoder):
         rgb, sigma = ops.decoder(self.flat_parameters(), self.packed_weights(), pts, dirs, z)
         return rgb, sigma.unsqueeze(-1)
 
-    def forward(self, x, d):
-        raise NotImplementedError(
-            "NeRFDecoder consumes raw coordinates through the fused kernel: call NeuralField(x, d) or "
-            "NeRFDecoder.field(pts, dirs); separately encoded inputs are not a supported entry point")
+    def forward(self, x_enc, d_enc):
+        """reference src/decoders.py:68-87: rgb [N,3], sigma [N,1] from the encoded position / direction.
+        (NeuralField takes the fused path ``field`` -- the codes are then formed in registers.)"""
+        if x_enc.shape[-1] != self.pos_dim or d_enc.shape[-1] != self.dir_dim:
+            raise ValueError(f"expected x_enc [N,{self.pos_dim}] and d_enc [N,{self.dir_dim}]")
+        pad = torch.nn.functional.pad
+        rgb, sigma = ops.decoder_encoded(self.flat_parameters(), self.packed_weights(), pad(x_enc, (0, 63 - self.pos_dim)),
+                                         pad(d_enc, (0, 27 - self.dir_dim)))
+        return rgb, sigma.unsqueeze(-1)
 
 
 class InstantNeRFDecoder(BaseDecoder):
@@ -108,4 +126,6 @@ class InstantNeRFDecoder(BaseDecoder):
         return self._packed
 
     def forward(self, x_enc, d_enc):
-        raise NotImplementedError("the Instant decoder runs fused with the hash encoding: call NeuralField(x, d)")
+        """reference src/decoders.py:136-162: sigma = softplus(h0 - 5), rgb = colour-net(cat([h16, d_enc]))."""
+        rgb, sigma = ops.instant_decoder_encoded(self.flat_parameters(), self.packed_weights(), x_enc, d_enc)
+        return rgb, sigma.unsqueeze(-1)

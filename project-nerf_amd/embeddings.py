@@ -60,9 +60,8 @@ class HashRepresentation(BaseRepresentation):
         return self.encoding.params.view(-1, 2)
 
     def forward(self, x):
-        if x.requires_grad or self.encoding.params.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("differentiate through NeuralField (fused hash + decoder), not the bare encoding")
-        return ops.hash_encode_fwd(x, self.table(), self.levels, self.bound)[0]
+        """reference src/embeddings.py:75-89 (normalise to [0,1], clamp, encode); differentiable w.r.t. the table."""
+        return ops.hash_encode(self.table(), x, self.levels, self.bound)
 
     @property
     def out_dim(self):

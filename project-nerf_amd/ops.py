@@ -434,6 +434,41 @@ class _Decoder(torch.autograd.Function):
         return grads, None, None, None, None
 
 
+class _DecoderEncoded(torch.autograd.Function):
+    """NeRFDecoder.forward(x_enc, d_enc) (reference src/decoders.py:68-87): the same chain kernels fed with the
+    caller's encodings; differentiable w.r.t. the flat parameter vector."""
+
+    @staticmethod
+    def forward(ctx, params, packed, x_enc, d_enc, train):
+        lib = _lib.load()
+        n = x_enc.shape[0]
+        rgb = torch.empty(n, 3, device=x_enc.device)
+        sigma = torch.empty(n, device=x_enc.device)
+        stash = torch.empty(mlp_stash_bytes(n), device=x_enc.device, dtype=torch.uint8) if train else None
+        _lib.check(lib.nerf_mlp_fwd_encoded(_p(packed), _p(x_enc), _p(d_enc), n, _p(rgb), _p(sigma), _p(stash), _stream()),
+                   "nerf_mlp_fwd_encoded")
+        if train:
+            ctx.save_for_backward(packed, stash, rgb, sigma)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        packed, stash, rgb, sigma = ctx.saved_tensors
+        return mlp_bwd(packed, stash, rgb, sigma, d_rgb.contiguous(), d_sigma.contiguous()), None, None, None, None
+
+
+def decoder_encoded(params: Tensor, packed: Tensor, x_enc: Tensor, d_enc: Tensor):
+    x_enc, d_enc = _dev(x_enc, "x_enc"), _dev(d_enc, "d_enc")
+    if x_enc.shape[1] != 63 or d_enc.shape[1] != 27 or x_enc.shape[0] != d_enc.shape[0]:
+        raise ValueError(f"expected x_enc [n,63] and d_enc [n,27], got {tuple(x_enc.shape)} and {tuple(d_enc.shape)}")
+    if x_enc.requires_grad or d_enc.requires_grad:
+        raise NotImplementedError("gradients w.r.t. the Fourier codes are not produced (positions are not trainable)")
+    if x_enc.shape[0] == 0:
+        return x_enc.new_zeros(0, 3), x_enc.new_zeros(0)
+    train = torch.is_grad_enabled() and params.requires_grad
+    return _DecoderEncoded.apply(params, packed, x_enc, d_enc, train)
+
+
 def decoder(params: Tensor, packed: Tensor, rays_o: Tensor, rays_d: Tensor, z: Optional[Tensor]):
     """rgb [n,3], sigma [n]; differentiable w.r.t. the flat parameter vector when it requires grad."""
     if torch.is_grad_enabled() and params.requires_grad:
@@ -542,6 +577,74 @@ class _InstantField(torch.autograd.Function):
         g_table = torch.zeros(ctx.table_shape, device=pts.device)
         hash_encode_bwd(pts, ctx.levels, ctx.bound, d_feat, g_table)
         return g_table, g_net, None, None, None, None, None, None
+
+
+class _HashEncode(torch.autograd.Function):
+    """HashRepresentation.forward as a stand-alone differentiable operator (table gradient only)."""
+
+    @staticmethod
+    def forward(ctx, table, pts, levels, bound):
+        out, _ = hash_encode_fwd(pts, table, levels, bound)
+        ctx.save_for_backward(pts)
+        ctx.levels, ctx.bound, ctx.table_shape = levels, bound, table.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (pts,) = ctx.saved_tensors
+        g = torch.zeros(ctx.table_shape, device=pts.device)
+        hash_encode_bwd(pts, ctx.levels, ctx.bound, d_out.contiguous(), g)
+        return g, None, None, None
+
+
+def hash_encode(table: Tensor, pts: Tensor, levels: HashLevelTable, bound: float) -> Tensor:
+    """features [n, 2 L] fp32, differentiable w.r.t. ``table`` [entries, 2]."""
+    pts = _dev(pts, "pts")
+    if pts.requires_grad:
+        raise NotImplementedError("gradients w.r.t. the encoded positions belong to the dynamic (Part 3/4) fields")
+    if pts.shape[0] == 0:
+        return pts.new_zeros(0, 2 * levels.n_levels)
+    if torch.is_grad_enabled() and table.requires_grad:
+        return _HashEncode.apply(table, pts, levels, bound)
+    return hash_encode_fwd(pts, table, levels, bound)[0]
+
+
+class _InstantDecoderEncoded(torch.autograd.Function):
+    """InstantNeRFDecoder.forward(x_enc, d_enc) (reference src/decoders.py:136-162): differentiable w.r.t. the
+    flat tiny-MLP parameters and the hash features."""
+
+    @staticmethod
+    def forward(ctx, net_params, packed, x_enc, d_enc, train):
+        lib = _lib.load()
+        n = x_enc.shape[0]
+        ws = torch.empty(lib.nerf_imlp_workspace_bytes(n), device=x_enc.device, dtype=torch.uint8)
+        rgb, sigma = torch.empty(n, 3, device=x_enc.device), torch.empty(n, device=x_enc.device)
+        _lib.check(lib.nerf_imlp_fwd_encoded(_p(packed), _p(ws), _p(x_enc), _p(d_enc), n, _p(rgb), _p(sigma), 1 if train else 0,
+                                             _stream()), "nerf_imlp_fwd_encoded")
+        if train:
+            ctx.save_for_backward(packed, ws, rgb, sigma)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_sigma):
+        lib = _lib.load()
+        packed, ws, rgb, sigma = ctx.saved_tensors
+        n = rgb.shape[0]
+        g_net = torch.empty(IMLP_PARAM_COUNT, device=rgb.device)
+        d_feat = torch.empty(n, 32, device=rgb.device)
+        _lib.check(lib.nerf_imlp_bwd(_p(packed), _p(ws), _p(rgb), _p(sigma), _p(d_rgb.contiguous()), _p(d_sigma.contiguous()), n,
+                                     _p(g_net), _p(d_feat), _stream()), "nerf_imlp_bwd")
+        return g_net, None, d_feat, None, None
+
+
+def instant_decoder_encoded(net_params: Tensor, packed: Tensor, x_enc: Tensor, d_enc: Tensor):
+    x_enc, d_enc = _dev(x_enc.float(), "x_enc"), _dev(d_enc, "d_enc")
+    if x_enc.shape[1] != 32 or d_enc.shape[1] != 27 or x_enc.shape[0] != d_enc.shape[0]:
+        raise ValueError(f"expected x_enc [n,32] and d_enc [n,27], got {tuple(x_enc.shape)} and {tuple(d_enc.shape)}")
+    if x_enc.shape[0] == 0:
+        return x_enc.new_zeros(0, 3), x_enc.new_zeros(0)
+    train = torch.is_grad_enabled() and (net_params.requires_grad or x_enc.requires_grad)
+    return _InstantDecoderEncoded.apply(net_params, packed, x_enc, d_enc, train)
 
 
 def instant_field(table: Tensor, net_params: Tensor, packed: Tensor, pts: Tensor, dirs: Tensor,

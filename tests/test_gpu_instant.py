@@ -362,3 +362,35 @@ def test_density_grid_update_around_instant_field_vs_reference_golden():
     flips = int((dg.binary_grid.cpu().numpy() != g["binary"]).sum())
     assert flips <= 0.01 * g["binary"].sum(), flips            # cells whose sigma sits at the threshold (bf16)
     assert abs(ratio - float(g["ratio"])) < 0.005
+
+
+def test_instant_operators_compose_like_the_fused_field():
+    """reference src/core.py:357-359 evaluates decoder(representation(x), dir_representation(d)); the classes at the
+    reference's module paths (src.embeddings.HashRepresentation, src.decoders.InstantNeRFDecoder) are callable on
+    their own and differentiable -- values and gradients against the fused NeuralField path and golden g13."""
+    from src.decoders import InstantNeRFDecoder
+    from src.embeddings import FourierRepresentation, HashRepresentation
+    model, g = _glue_model()
+    assert isinstance(model.representation, HashRepresentation) and isinstance(model.decoder, InstantNeRFDecoder)
+    assert isinstance(model.dir_representation, FourierRepresentation)
+    pts, dirs = torch.from_numpy(g["pts"]).cuda(), torch.from_numpy(g["dirs"]).cuda()
+    w = torch.randn(700, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    res = []
+    for fused in (True, False):
+        model.zero_grad()
+        if fused:
+            rgb, sigma = model(pts, dirs)
+        else:
+            x_enc = model.representation(pts)
+            assert x_enc.requires_grad and x_enc.shape == (700, 32)
+            rgb, sigma = model.decoder(x_enc, model.dir_representation(dirs))
+        assert rgb.shape == (700, 3) and sigma.shape == (700, 1)
+        ((rgb * w).sum() + sigma.sum()).backward()
+        res.append((rgb.detach(), sigma.detach(), model.representation.encoding.params.grad.clone(),
+                    torch.cat([model.decoder.sigma_net.params.grad, model.decoder.color_net.params.grad])))
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), g["rgb"], atol=4e-2)
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), res[0][0].cpu().numpy(), atol=1e-2)
+    np.testing.assert_allclose(res[1][1].cpu().numpy(), res[0][1].cpu().numpy(), rtol=5e-2, atol=1e-2 * float(res[0][1].max()))
+    for k in (2, 3):
+        a, b = res[1][k], res[0][k]
+        assert float((a - b).norm() / b.norm()) < 5e-2, k

@@ -286,3 +286,71 @@ def test_train_batch_kernel_statistics_and_formulas(tmp_path):
         assert torch.equal(target[sel], want)                               # same roundings as run.py:317-322
         rows = pix // ds.W
         assert 0 <= int(rows.min()) and int(rows.max()) < ds.H
+
+
+# ------------------------------------------------------------------ operator surface
+def test_nerf_decoder_forward_on_encoded_inputs(field):
+    """BaseDecoder.forward(x_enc, d_enc) of reference src/decoders.py:68-87: the separable chain
+    decoder(representation(x), dir_representation(d)) -- what reference core.py:357-359 evaluates -- against the
+    fused entry and the reference's golden, values and parameter gradients."""
+    import copy
+    g = golden("g4_decoder")
+    model = copy.deepcopy(field)
+    pts, dirs = T(g["pts"]).cuda(), T(g["dirs"]).cuda()
+    with torch.no_grad():
+        x_enc, d_enc = model.representation(pts), model.dir_representation(dirs)
+        assert x_enc.shape == (512, 63) and d_enc.shape == (512, 27)
+        rgb, sigma = model.decoder(x_enc, d_enc)
+        rgb_f, sigma_f = model(pts, dirs)
+    assert rgb.shape == (512, 3) and sigma.shape == (512, 1)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb"], atol=2e-2)
+    np.testing.assert_allclose(rgb.cpu().numpy(), rgb_f.cpu().numpy(), atol=6e-3)     # sinf codes vs in-register v_sin codes
+    np.testing.assert_allclose(sigma.cpu().numpy(), sigma_f.cpu().numpy(), atol=6e-3 * max(1.0, float(sigma_f.max())))
+    w = torch.randn(512, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    grads = []
+    for fused in (False, True):
+        model.zero_grad()
+        out = model(pts, dirs) if fused else model.decoder(model.representation(pts), model.dir_representation(dirs))
+        ((out[0] * w).sum() + out[1].sum()).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.decoder.parameters()]))
+    rel = float((grads[0] - grads[1]).norm() / grads[1].norm())
+    assert rel < 2e-2, rel
+
+
+@pytest.mark.parametrize("L,L_dir,use_dirs", [(6, 2, True), (10, 0, True), (0, 4, True), (4, 4, False)])
+def test_narrower_fourier_codes_from_yaml(L, L_dir, use_dirs):
+    """L_embed / L_embed_dir / use_viewdirs / use_positional_encoding are YAML keys of the reference
+    (src/core.py:36-55): any code of up to 10 / 4 bands runs on the compiled kernels (zero-padded weight
+    columns), checked against the oracle with the same parameters."""
+    from src.core import NeuralField
+    cfg = {"mode": "part2_nerf", "L_embed": L, "L_embed_dir": L_dir, "use_viewdirs": use_dirs,
+           "use_positional_encoding": L > 0, "hidden_dim": 256, "num_layers": 8, "skip_layer": 4, "view_dim": 128}
+    torch.manual_seed(L * 10 + L_dir)
+    model = NeuralField(cfg).cuda()
+    l_dir = L_dir if use_dirs else 0
+    assert model.decoder.pts_layers[0].weight.shape == (256, 3 + 6 * L)
+    assert model.decoder.view_layer.weight.shape == (128, 256 + 3 + 6 * l_dir)
+    params = {k[len("decoder."):]: v.detach().cpu() * (1.5 if k.endswith("weight") else 1.0)
+              for k, v in model.state_dict().items() if k.startswith("decoder.")}
+    model.load_state_dict({**model.state_dict(), **{"decoder." + k: v for k, v in params.items()}})
+    gen = torch.Generator().manual_seed(3)
+    pts = (torch.rand(300, 3, generator=gen) - 0.5) * 2.4
+    dirs = torch.nn.functional.normalize(torch.randn(300, 3, generator=gen), dim=-1)
+    rgb, sigma = model(pts.cuda(), dirs.cuda())
+    ref_rgb, ref_sigma = O.nerf_field(params, pts, dirs, l_pos=L, l_dir=l_dir)
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), ref_rgb.numpy(), atol=2e-2)
+    np.testing.assert_allclose(sigma.detach().cpu().numpy(), ref_sigma.numpy(), atol=3e-2 * max(1.0, float(ref_sigma.max())))
+    # gradients reach every (unpadded) parameter with the reference's shapes
+    (rgb.sum() + sigma.sum()).backward()
+    for name, p in model.decoder.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and bool(torch.isfinite(p.grad).all()), name
+    ps = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    r2, s2 = O.nerf_field(ps, pts, dirs, l_pos=L, l_dir=l_dir)
+    (r2.sum() + s2.sum()).backward()
+    for name in ("pts_layers.0.weight", "pts_layers.4.weight", "view_layer.weight", "rgb_layer.weight"):
+        got, want = dict(model.decoder.named_parameters())[name].grad.cpu(), ps[name].grad
+        cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-20))
+        assert cos > 0.97, (name, cos)
+
+    with pytest.raises(NotImplementedError):
+        NeuralField({**cfg, "hidden_dim": 128})
