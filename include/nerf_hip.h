@@ -303,6 +303,19 @@ int nerf_imlp_bwd(const void* packed, void* workspace, const float* rgb, const f
                   const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
                   float* d_feat, nerf_stream_t stream);
 
+/* ---- a10 + a11: evaluation of the vanilla field as one launch chain ----------------------------
+ * replaces render_rays(perturb=False) / render_image's chunk loop (src/renderer.py:240-384, 387-418) for
+ * mode part2_nerf: stratified depths -> fused Fourier + decoder -> compositing for every chunk of
+ * `chunk_rays` rays, on the caller's stream, in ONE caller-provided workspace of
+ * nerf_render_rays_workspace_bytes(chunk_rays, n_samples) bytes (256-byte aligned): no allocation and no
+ * host synchronisation, so the whole frame can be captured in a hipGraph.  bg as in nerf_composite_fwd.
+ * n_samples <= 1024. */
+size_t nerf_render_rays_workspace_bytes(int64_t chunk_rays, int n_samples);
+int nerf_render_rays_fwd(const void* packed, const float* rays_o, const float* rays_d, int64_t n_rays,
+                         int n_samples, float near_plane, float far_plane, const float* bg, int64_t bg_rows,
+                         int64_t chunk_rays, void* workspace, float* out_rgb, float* out_depth, float* out_acc,
+                         nerf_stream_t stream);
+
 /* ---- a9 + a14: compositing fused with the MSE loss and its backward --------------------------
  * replaces, for one training step, volume_render (src/renderer.py:204-237), nn.MSELoss
  * (run.py:308,334; run.py:598) and the compositing part of loss.backward() (run.py:337,619):

@@ -41,6 +41,8 @@ PROTOTYPES = {
                                  c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_composite_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr,
                                  c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_render_rays_workspace_bytes": (size_t, [i64, i32]),
+    "nerf_render_rays_fwd": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, i64, i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_packed_bytes": (size_t, []),
     "nerf_mlp_pack": (i32, [c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_stash_bytes": (size_t, [i64]),

@@ -6,15 +6,16 @@
 
 namespace nerf {
 
-constexpr int kMaxPerLane = 4;  // S <= 256
+constexpr int kMaxPerLane = 16;  // S <= 1024 (instantiated for 1, 2, 3, 4, 6, 8, 12, 16 samples per lane)
 
+template <int K>
 struct RayCtx {
-  float e[kMaxPerLane];      // exp(-sigma*delta)
-  float alpha[kMaxPerLane];  // 1 - e
-  float q[kMaxPerLane];      // 1 - alpha + 1e-10
-  float T[kMaxPerLane];      // exclusive transmittance
-  float z[kMaxPerLane];
-  float delta[kMaxPerLane];
+  float e[K];      // exp(-sigma*delta)
+  float alpha[K];  // 1 - e
+  float q[K];      // 1 - alpha + 1e-10
+  float T[K];      // exclusive transmittance
+  float z[K];
+  float delta[K];
 };
 
 // loads sigma/z for the lane's K samples of ray r and builds alpha / transmittance
@@ -27,7 +28,7 @@ __device__ __forceinline__ int64_t row_of(const int* __restrict__ slots, int64_t
 template <int K>
 __device__ __forceinline__ void ray_setup(const float* __restrict__ sigma, const float* __restrict__ z,
                                           const float* __restrict__ rays_d, const int* __restrict__ slots,
-                                          int64_t r, int S, int lane, RayCtx& c, float* sig_out, int64_t* row_out) {
+                                          int64_t r, int S, int lane, RayCtx<K>& c, float* sig_out, int64_t* row_out) {
   const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
   const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
   const int s0 = lane * K;
@@ -86,7 +87,7 @@ composite_fwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t r = wave; r < R; r += nwave) {
-    RayCtx c;
+    RayCtx<K> c;
     float sg[K];
     int64_t row[K];
     ray_setup<K>(sigma, z, rays_d, slots, r, S, lane, c, sg, row);
@@ -153,7 +154,7 @@ composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t r = wave; r < R; r += nwave) {
-    RayCtx c;
+    RayCtx<K> c;
     float sg[K];
     int64_t row[K];
     ray_setup<K>(sigma, z, rays_d, slots, r, S, lane, c, sg, row);
@@ -230,7 +231,7 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
   const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
   float loss_local = 0.0f, amax = 0.0f;
   for (int64_t r = wave; r < R; r += nwave) {
-    RayCtx c;
+    RayCtx<K> c;
     float sg[K];
     int64_t row[K];
     ray_setup<K>(sigma, z, rays_d, slots, r, S, lane, c, sg, row);
@@ -315,7 +316,11 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
   }
 }
 
-static int per_lane(int S) { return (S + 63) / 64; }
+// samples per lane: the smallest instantiated K with 64 K >= S (lanes past S are masked in the kernels)
+static int per_lane(int S) {
+  const int k = (S + 63) / 64;
+  return k <= 4 ? k : (k <= 6 ? 6 : (k <= 8 ? 8 : (k <= 12 ? 12 : 16)));
+}
 
 }  // namespace nerf
 
@@ -326,7 +331,11 @@ using namespace nerf;
     case 1: hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
     case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
     case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
-    default: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+    case 12: hipLaunchKernelGGL(KERNEL<12>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL(KERNEL<16>, grid, dim3(256), 0, as_stream(stream), __VA_ARGS__); break; \
   }
 
 static int composite_fwd_impl(const float* rgb, const float* sigma, const float* z, const float* rays_d,

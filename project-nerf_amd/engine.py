@@ -190,12 +190,15 @@ class VanillaNerfEngine:
     def render_image(self, rays_o: Tensor, rays_d: Tensor, n_samples: int, chunk: int = 65536, n_fine: int = 0) -> Tensor:
         shape = rays_o.shape[:-1]
         o, d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+        if n_fine == 0:
+            # one launch chain over all chunks in one reused workspace (nerf_render_rays_fwd): chunking is a
+            # property of the launch chain, not a Python loop with per-chunk allocations
+            chunk = max(1, min(chunk, o.shape[0]))
+            ws = self._buf("render", ops._lib.load().nerf_render_rays_workspace_bytes(chunk, n_samples))
+            return ops.render_rays_fwd(self.packed, o, d, n_samples, self.near, self.far, self.bg, chunk, ws)[0].view(*shape, 3)
         out = torch.empty(o.shape[0], 3, device=self.device)
         for i in range(0, o.shape[0], chunk):
-            if n_fine > 0:
-                out[i:i + chunk] = self.render_rays_hierarchical(o[i:i + chunk], d[i:i + chunk], n_samples, n_fine)[0]
-            else:
-                out[i:i + chunk] = self.render_rays(o[i:i + chunk], d[i:i + chunk], n_samples)[0]
+            out[i:i + chunk] = self.render_rays_hierarchical(o[i:i + chunk], d[i:i + chunk], n_samples, n_fine)[0]
         return out.view(*shape, 3)
 
 

@@ -367,6 +367,28 @@ def mlp_fwd(packed: Tensor, rays_o: Tensor, rays_d: Tensor, z: Optional[Tensor],
     return rgb, sigma
 
 
+def render_rays_fwd(packed: Tensor, rays_o: Tensor, rays_d: Tensor, n_samples: int, near: float, far: float,
+                    bg: Optional[Tensor] = None, chunk: int = 65536, workspace: Optional[Tensor] = None):
+    """(rgb [R,3], depth [R], acc [R]) of the vanilla field for any number of rays: one launch chain over
+    chunks of ``chunk`` rays in one reused workspace (nerf_render_rays_fwd)."""
+    lib = _lib.load()
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    R = rays_o.shape[0]
+    chunk = max(1, min(chunk, max(R, 1)))
+    need = lib.nerf_render_rays_workspace_bytes(chunk, n_samples)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=rays_o.device, dtype=torch.uint8)
+    bg_rows = 0
+    if bg is not None:
+        bg = _dev(bg, "bg")
+        bg_rows = 1 if bg.dim() == 1 else bg.shape[0]
+    out = torch.empty(R, 3, device=rays_o.device)
+    depth, acc = torch.empty(R, device=rays_o.device), torch.empty(R, device=rays_o.device)
+    _lib.check(lib.nerf_render_rays_fwd(_p(packed), _p(rays_o), _p(rays_d), R, n_samples, float(near), float(far), _p(bg), bg_rows,
+                                        chunk, _p(workspace), _p(out), _p(depth), _p(acc), _stream()), "nerf_render_rays_fwd")
+    return out, depth, acc
+
+
 def mlp_bwd_workspace_bytes(n: int) -> int:
     return _lib.load().nerf_mlp_bwd_workspace_bytes(n)
 

@@ -101,6 +101,11 @@ def render_image(model, rays_o, rays_d, near, far, n_samples, chunk, white_bkgd)
     """reference src/renderer.py:387-418."""
     h, w = rays_o.shape[:2]
     o, d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    if getattr(model, "mode", None) == "part2_nerf" and not torch.is_grad_enabled():
+        # the whole image as one launch chain (nerf_render_rays_fwd): same kernels, one reused workspace
+        bg = torch.ones(3, device=o.device) if white_bkgd else torch.zeros(3, device=o.device)
+        return ops.render_rays_fwd(model.decoder.packed_weights(), o.contiguous(), d.contiguous(), n_samples, near, far, bg,
+                                   chunk)[0].view(h, w, 3)
     out = []
     for i in range(0, o.shape[0], chunk):
         out.append(render_rays(model=model, rays_o=o[i:i + chunk], rays_d=d[i:i + chunk], near=near, far=far,

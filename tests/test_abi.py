@@ -82,7 +82,7 @@ def test_argument_validation_returns_error_codes(lib):
     assert h.nerf_sample_rays(None, None, None, -1, 64, 2.0, 6.0, None, None, None, None) == -22
     assert b"n_rays" in h.nerf_last_error()
     assert h.nerf_sample_rays(None, None, None, 4, 1, 2.0, 6.0, None, None, None, None) == -22     # n_samples < 2
-    assert h.nerf_composite_fwd(None, None, None, None, None, 0, None, 5, 1000, None, None, None, None, None, None) == -22
+    assert h.nerf_composite_fwd(None, None, None, None, None, 0, None, 5, 1025, None, None, None, None, None, None) == -22
     assert b"n_samples" in h.nerf_last_error()
     assert h.nerf_fourier_encode(None, 10, 3, 99, None, None) == -22                               # n_freq out of range
     assert h.nerf_mlp_pack(None, None, None) == -22
