@@ -44,7 +44,7 @@ int nerf_abi_version(void);
  * environment ONCE per process (NERF_CHAIN_LEGACY, NERF_FWD_CYCLES, NERF_WGRAD_OVH,
  * NERF_WGRAD_DEBUG, NERF_WGRAD_ONLY, NERF_HASH_BWD_ONLY_LEVEL, NERF_STASH_BF16); afterwards they
  * change only through nerf_set_option.  Names: "chain_legacy", "fwd_cycles", "wgrad_overhead",
- * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "stash_bf16".  No hot-path launch reads the
+ * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "stash_bf16", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed".  No hot-path launch reads the
  * environment. */
 int nerf_set_option(const char* name, int value);
 int nerf_get_option(const char* name, int* value_out);
@@ -195,6 +195,10 @@ int nerf_composite_bwd_indexed(const float* rgb_compact, const float* sigma_comp
 size_t nerf_mlp_packed_bytes(void);
 /* params_f32 [595844] -> packed (nerf_mlp_packed_bytes() bytes, 256-B aligned) */
 int nerf_mlp_pack(const float* params_f32, void* packed, nerf_stream_t stream);
+/* the same for a subset of the streams: which = 1 the training streams (forward + transposed, 32x32x16
+ * fragments) and the bias table; 2 the inference stream (16x16x32 fragments); 3 both (= nerf_mlp_pack).
+ * A training loop repacks 1 after every optimiser step and 2 only before it renders. */
+int nerf_mlp_pack_streams(const float* params_f32, void* packed, int which, nerf_stream_t stream);
 
 /* Inputs, one of:
  *   ray mode   : rays_o/rays_d [R,3] + z [R,S]  (n = R*S samples, sample i -> ray i / S)

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "nerf_render_rays_fwd": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, i64, i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_packed_bytes": (size_t, []),
     "nerf_mlp_pack": (i32, [c_ptr, c_ptr, c_ptr]),
+    "nerf_mlp_pack_streams": (i32, [c_ptr, c_ptr, i32, c_ptr]),
     "nerf_mlp_stash_bytes": (size_t, [i64]),
     "nerf_mlp_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_fwd_encoded": (i32, [c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -59,7 +59,12 @@ def vr(a, n=1):
 
 
 # ---------------------------------------------------------------- plans
-def fwd_groups():
+def fwd_groups(s16=False):
+    """s16: the 16x16x32 MFMA shape (inference).  A group is still one 32-row output tile of a step, now held as
+    FOUR 16x16 accumulators a(t, g) = T + 4 (2 t + g): t = 16-row half of the tile, g = 16-sample half of the
+    wave's 32 samples.  Fragment k of a group feeds t = k & 1 at k-step kk = k >> 1 (32 deep) with both halves
+    g = 0, 1 of the B operand, so every A fragment still feeds 32 cycles of matrix work and the fragment stream
+    has exactly the chunking of the 32x32x16 stream."""
     steps = [("PTS0", 8, 0, 4, 0)] + [(f"PTS{l}", 8, 16, 4 if l == 4 else 0, 256 * l) for l in range(1, 8)] + [
         ("HEAD", 9, 16, 0, 2048), ("VIEW", 4, 16, 2, 2048 + 288), ("RGB", 1, 8, 0, 2048 + 288 + 128)]
     src = {"PTS0": None, "PTS1": P, "PTS2": Q, "PTS3": P, "PTS4": Q, "PTS5": P, "PTS6": Q, "PTS7": P,
@@ -69,9 +74,13 @@ def fwd_groups():
     groups = []
     for li, (name, mt, ks_acc, ks_nat, boff) in enumerate(steps):
         for m in range(mt):
-            bops = [vr(src[name] + 4 * k, 4) for k in range(ks_acc)]
             code = "x" if name in ("PTS0", "PTS4") else "d"
-            bops += [f"%[{code}{k}]" for k in range(ks_nat)]
+            if s16:
+                bops = [(vr(src[name] + 4 * (2 * (k >> 1)), 4), vr(src[name] + 4 * (2 * (k >> 1) + 1), 4)) for k in range(ks_acc)]
+                bops += [(f"%[{code}{k >> 1}a]", f"%[{code}{k >> 1}b]") for k in range(ks_nat)]
+            else:
+                bops = [vr(src[name] + 4 * k, 4) for k in range(ks_acc)]
+                bops += [f"%[{code}{k}]" for k in range(ks_nat)]
             if name == "RGB":
                 epi = dict(kind="rgb")
             elif name == "HEAD" and m == 8:
@@ -117,9 +126,9 @@ def chunk_groups(groups):
 
 # ---------------------------------------------------------------- stream
 def generate(mode):
-    bwd, train = mode == "bwd", mode == "train"
+    bwd, train, s16 = mode == "bwd", mode == "train", mode == "infer16"
     stash = bwd or train
-    groups = bwd_groups() if bwd else fwd_groups()
+    groups = bwd_groups() if bwd else fwd_groups(s16)
     chunks = chunk_groups(groups)
     n_groups, n_chunks = len(groups), len(chunks)
     assert n_groups % 2 == 0 and n_chunks % 2 == 0
@@ -219,10 +228,24 @@ def generate(mode):
         T = X if gi % 2 == 0 else Y
         units = []
         if e["kind"] == "sigma":
+            if s16:
+                return [[f"v_mov_b32 %[sg0], {vr(T)}", f"v_mov_b32 %[sg1], {vr(T + 4)}"]]
             return [[f"v_mov_b32 %[sg], {vr(T)}"]]
         if e["kind"] != "cvt":
             return []
         r0 = e["dst"] + 8 * e["m"]
+        if s16:
+            # B operand of k-step m for sample half g = registers r0 + 4g .. +3: [t0 rows 4q..4q+3 | t1 rows 16+4q..]
+            for gsel in range(2):
+                for t in range(2):
+                    a = T + 4 * (2 * t + gsel)
+                    for h in range(2):
+                        dstr = r0 + 4 * gsel + 2 * t + h
+                        u = [f"v_cvt_pk_bf16_f32 {vr(dstr)}, {vr(a + 2 * h)}, {vr(a + 2 * h + 1)}"]
+                        if e["relu"]:
+                            u.append(f"v_pk_max_i16 {vr(dstr)}, {vr(dstr)}, 0")
+                        units.append(u)
+            return units
         masked = e["mask_layer"] is not None
         for j in range(8):
             u = [f"v_cvt_pk_bf16_f32 {vr(r0 + j)}, {vr(T + 2 * j)}, {vr(T + 2 * j + 1)}"]
@@ -271,6 +294,8 @@ def generate(mode):
         g = groups[gi_next]
         if g["bias"] is None:
             return []
+        if s16:   # a(t, g) <- bias rows 16 t + 4 q .. +3 (bb carries 16 q); both sample halves start from the same bias
+            return [(f"ds_read_b128 {vr(T + 4 * q, 4)}, %[bb] offset:{g['bias'] + 64 * (q >> 1)}", ("b", gi_next, q)) for q in range(4)]
         return [(f"ds_read_b128 {vr(T + 4 * q, 4)}, %[bb] offset:{g['bias'] + 32 * q}", ("b", gi_next, q)) for q in range(4)]
 
     # ---- pass prologue ----
@@ -323,7 +348,11 @@ def generate(mode):
                 need |= {("b", gi, q) for q in range(4)} & set(lds_q)
             wait_lds(need)
             c_in = vr(T, 16) if (k > 0 or g["bias"] is not None) else "0"
-            if "shape32" in ABLATE:
+            if s16:
+                a0, a1 = vr(T + 4 * (2 * (k & 1)), 4), vr(T + 4 * (2 * (k & 1) + 1), 4)
+                emit(f"v_mfma_f32_16x16x32_bf16 {a0}, %[w{j % D}], {g['bops'][k][0]}, {a0}")
+                emit(f"v_mfma_f32_16x16x32_bf16 {a1}, %[w{j % D}], {g['bops'][k][1]}, {a1}")
+            elif "shape32" in ABLATE:
                 # timing probe of the 16x16x32 shape (results are wrong): the same operands feed two half-length MFMAs
                 for h in range(2):
                     ch = vr(T + 4 * h, 4) if c_in != "0" else "0"
@@ -366,7 +395,11 @@ def generate(mode):
     T = X if (n_groups - 1) % 2 == 0 else Y
     emit("s_nop 15")
     emit("s_nop 3")
-    if not bwd:
+    if s16:
+        for c in range(3):
+            emit(f"v_mov_b32 %[c{c}], {vr(T + c)}")
+            emit(f"v_mov_b32 %[c{3 + c}], {vr(T + 4 + c)}")
+    elif not bwd:
         for c, name in enumerate(("cr", "cg", "cb")):
             emit(f"v_mov_b32 %[{name}], {vr(T + c)}")
     elif "epi" not in ABLATE:
@@ -388,6 +421,9 @@ SIGS = {
     "infer": ("fwd_stream_pass",
               "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
               "    unsigned voff, unsigned ldsw, float& sg, float& cr, float& cg, float& cb"),
+    "infer16": ("fwd_stream16_pass",
+                "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
+                "    unsigned voff, unsigned ldsw, float (&sg)[2], float (&c)[6]"),
     "train": ("fwd_train_stream_pass",
               "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
               "    unsigned voff, unsigned ldsw, unsigned so8, unsigned so4, unsigned mo0, const void* karg, float scale,\n"
@@ -404,7 +440,7 @@ def emit_function(mode, p):
         lines = [l for l in lines if l != "s_barrier"]
     name, sig = SIGS[mode]
     tab = "kBwdChunks" if mode == "bwd" else "kFwdChunks"
-    if mode != "train":
+    if mode not in ("train", "infer16"):
         p(f"static_assert(plan::{tab}.n_chunks == {len(chunks)} && plan::{tab}.n_groups == {len(groups)}, \"stream plan\");")
         for i, c in enumerate(chunks):
             p(f"static_assert(plan::{tab}.chunk_frag0[{i}] == {c['frag0']} && plan::{tab}.chunk_count[{i}] == {c['count']}, \"stream plan\");")
@@ -421,13 +457,16 @@ def emit_function(mode, p):
     ins = ['[ab0] "v"(ab0)', '[ab1] "v"(ab1)', '[src] "s"(src)', '[voff] "v"(voff)', '[ldsw] "s"(ldsw)']
     if mode == "bwd":
         ins += ['[g0] "v"(g0)', '[gs] "v"(gs)', '[mo0n] "v"(mo0n)', '[first] "s"(first)']
+    elif mode == "infer16":
+        outs += ['[sg0] "=&v"(sg[0])', '[sg1] "=&v"(sg[1])'] + [f'[c{i}] "=&v"(c[{i}])' for i in range(6)]
+        ins += ['[bb] "v"(bb)'] + [f'[x{i >> 1}{"ab"[i & 1]}] "v"(x[{i}])' for i in range(4)] + [f'[d0{"ab"[i]}] "v"(d[{i}])' for i in range(2)]
     else:
         outs += ['[sg] "=&v"(sg)', '[cr] "=&v"(cr)', '[cg] "=&v"(cg)', '[cb] "=&v"(cb)']
         ins += ['[bb] "v"(bb)'] + [f'[x{i}] "v"(x[{i}])' for i in range(4)] + [f'[d{i}] "v"(d[{i}])' for i in range(2)]
-    if mode != "infer":
+    if mode not in ("infer", "infer16"):
         ins += ['[so8] "v"(so8)', '[so4] "v"(so4)', '[mo0] "v"(mo0)', '[karg] "s"(karg)', '[scale] "s"(scale)']
     clob = [f'"v{i}"' for i in range(FIRST_LITERAL_VGPR, 256)]
-    if mode != "infer":
+    if mode not in ("infer", "infer16"):
         clob += [f'"s{i}"' for i in SGPR_LITERALS]
     p("      : " + ", ".join(outs))
     p("      : " + ", ".join(ins))
@@ -448,7 +487,7 @@ def main():
     p("// voff = wave*1024 + lane*16; ldsw = ring base + wave*1024 (wave-uniform); src = fragment stream;")
     p("// so8/so4 = wave_tile*MT*1024 + block8_lane_offset(col, half) for MT = 8/4; mo0 = (tile*72*512 + tid)*4;")
     p("// karg = kernarg segment.\n")
-    for mode in os.environ.get("GEN_MODES", "infer,train,bwd").split(","):
+    for mode in os.environ.get("GEN_MODES", "infer,infer16,train,bwd").split(","):
         emit_function(mode, p)
     p("}  // namespace nerf")
 

@@ -48,6 +48,32 @@ __device__ __forceinline__ int src_index(int kind, int row, int k, bool nat) {
   }
 }
 
+// forward stream in the operand layout of v_mfma_f32_16x16x32_bf16: lane (q = lane >> 4, r = lane & 15) of
+// fragment k of m-tile mt holds A[row 32 mt + 16 (k & 1) + r][8 elements of the 32-deep k-step kk = k >> 1]:
+// natural steps element j = column 32 kk + 8 q + j; accumulator-fed steps j = column 32 kk + 16 (j >> 2) + 4 q + (j & 3)
+// (the order in which two stacked 16x16 accumulator tiles become the next B operand)
+__global__ void __launch_bounds__(256) pack16_kernel(const float* __restrict__ params, __bf16* __restrict__ packed_fwd16) {
+  const int total = kFwdFrags * 64;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int frag = t >> 6, lane = t & 63;
+    const int desc = g_frag_table.v[frag];
+    const int kind = desc >> 16, mt = (desc >> 8) & 0xFF, ks = desc & 0xFF;
+    const Step st = step_of(kind);
+    const int row = mt * 32 + 16 * (ks & 1) + (lane & 15), q = lane >> 4;
+    const bool nat = ks >= st.ks_acc;
+    const int kk = nat ? (ks - st.ks_acc) >> 1 : ks >> 1;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    bf16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = nat ? 32 * kk + 8 * q + j : 32 * kk + 16 * (j >> 2) + 4 * q + (j & 3);
+      const int src = src_index(kind, row, k, nat);
+      out[j] = (__bf16)(src >= 0 ? params[src] : 0.0f);
+    }
+    *reinterpret_cast<bf16x8*>(packed_fwd16 + (size_t)frag * 512 + lane * 8) = out;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 pack_kernel(const float* __restrict__ params, __bf16* __restrict__ packed_fwd,
             __bf16* __restrict__ packed_bwd, float* __restrict__ bias) {
@@ -87,14 +113,23 @@ pack_kernel(const float* __restrict__ params, __bf16* __restrict__ packed_fwd,
 
 extern "C" size_t nerf_mlp_packed_bytes(void) { return nerf::plan::kPackBytes; }
 
-extern "C" int nerf_mlp_pack(const float* params_f32, void* packed, nerf_stream_t stream) {
+extern "C" int nerf_mlp_pack_streams(const float* params_f32, void* packed, int which, nerf_stream_t stream) {
   using namespace nerf;
   NERF_REQUIRE(params_f32 && packed, "nerf_mlp_pack: NULL pointer");
   NERF_REQUIRE(((uintptr_t)packed & 255) == 0, "nerf_mlp_pack: packed buffer must be 256-byte aligned");
+  NERF_REQUIRE(which >= 1 && which <= 3, "nerf_mlp_pack_streams: which=%d (1 training streams + biases, 2 inference stream, 3 all)", which);
   char* base = static_cast<char*>(packed);
-  hipLaunchKernelGGL(pack_kernel, dim3(512), dim3(256), 0, as_stream(stream), params_f32,
-                     reinterpret_cast<__bf16*>(base + plan::kPackFwdOff),
-                     reinterpret_cast<__bf16*>(base + plan::kPackBwdOff),
-                     reinterpret_cast<float*>(base + plan::kPackBiasOff));
+  if (which & 1)
+    hipLaunchKernelGGL(pack_kernel, dim3(512), dim3(256), 0, as_stream(stream), params_f32,
+                       reinterpret_cast<__bf16*>(base + plan::kPackFwdOff),
+                       reinterpret_cast<__bf16*>(base + plan::kPackBwdOff),
+                       reinterpret_cast<float*>(base + plan::kPackBiasOff));
+  if (which & 2)
+    hipLaunchKernelGGL(pack16_kernel, dim3(304), dim3(256), 0, as_stream(stream), params_f32,
+                       reinterpret_cast<__bf16*>(base + plan::kPackFwd16Off));
   return check_launch("nerf_mlp_pack");
+}
+
+extern "C" int nerf_mlp_pack(const float* params_f32, void* packed, nerf_stream_t stream) {
+  return nerf_mlp_pack_streams(params_f32, packed, 3, stream);
 }

@@ -160,7 +160,10 @@ constexpr size_t kPackFwdOff = 0;
 constexpr size_t kStreamPad = 8 * kFragBytes;   // DMA tail pieces may read this far past a stream
 constexpr size_t kPackBwdOff = kPackFwdOff + (size_t)kFwdFrags * kFragBytes + kStreamPad;
 constexpr size_t kPackBiasOff = kPackBwdOff + (size_t)kBwdFrags * kFragBytes + kStreamPad;
-constexpr size_t kPackBytes = kPackBiasOff + ((kBiasFloats * 4 + 255) / 256) * 256;
+// forward stream for the 16x16x32 MFMA shape (inference): same fragment count and chunking; fragment k of an
+// m-tile = 16-row half k & 1 at the 32-deep k-step k >> 1 (gen_stream_asm.py::fwd_groups)
+constexpr size_t kPackFwd16Off = kPackBiasOff + ((kBiasFloats * 4 + 255) / 256) * 256;
+constexpr size_t kPackBytes = kPackFwd16Off + (size_t)kFwdFrags * kFragBytes + kStreamPad;
 
 // ---- training stash: blocked images [xenc 64 | h0..h7 8x256 | feat 256 | hv 128 | denc 32] per
 // sample, followed by relu bitmasks; byte layout in mlp_stash.h, block shapes in mlp_chain.h.

@@ -87,8 +87,17 @@ class VanillaNerfEngine:
         self.repack()
 
     # -- weights ---------------------------------------------------------------
-    def repack(self) -> None:
-        ops.mlp_pack(self.params, self.packed)
+    def repack(self, training_only: bool = False) -> None:
+        """bf16 fragment streams of the current weights; a training step refreshes only the streams it uses,
+        the inference stream (16x16x32 fragments) is refreshed when something is rendered next."""
+        ops.mlp_pack(self.params, self.packed, which=1 if training_only else 3)
+        self._infer_stale = training_only
+
+    def _inference_weights(self) -> Tensor:
+        if getattr(self, "_infer_stale", False):
+            ops.mlp_pack(self.params, self.packed, which=2)
+            self._infer_stale = False
+        return self.packed
 
     def state_dict(self, prefix: str = "decoder.") -> Dict[str, Tensor]:
         return {k: v.clone() for k, v in unflatten(self.params, prefix).items()}
@@ -149,7 +158,7 @@ class VanillaNerfEngine:
         self.step_count += 1
         ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                       grad_scale=self.grad_scale if self.world_size > 1 else None)
-        self.repack()
+        self.repack(training_only=True)
 
     def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 64,
                    u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, mark=None,
@@ -167,7 +176,7 @@ class VanillaNerfEngine:
     @torch.no_grad()
     def render_rays(self, rays_o: Tensor, rays_d: Tensor, n_samples: int, u: Optional[Tensor] = None):
         z = ops.sample_rays(rays_o, rays_d, self.near, self.far, n_samples, u=u)
-        rgb, sigma = ops.mlp_fwd(self.packed, rays_o, rays_d, z)
+        rgb, sigma = ops.mlp_fwd(self._inference_weights(), rays_o, rays_d, z)
         R = rays_o.shape[0]
         c, depth, acc, _, _ = ops.composite_fwd(rgb.view(R, n_samples, 3), sigma.view(R, n_samples), z, rays_d, self.bg)
         return c, depth, acc
@@ -178,11 +187,11 @@ class VanillaNerfEngine:
         BASELINE.json; the reference itself has one stratified pass only)."""
         R = rays_o.shape[0]
         z = ops.sample_rays(rays_o, rays_d, self.near, self.far, n_coarse)
-        rgb, sigma = ops.mlp_fwd(self.packed, rays_o, rays_d, z)
+        rgb, sigma = ops.mlp_fwd(self._inference_weights(), rays_o, rays_d, z)
         w = ops.composite_fwd(rgb.view(R, n_coarse, 3), sigma.view(R, n_coarse), z, rays_d, self.bg, want_weights=True)[4]
         z_all = ops.sample_pdf(z, w, n_fine)
         S = n_coarse + n_fine
-        rgb, sigma = ops.mlp_fwd(self.packed, rays_o, rays_d, z_all)
+        rgb, sigma = ops.mlp_fwd(self._inference_weights(), rays_o, rays_d, z_all)
         c, depth, acc, _, _ = ops.composite_fwd(rgb.view(R, S, 3), sigma.view(R, S), z_all, rays_d, self.bg)
         return c, depth, acc
 
@@ -195,7 +204,7 @@ class VanillaNerfEngine:
             # property of the launch chain, not a Python loop with per-chunk allocations
             chunk = max(1, min(chunk, o.shape[0]))
             ws = self._buf("render", ops._lib.load().nerf_render_rays_workspace_bytes(chunk, n_samples))
-            return ops.render_rays_fwd(self.packed, o, d, n_samples, self.near, self.far, self.bg, chunk, ws)[0].view(*shape, 3)
+            return ops.render_rays_fwd(self._inference_weights(), o, d, n_samples, self.near, self.far, self.bg, chunk, ws)[0].view(*shape, 3)
         out = torch.empty(o.shape[0], 3, device=self.device)
         for i in range(0, o.shape[0], chunk):
             out[i:i + chunk] = self.render_rays_hierarchical(o[i:i + chunk], d[i:i + chunk], n_samples, n_fine)[0]

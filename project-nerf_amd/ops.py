@@ -334,15 +334,16 @@ def mlp_packed_bytes() -> int:
     return _lib.load().nerf_mlp_packed_bytes()
 
 
-def mlp_pack(params: Tensor, packed: Optional[Tensor] = None) -> Tensor:
-    """flat fp32 [595844] (reference state_dict order) -> fragment-ordered bf16 streams."""
+def mlp_pack(params: Tensor, packed: Optional[Tensor] = None, which: int = 3) -> Tensor:
+    """flat fp32 [595844] (reference state_dict order) -> fragment-ordered bf16 streams.  ``which``: 1 the
+    training streams + biases, 2 the inference stream, 3 both."""
     lib = _lib.load()
     params = _dev(params, "params")
     if params.numel() != MLP_PARAM_COUNT:
         raise ValueError(f"params must have {MLP_PARAM_COUNT} elements, got {params.numel()}")
     if packed is None:
         packed = torch.empty(lib.nerf_mlp_packed_bytes(), device=params.device, dtype=torch.uint8)
-    _lib.check(lib.nerf_mlp_pack(_p(params), _p(packed), _stream()), "nerf_mlp_pack")
+    _lib.check(lib.nerf_mlp_pack_streams(_p(params), _p(packed), which, _stream()), "nerf_mlp_pack")
     return packed
 
 
