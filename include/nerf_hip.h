@@ -281,6 +281,13 @@ int nerf_hash_encode_bwd_levels(const float* pts, int64_t n, int n_levels, const
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table, int first_level, int end_level,
                          nerf_stream_t stream);
+/* gradient with respect to the encoded positions (dynamic fields encode x + delta_x: reference
+ * src/core.py:268-271, 341-344): d_pts [n,3] = d_feat . d features / d x, zero along an axis on which
+ * HashRepresentation's clamp is active; d_pts is OVERWRITTEN. */
+int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const float* table, int n_levels,
+                               const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                               const unsigned* offset_host, const unsigned* dense_host, float bound,
+                               const float* d_feat, float* d_pts, nerf_stream_t stream);
 
 
 /* ---- a7: Instant decoder (two bias-free tiny MLPs, bf16 MFMA) -----------------------

@@ -120,6 +120,49 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const f
 // workgroup per 16384-entry slice scans the whole batch into LDS) -- slower, the 32-fold
 // recomputation of the corner hashes costs more than the atomics it removes; a packed-fp16
 // gradient table (one atomic per corner) -- 1.29 ms against 0.72 ms for the coalesced fp32 form.
+// Gradient with respect to the ENCODED POSITION (dynamic fields: x_canonical = x + delta_x is encoded, so the
+// loss reaches the deformation through d features / d x; reference src/core.py:268-271, 341-344):
+//   d f / d x01_a = scale_l * sum_corners table[corner] * (+1 | -1 along a) * prod_{b != a} w_b,
+//   d x01 / d x = 1 / (2 bound) inside the box, 0 where HashRepresentation's clamp is active.
+// One thread per (point, level), level-major like the forward; the 16 levels of a point meet in d_pts through
+// float atomics (three per thread; d_pts is zeroed by the launcher).
+__global__ void __launch_bounds__(256)
+hash_bwd_input_kernel(const float* __restrict__ pts, int64_t n, const float2* __restrict__ table, HashLevels L,
+                      const float* __restrict__ d_feat, float* __restrict__ d_pts) {
+  const int lvl = blockIdx.y;
+  const float two_b = 2.0f * L.bound;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0], g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1];
+    if (g0 == 0.0f && g1 == 0.0f) continue;
+    const float px = pts[p * 3 + 0], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+    const Corner c = corners_of(L, lvl, px, py, pz);
+    // per-axis weights recovered from the same arithmetic as corners_of
+    float frac[3], x01[3] = {add_rn(px, L.bound) / two_b, add_rn(py, L.bound) / two_b, add_rn(pz, L.bound) / two_b};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float cl = fminf(fmaxf(x01[a], 0.0f), 1.0f);
+      const float pos = add_rn(mul_rn(cl, L.scale[lvl]), 0.5f);
+      frac[a] = sub_rn(pos, floorf(pos));
+    }
+    float d[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float2 v = table[c.idx[k]];
+      const float gv = g0 * v.x + g1 * v.y;
+      const float wx = (k & 1) ? frac[0] : 1.0f - frac[0], wy = (k & 2) ? frac[1] : 1.0f - frac[1], wz = (k & 4) ? frac[2] : 1.0f - frac[2];
+      d[0] += gv * ((k & 1) ? 1.0f : -1.0f) * wy * wz;
+      d[1] += gv * ((k & 2) ? 1.0f : -1.0f) * wx * wz;
+      d[2] += gv * ((k & 4) ? 1.0f : -1.0f) * wx * wy;
+    }
+    const float s = L.scale[lvl] / two_b;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const bool inside = x01[a] >= 0.0f && x01[a] <= 1.0f;          // torch.clamp passes the gradient on its closed interval
+      if (inside && d[a] != 0.0f) atomicAdd(d_pts + p * 3 + a, d[a] * s);
+    }
+  }
+}
+
 constexpr int kLdsEntries = 16384;      // 128 KiB of float2
 template <bool in_lds>
 __global__ void __launch_bounds__(512)
@@ -263,4 +306,24 @@ extern "C" int nerf_hash_encode_bwd_levels(const float* pts, int64_t n, int n_le
                                            int first_level, int end_level, nerf_stream_t stream) {
   return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table,
                        first_level, end_level, stream);
+}
+
+extern "C" int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const float* table, int n_levels,
+                                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                          const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                          const float* d_feat, float* d_pts, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd_input: n=%lld", (long long)n);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(pts && table && d_feat && d_pts && scale_host && res_host && size_host && offset_host && dense_host,
+               "nerf_hash_encode_bwd_input: NULL pointer");
+  HashLevels L;
+  int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
+  if (rc != NERF_OK) return rc;
+  if (hipMemsetAsync(d_pts, 0, sizeof(float) * 3 * (size_t)n, as_stream(stream)) != hipSuccess)
+    return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_input: memset failed");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(hash_bwd_input_kernel, dim3((int)blocks, n_levels), dim3(256), 0, as_stream(stream), pts, n,
+                     reinterpret_cast<const float2*>(table), L, d_feat, d_pts);
+  return check_launch("nerf_hash_encode_bwd_input");
 }

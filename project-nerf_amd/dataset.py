@@ -119,6 +119,50 @@ class BlenderDataset:
         return o.to(device), d.to(device), rgba.to(device)
 
 
+class DynamicDataset(BlenderDataset):
+    """Dynamic scene (reference src/dataset.py:174-294): every frame carries a time stamp in [0, 1] (``time`` in
+    the json, else its position in the sequence); rgb and alpha are kept apart, ``images`` is the composited
+    target.  get_image_rays -> (o, d, target, time [1,1]); sample_random_rays -> (o, d, rgba [B,4], times [B,1])."""
+
+    def __init__(self, root_dir, split="train", downscale=1, white_bkgd=True, scene_scale=1.0):
+        super().__init__(root_dir, split, downscale, white_bkgd, scene_scale)
+        n = len(self.frames)
+        self.times = torch.tensor([float(f["time"]) if "time" in f else (i / (n - 1) if n > 1 else 0.0)
+                                   for i, f in enumerate(self.frames)], dtype=torch.float32)
+        self.images_rgb, self.images_alpha = self.images[..., :3].contiguous(), self.images[..., 3:4].contiguous()
+        self.rgba = self.images
+        self.images = self.images_rgb * self.images_alpha + ((1.0 - self.images_alpha) if white_bkgd else 0.0)
+
+    def to(self, device):
+        self.rgba, self.poses, self.times = self.rgba.to(device), self.poses.to(device), self.times.to(device)
+        self.images, self.images_rgb, self.images_alpha = self.images.to(device), self.images_rgb.to(device), self.images_alpha.to(device)
+        self._directions = self._directions.to(device)
+        return self
+
+    def get_image_rays(self, index, device):
+        o, d = self.get_rays(self.poses[index])
+        return o.to(device), d.to(device), self.images[index].to(device), self.times[index].view(1, 1).to(device)
+
+    def sample_random_rays(self, batch_size, device):
+        dev = self.rgba.device
+        img = torch.randint(0, len(self), (batch_size,), device=dev)
+        py = torch.randint(0, self.H, (batch_size,), device=dev)
+        px = torch.randint(0, self.W, (batch_size,), device=dev)
+        times = self.times[img].unsqueeze(-1)
+        if dev.type == "cuda" and dev == torch.device(device):
+            from . import ops
+            o, d, rgba = ops.gather_rays(self.rgba, self.poses, img, py, px, self.focal, self.scene_scale)
+            return o, d, rgba, times
+        c2w = self.poses[img]
+        dirs = torch.stack([(px - self.W * 0.5) / self.focal, -(py - self.H * 0.5) / self.focal, -torch.ones_like(px)], dim=-1)
+        d = torch.bmm(c2w[:, :3, :3], dirs.unsqueeze(-1)).squeeze(-1)
+        o = c2w[:, :3, 3]
+        if self.scene_scale != 1.0:
+            o = o * self.scene_scale
+        d = d / torch.norm(d, dim=-1, keepdim=True)
+        return o.to(device), d.to(device), self.rgba[img, py, px].to(device), times.to(device)
+
+
 # ---------------------------------------------------------------------------------------------
 def look_at_pose(eye):
     """Camera-to-world with -z looking at the origin, z-up world (Blender convention)."""

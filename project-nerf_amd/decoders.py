@@ -94,13 +94,62 @@ class NeRFDecoder(BaseDecoder):
         return rgb, sigma.unsqueeze(-1)
 
 
+def _pad16(n):
+    return (n + 15) // 16 * 16
+
+
+def tiny_mlp_shapes(n_in, n_out, hidden, n_hidden_layers):
+    """[out, in] matrix shapes of a bias-free fully fused MLP in this build's flat ``params`` layout
+    (include/nerf_hip.h): in / out widths rounded up to multiples of 16, matrices concatenated row-major."""
+    widths = [_pad16(n_in)] + [hidden] * n_hidden_layers + [_pad16(n_out)]
+    return [(widths[i + 1], widths[i]) for i in range(len(widths) - 1)]
+
+
+def tiny_mlp_init(n_in, n_out, hidden, n_hidden_layers):
+    parts = []
+    shapes = tiny_mlp_shapes(n_in, n_out, hidden, n_hidden_layers)
+    for i, (o, k) in enumerate(shapes):
+        fan_in = n_in if i == 0 else k
+        fan_out = n_out if i == len(shapes) - 1 else o
+        w = (torch.rand(o, k) * 2 - 1) * (6.0 / (fan_in + fan_out)) ** 0.5
+        if i == 0:
+            w[:, n_in:] = 0
+        if i == len(shapes) - 1:
+            w[n_out:] = 0
+        parts.append(w.reshape(-1))
+    return torch.cat(parts)
+
+
+def tiny_mlp_apply(params, shapes, x, n_out, sigmoid=False):
+    """Bias-free MLP, ReLU between layers, pad inputs zero -- the tiny networks whose shapes the fused HIP
+    kernels are not compiled for (Part 4: 88 -> 64 -> 64 -> 3 and 53 -> 64 -> 16) run as library GEMMs."""
+    pad = shapes[0][1] - x.shape[-1]
+    h = torch.nn.functional.pad(x.float(), (0, pad)) if pad else x.float()
+    off = 0
+    for i, (o, k) in enumerate(shapes):
+        h = torch.nn.functional.linear(h, params[off:off + o * k].view(o, k))
+        off += o * k
+        if i + 1 < len(shapes):
+            h = torch.relu(h)
+    h = h[:, :n_out]
+    return torch.sigmoid(h) if sigmoid else h
+
+
 class InstantNeRFDecoder(BaseDecoder):
-    """reference src/decoders.py:90-162: sigma-net 32->64->16, colour-net (16+27)->64->64->3."""
+    """reference src/decoders.py:90-162: sigma-net pos->64->16, colour-net (16+dir)->64->64->3.
+    pos 32 / dir 27 / hidden 64 (Part 2 Instant) runs on the fused HIP tiny-MLP kernels; the time-conditioned
+    shape of Part 4 (pos 32 + 21) runs the same arithmetic as library GEMMs."""
 
     def __init__(self, pos_dim, dir_dim, hidden_dim=64):
         super().__init__()
-        if (pos_dim, dir_dim, hidden_dim) != (32, 27, 64):
-            raise NotImplementedError("libnerf_hip is compiled for pos 32 / dir 27 / hidden 64")
+        self.pos_dim, self.dir_dim, self.hidden_dim = pos_dim, dir_dim, hidden_dim
+        self.fused = (pos_dim, dir_dim, hidden_dim) == (32, 27, 64)
+        if not self.fused:
+            self._s_shapes = tiny_mlp_shapes(pos_dim, 16, hidden_dim, 1)
+            self._c_shapes = tiny_mlp_shapes(16 + dir_dim, 3, hidden_dim, 2)
+            self.sigma_net = ParamHolder(tiny_mlp_init(pos_dim, 16, hidden_dim, 1))
+            self.color_net = ParamHolder(tiny_mlp_init(16 + dir_dim, 3, hidden_dim, 2))
+            return
 
         def xavier(rows, cols, fan_in, fan_out):
             return (torch.rand(rows, cols) * 2 - 1) * (6.0 / (fan_in + fan_out)) ** 0.5
@@ -127,5 +176,58 @@ class InstantNeRFDecoder(BaseDecoder):
 
     def forward(self, x_enc, d_enc):
         """reference src/decoders.py:136-162: sigma = softplus(h0 - 5), rgb = colour-net(cat([h16, d_enc]))."""
+        if not self.fused:
+            h = tiny_mlp_apply(self.sigma_net.params, self._s_shapes, x_enc, 16)
+            sigma = torch.nn.functional.softplus(h[..., 0:1] - 5.0)
+            rgb = tiny_mlp_apply(self.color_net.params, self._c_shapes, torch.cat([h, d_enc], dim=-1), 3, sigmoid=True)
+            return rgb, sigma
         rgb, sigma = ops.instant_decoder_encoded(self.flat_parameters(), self.packed_weights(), x_enc, d_enc)
         return rgb, sigma.unsqueeze(-1)
+
+
+class HashDeformationDecoder(BaseDecoder):
+    """reference src/decoders.py:264-318: [hash features | time modulation] -> 64 -> 64 -> 3 (bias-free, ReLU),
+    times the learnable ``displacement_scale`` (0.1 at start)."""
+
+    def __init__(self, hash_dim, time_mod_dim, hidden_dim=64):
+        super().__init__()
+        self._shapes = tiny_mlp_shapes(hash_dim + time_mod_dim, 3, hidden_dim, 2)
+        self.deform_net = ParamHolder(tiny_mlp_init(hash_dim + time_mod_dim, 3, hidden_dim, 2))
+        self.displacement_scale = nn.Parameter(torch.tensor(0.1))
+
+    def forward(self, hash_feat, time_mod):
+        delta = tiny_mlp_apply(self.deform_net.params, self._shapes, torch.cat([hash_feat, time_mod], dim=-1), 3)
+        return delta * self.displacement_scale
+
+
+class TimeModulationNetwork(BaseDecoder):
+    """reference src/decoders.py:321-371: Linear/ReLU stack on the time code, sigmoid gate; last layer
+    xavier-uniform weights and bias -1."""
+
+    def __init__(self, time_dim, output_dim=64, hidden_dim=64, num_layers=2):
+        super().__init__()
+        self.output_dim = output_dim
+        layers, in_dim = [], time_dim
+        for i in range(num_layers):
+            out_dim = hidden_dim if i < num_layers - 1 else output_dim
+            layers.append(nn.Linear(in_dim, out_dim))
+            if i < num_layers - 1:
+                layers.append(nn.ReLU())
+            in_dim = out_dim
+        self.net = nn.Sequential(*layers)
+        nn.init.xavier_uniform_(layers[-1].weight)
+        nn.init.constant_(layers[-1].bias, -1.0)
+
+    def forward(self, time_feat):
+        return torch.sigmoid(self.net(time_feat))
+
+
+class DeformationNetwork(BaseDecoder):
+    """reference src/decoders.py:165-195 (Part 3 MLP deformation field): not part of the built rows."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("Part 3 (MLP deformation field) is out of the built scope; Part 4 (dual hash) is built")
+
+    def forward(self, *args):
+        raise NotImplementedError

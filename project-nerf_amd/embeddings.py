@@ -48,8 +48,8 @@ class HashRepresentation(BaseRepresentation):
     def __init__(self, n_levels=16, n_features_per_level=2, log2_hashmap_size=19, base_resolution=16,
                  per_level_scale=1.5, bound=1.0):
         super().__init__()
-        if n_features_per_level != 2 or n_levels != 16:
-            raise NotImplementedError("libnerf_hip is compiled for 16 levels x 2 features (32 hash channels)")
+        if n_features_per_level != 2 or not 1 <= n_levels <= 16:
+            raise NotImplementedError("libnerf_hip's hash-grid kernels are compiled for 2 features per level and up to 16 levels")
         self.bound = bound
         self.levels = ops.HashLevelTable(n_levels, log2_hashmap_size, base_resolution, per_level_scale)
         init = (torch.rand(self.levels.entries * 2) * 2 - 1) * 1e-4

@@ -608,26 +608,39 @@ class _HashEncode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, pts, levels, bound):
         out, _ = hash_encode_fwd(pts, table, levels, bound)
-        ctx.save_for_backward(pts)
-        ctx.levels, ctx.bound, ctx.table_shape = levels, bound, table.shape
+        ctx.save_for_backward(pts, table)
+        ctx.levels, ctx.bound = levels, bound
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        (pts,) = ctx.saved_tensors
-        g = torch.zeros(ctx.table_shape, device=pts.device)
-        hash_encode_bwd(pts, ctx.levels, ctx.bound, d_out.contiguous(), g)
-        return g, None, None, None
+        pts, table = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        g = d_pts = None
+        if ctx.needs_input_grad[0]:
+            g = torch.zeros(table.shape, device=pts.device)
+            hash_encode_bwd(pts, ctx.levels, ctx.bound, d_out, g)
+        if ctx.needs_input_grad[1]:
+            d_pts = hash_encode_bwd_input(pts, table, ctx.levels, ctx.bound, d_out)
+        return g, d_pts, None, None
+
+
+def hash_encode_bwd_input(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor) -> Tensor:
+    """d_pts [n,3]: gradient of the features w.r.t. the encoded positions (dynamic fields)."""
+    lib = _lib.load()
+    pts, table, d_feat = _dev(pts, "pts"), _dev(table, "table"), _dev(d_feat, "d_feat")
+    d_pts = torch.empty_like(pts)
+    _lib.check(lib.nerf_hash_encode_bwd_input(_p(pts), pts.shape[0], _p(table), levels.n_levels, *levels.host_args(), float(bound),
+                                              _p(d_feat), _p(d_pts), _stream()), "nerf_hash_encode_bwd_input")
+    return d_pts
 
 
 def hash_encode(table: Tensor, pts: Tensor, levels: HashLevelTable, bound: float) -> Tensor:
-    """features [n, 2 L] fp32, differentiable w.r.t. ``table`` [entries, 2]."""
+    """features [n, 2 L] fp32, differentiable w.r.t. ``table`` [entries, 2] and w.r.t. the positions."""
     pts = _dev(pts, "pts")
-    if pts.requires_grad:
-        raise NotImplementedError("gradients w.r.t. the encoded positions belong to the dynamic (Part 3/4) fields")
     if pts.shape[0] == 0:
         return pts.new_zeros(0, 2 * levels.n_levels)
-    if torch.is_grad_enabled() and table.requires_grad:
+    if torch.is_grad_enabled() and (table.requires_grad or pts.requires_grad):
         return _HashEncode.apply(table, pts, levels, bound)
     return hash_encode_fwd(pts, table, levels, bound)[0]
 

@@ -25,16 +25,29 @@ class DensityGrid(nn.Module):
         static fields overwrite, dynamic ones keep max(grid*decay, current) (renderer.py:35-132)."""
         res = self.resolution
         mode = getattr(model, "mode", "unknown")
-        if mode in ("part3", "part4"):
-            raise NotImplementedError("dynamic fields are not part of the built hot path yet")
+        if mode == "part3":
+            raise NotImplementedError("Part 3 (MLP deformation field) is outside the built scope")
         pts = ops.grid_lattice(self.bound, res, self.grid.device)
-        sig = torch.empty(res ** 3, device=self.grid.device)
         batch = 2 ** 18
-        for i in range(0, pts.shape[0], batch):
-            p = pts[i:i + batch]
-            _, s = model(p, torch.zeros_like(p))
-            sig[i:i + batch] = s.reshape(-1).float()
-        self.grid = sig.view(res, res, res)
+
+        def query(t_anchor=None):
+            sig = torch.empty(res ** 3, device=self.grid.device)
+            for i in range(0, pts.shape[0], batch):
+                p = pts[i:i + batch]
+                if t_anchor is None:
+                    _, s = model(p, torch.zeros_like(p))
+                else:
+                    _, s, _ = model(p, torch.zeros_like(p), t=torch.full((p.shape[0], 1), t_anchor, device=p.device))
+                sig[i:i + batch] = s.reshape(-1).float()
+            return sig
+
+        if mode == "part4":
+            # density at the three time anchors 0, 0.5, 1 (`time` is ignored), element-wise maximum, then the
+            # running maximum against the decayed history (reference src/renderer.py:65-86, 122-125)
+            sig = torch.stack([query(a) for a in (0.0, 0.5, 1.0)], 0).max(dim=0)[0]
+            self.binary_grid, ratio = ops.grid_threshold(sig.view(res, res, res).contiguous(), self.threshold, prev=self.grid, decay=decay)
+            return ratio
+        self.grid = query().view(res, res, res)
         self.binary_grid, ratio = ops.grid_threshold(self.grid, self.threshold)
         return ratio
 
@@ -60,12 +73,15 @@ def volume_render(rgb, sigma, z_vals, rays_d, bg_color=None):
 
 def render_rays(model, rays_o, rays_d, near, far, n_samples, perturb, density_grid=None, times=None,
                 white_bkgd=True, bg_color=None):
-    """reference src/renderer.py:240-384 for static fields: 3-tuple (rgb, depth, acc)."""
+    """reference src/renderer.py:240-384: 3-tuple (rgb, depth, acc) for static fields; for the dynamic (part4)
+    field a 4-tuple with ``extras['mean_delta_x']`` = sum_s w_s delta_x_s (missing ``times`` mean t = 0)."""
     device = rays_o.device
     n_rays = rays_o.shape[0]
     mode = getattr(model, "mode", "unknown")
-    if mode in ("part3", "part4") or times is not None:
-        raise NotImplementedError("dynamic fields are not part of the built hot path yet")
+    if mode == "part3":
+        raise NotImplementedError("Part 3 (MLP deformation field) is outside the built scope")
+    if mode == "part4":
+        return _render_rays_dynamic(model, rays_o, rays_d, near, far, n_samples, perturb, density_grid, times, white_bkgd, bg_color)
     if bg_color is None:
         bg_color = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)
     rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
@@ -95,6 +111,56 @@ def render_rays(model, rays_o, rays_d, near, far, n_samples, perturb, density_gr
     rgb = rgb.float().view(n_rays, n_samples, 3)
     sigma = sigma.float().view(n_rays, n_samples)
     return volume_render(rgb, sigma, z, rays_d, bg_color=bg_color)
+
+
+def _render_rays_dynamic(model, rays_o, rays_d, near, far, n_samples, perturb, density_grid, times, white_bkgd, bg_color):
+    """Dynamic branch of render_rays (reference src/renderer.py:277-384): per-ray times broadcast to the samples
+    (t = 0 if none were given), occupancy-masked query with zero-filled scatter of rgb / sigma / delta_x, compositing
+    with the displacement as an extra channel (one kernel yields rgb, depth, acc and mean_delta_x)."""
+    device = rays_o.device
+    n_rays = rays_o.shape[0]
+    if bg_color is None:
+        bg_color = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)
+    # the reference substitutes t = 0 for missing times BEFORE it decides on the return arity
+    # (src/renderer.py:279-284, 363), so a dynamic field always yields the 4-tuple
+    want_extras = True
+    if times is None:
+        times = torch.zeros((n_rays, 1), device=device)
+    rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+    u = torch.rand(n_rays, n_samples, device=device) if perturb else None
+    t_flat = times.expand(-1, n_samples).reshape(-1, 1)
+    if density_grid is not None:
+        z, slots, pts, dirs = ops.sample_compact(rays_o, rays_d, near, far, n_samples, density_grid.binary_grid, density_grid.bound, u=u)
+        active = slots >= 0
+        if pts.shape[0] == 0:                                   # keep the graph connected (renderer.py:309-311)
+            _, p_all, d_all = ops.sample_rays(rays_o[:1], rays_d[:1], near, far, n_samples,
+                                              u=None if u is None else u[:1].contiguous(), want_points=True)
+            pts, dirs = p_all[:1].contiguous(), d_all[:1].contiguous()
+            active = torch.zeros_like(active)
+            active[0] = True
+            order = torch.zeros(1, dtype=torch.long, device=device)
+        else:
+            order = slots[active].long()                        # compact row of every active sample
+        t_c = torch.empty(pts.shape[0], 1, device=device)
+        t_c[order] = t_flat[active]
+        c_rgb, c_sigma, c_delta = model(pts, dirs, t=t_c)
+        n = n_rays * n_samples
+        rgb = c_rgb.new_zeros(n, 3, dtype=torch.float32)
+        sigma = c_sigma.new_zeros(n, 1, dtype=torch.float32)
+        delta = c_delta.new_zeros(n, 3, dtype=torch.float32)
+        rgb[active] = c_rgb.float()[order]
+        sigma[active] = c_sigma.float()[order]
+        delta[active] = c_delta.float()[order]
+    else:
+        z, pts, dirs = ops.sample_rays(rays_o, rays_d, near, far, n_samples, u=u, want_points=True)
+        rgb, sigma, delta = model(pts, dirs, t=t_flat.contiguous())
+    rgb = rgb.float().view(n_rays, n_samples, 3)
+    sigma = sigma.float().view(n_rays, n_samples)
+    extra = delta.float().view(n_rays, n_samples, 3).contiguous() if want_extras else None
+    out_rgb, depth, acc, mean_delta = ops.composite(rgb.contiguous(), sigma.contiguous(), z, rays_d, bg_color, extra)
+    if want_extras:
+        return out_rgb, depth, acc, {"mean_delta_x": mean_delta}
+    return out_rgb, depth, acc
 
 
 def render_image(model, rays_o, rays_d, near, far, n_samples, chunk, white_bkgd):

@@ -327,6 +327,77 @@ def g13_instant_glue():
     del sys.modules["tinycudann"]
 
 
+PART4_CFG = {"mode": "part4", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 11, "base_resolution": 16,
+             "per_level_scale": 1.5, "scene_bound": 1.5, "L_embed_dir": 4, "L_embed_time": 10, "hidden_dim": 64,
+             "time_modulation_dim": 64, "time_modulation_layers": 2, "deform_n_levels": 12, "deform_n_features_per_level": 2,
+             "deform_log2_hashmap_size": 10, "deform_base_resolution": 16, "deform_per_level_scale": 1.5, "deform_hidden_dim": 64}
+
+
+def part4_table(n, phase):
+    i = torch.arange(n, dtype=torch.float64)
+    return (0.5 * torch.sin(0.37 * i + phase + 0.11 * (i % 7))).float()
+
+
+def g14_part4():
+    """The reference's Part 4 dual-hash field (src/core.py:148-225, 282-352) around the stand-in tinycudann:
+    forward (rgb, sigma, delta_x), its autograd (incl. the path through d features / d x of the canonical grid),
+    render_rays with times (4-tuple, mean_delta_x) behind an occupancy grid, DensityGrid.update at the three anchors."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tinycudann", os.path.join(HERE, "tinycudann_shim.py"))
+    shim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shim)
+    sys.modules["tinycudann"] = shim
+    torch.manual_seed(14)
+    model = NeuralField(dict(PART4_CFG))
+    with torch.no_grad():
+        for k, (name, ph) in enumerate((("canonical_repr", 0.0), ("deform_grid_start", 1.0), ("deform_grid_mid", 2.0), ("deform_grid_end", 3.0))):
+            t = getattr(model, name).encoding.params
+            t.copy_(part4_table(t.numel(), ph))
+        model.decoder.sigma_net.params[:64 * 64].mul_(1.5)
+        model.decoder.sigma_net.params[64 * 64:64 * 64 + 64].mul_(24.0)     # the density row: visible densities
+        model.deform_decoder.deform_net.params.mul_(2.0)
+    sd = {k: v.clone() for k, v in model.state_dict().items() if "encoding.params" not in k and "freq_bands" not in k}
+    gen = torch.Generator().manual_seed(41)
+    n = 400
+    pts = (torch.rand(n, 3, generator=gen) - 0.5) * 3.2
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    times = torch.rand(n, 1, generator=gen)
+    times[:3] = torch.tensor([[0.0], [0.5], [1.0]])
+    model.eval()
+    rgb, sigma, delta = model(pts, dirs, t=times)
+    w_rgb, w_dx = torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen)
+    model.zero_grad()
+    ((rgb * w_rgb).sum() + sigma.sum() + (delta * w_dx).sum()).backward()
+    grads = {}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        if "encoding.params" in k:
+            nz = torch.nonzero(p.grad).flatten()[::5]
+            grads["gi:" + k], grads["gv:" + k], grads["gn:" + k] = nz, p.grad[nz], p.grad.norm()
+        else:
+            grads["g:" + k] = p.grad.clone()
+    # ---- render_rays with times behind an occupancy grid
+    o, d = synth_rays(96, gen)
+    ray_t = torch.rand(96, 1, generator=gen)
+    grid = DensityGrid(resolution=64, bound=1.5, threshold=0.01)
+    ax = torch.linspace(-1.5, 1.5, 64)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    grid.binary_grid = (gx ** 2 + gy ** 2 + gz ** 2) < 1.1 ** 2
+    with torch.no_grad():
+        c, dep, acc, extras = render_rays(model, o, d, 2.0, 6.0, 48, False, density_grid=grid, times=ray_t,
+                                          bg_color=torch.tensor([0.2, 0.4, 0.6]))
+        c3 = render_rays(model, o[:8], d[:8], 2.0, 6.0, 48, False)                  # no times: 3-tuple at t = 0
+        dg = DensityGrid(resolution=24, bound=1.5, threshold=0.05)
+        r1 = dg.update(model, device="cpu", decay=0.95)
+        r2 = dg.update(model, device="cpu", decay=0.95)
+    save("g14_part4", pts=pts, dirs=dirs, times=times, rgb=rgb, sigma=sigma, delta=delta, w_rgb=w_rgb, w_dx=w_dx,
+         rays_o=o, rays_d=d, ray_t=ray_t, r_rgb=c, r_depth=dep, r_acc=acc, r_mean_delta=extras["mean_delta_x"],
+         r3_rgb=c3[0], n_tuple3=np.int64(len(c3)), grid=dg.grid, binary=dg.binary_grid, ratios=np.array([r1, r2]),
+         **{"w:" + k: v for k, v in sd.items()}, **grads)
+    del sys.modules["tinycudann"]
+
+
 def g11_psnr():
     mse = np.array([1e-4, 3.3e-3, 0.02, 0.25])
     save("g11_psnr", mse=mse, psnr=np.array([compute_psnr(m) for m in mse]))
@@ -353,3 +424,4 @@ if __name__ == "__main__":
     g11_psnr()
     g12_part1()
     g13_instant_glue()
+    g14_part4()
