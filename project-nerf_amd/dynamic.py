@@ -1,0 +1,100 @@
+"""Part 4 training / evaluation loop (mode part4; reference run.py:1562-2331 run_part4): DynamicDataset,
+NeuralField('part4'), render_rays with per-ray times, AdamW + cosine LR, occupancy grid refreshed at the three
+time anchors, best-on-validation checkpoints.  The reference's optional regularisers (temporal smoothness,
+unsupervised deformation consistency, total variation on the deformation grids) are outside the built scope
+(the path is sampling -> encodings -> decoders -> compositing); the displacement-magnitude term on
+``mean_delta_x`` is kept because it is part of render_rays' contract."""
+import os
+
+import numpy as np
+import torch
+
+
+def run_dynamic(cfg, args):
+    from .core import NeuralField
+    from .dataset import DynamicDataset
+    from .renderer import DensityGrid, render_rays
+    from .utils import compute_psnr, compute_psnr_torch
+    if not args.data_dir:
+        raise ValueError("Part 4 requires --data_dir pointing to a D-NeRF dataset root.")
+    if not torch.cuda.is_available():
+        raise RuntimeError("the NeRF hot path runs on a HIP device only (no CPU fallback)")
+    device = torch.device("cuda")
+    downscale, white_bkgd = cfg.get("downscale", 2), cfg.get("white_bkgd", True)
+    near, far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
+    n_samples = cfg.get("n_samples", 64)
+    render_n = cfg.get("render_n_samples", n_samples)
+    batch, iters, lr = cfg.get("batch_size", 4096), cfg.get("train_iters", 5000), cfg.get("learning_rate", 0.01)
+    chunk = args.render_chunk or cfg.get("chunk", 16384)
+    log_every = cfg.get("log_every", 50)
+    log_dir = os.path.join(cfg.get("log_dir", "output/part4"), os.path.basename(args.data_dir.rstrip("/")))
+    os.makedirs(log_dir, exist_ok=True)
+    train_set = DynamicDataset(args.data_dir, "train", downscale, white_bkgd, cfg.get("scene_scale", 1.0)).to(device)
+    split = "test" if os.path.exists(os.path.join(args.data_dir, "transforms_test.json")) else "train"
+    test_set = DynamicDataset(args.data_dir, split, downscale, white_bkgd, cfg.get("scene_scale", 1.0))
+    model = NeuralField(cfg).to(device)
+    grid = None
+    if cfg.get("use_density_grid", True):
+        grid = DensityGrid(cfg.get("grid_resolution", 64), cfg.get("scene_bound", 1.5), cfg.get("grid_threshold", 0.01)).to(device)
+    if args.checkpoint:
+        ckpt = torch.load(args.checkpoint, map_location=device)
+        model.load_state_dict(ckpt["model_state_dict"])
+        if grid is not None and "density_grid" in ckpt:
+            grid.load_state_dict(ckpt["density_grid"])
+    bg = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)
+
+    def evaluate(indices):
+        model.eval()
+        vals = []
+        with torch.no_grad():
+            for idx in indices:
+                o, d, tgt, t = test_set.get_image_rays(idx, device)
+                o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+                pred = torch.cat([render_rays(model, o[i:i + chunk], d[i:i + chunk], near, far, render_n, False, density_grid=grid,
+                                              times=t.expand(min(chunk, o.shape[0] - i), 1), bg_color=bg)[0]
+                                  for i in range(0, o.shape[0], chunk)], 0)
+                vals.append(compute_psnr_torch(pred.clamp(0, 1), tgt.reshape(-1, 3)))
+        model.train()
+        return float(np.mean(vals)) if vals else 0.0
+
+    best = 0.0
+    if not args.eval_only:
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=cfg.get("weight_decay", 1e-5))
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=cfg.get("eta_min", 1e-4))
+        reg_w = float(cfg.get("deformation_reg_weight", 1e-4))
+        warm, stop, decay = cfg.get("grid_warmup_iters", 256), cfg.get("grid_stop_ratio", 0.9), cfg.get("grid_decay", 0.95)
+        active = 1.0
+        model.train()
+        for step in range(1, iters + 1):
+            o, d, rgba, t = train_set.sample_random_rays(batch, device)
+            target = rgba[:, :3] * rgba[:, 3:4] + bg * (1 - rgba[:, 3:4])
+            pred, _, _, extras = render_rays(model, o, d, near, far, n_samples, True, density_grid=grid, times=t, bg_color=bg)
+            loss_rgb = torch.nn.functional.mse_loss(pred, target)
+            loss = loss_rgb + reg_w * extras["mean_delta_x"].abs().mean()
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            opt.step()
+            sched.step()
+            if grid is not None and step < iters * stop:
+                interval = 32 if step < iters * 0.1 else (128 if step < iters * 0.5 else 512)
+                if grid.should_update(step, interval, warm):
+                    model.eval()
+                    active = grid.update(model, device=device, decay=decay)      # three time anchors, running maximum
+                    model.train()
+            if step % log_every == 0:
+                print(f">>> Step {step}/{iters} | Loss {loss.item():.6f} | PSNR {compute_psnr(loss_rgb.item()):.2f} dB"
+                      f" | Skip: {(1 - active) * 100:.1f}%")
+            if step % cfg.get("val_every", 500) == 0 or step == iters:
+                v = evaluate(range(min(len(test_set), cfg.get("val_views", 4))))
+                print(f"    [Validation] PSNR: {v:.2f} dB")
+                if v > best:
+                    best = v
+                    save = {"model_state_dict": model.state_dict(), "config": cfg, "step": step, "val_psnr": best}
+                    if grid is not None:
+                        save["density_grid"] = grid.state_dict()
+                    torch.save(save, os.path.join(log_dir, "best_model.pth"))
+    n_eval = len(test_set) if args.render_n in (None, -1) else min(args.render_n, len(test_set))
+    avg = evaluate(range(n_eval))
+    print(f">>> Test PSNR: {avg:.2f} dB (best validation {best:.2f} dB)")
+    return avg

@@ -150,6 +150,12 @@ def run_part2_instant(cfg, args):
     return run_instant(cfg, args)
 
 
+def run_part4(cfg, args):
+    """Dual-hash dynamic NeRF (reference run.py:1562-2331)."""
+    from project_nerf_amd.dynamic import run_dynamic
+    return run_dynamic(cfg, args)
+
+
 def main():
     ap = argparse.ArgumentParser(description="MI355X-native NeRF (CLI of CV-Project2025/Project-NeRF)")
     ap.add_argument("--image", type=str, default=None)
@@ -169,8 +175,10 @@ def main():
         run_part2(cfg, args)
     elif mode == "part2_instant":
         run_part2_instant(cfg, args)
+    elif mode == "part4":
+        run_part4(cfg, args)
     else:
-        raise ValueError(f"mode {mode!r} is not built (part1_fourier, part2_nerf, part2_instant are); see DESIGN.md")
+        raise ValueError(f"mode {mode!r} is not built (part1_fourier, part2_nerf, part2_instant, part4 are); see DESIGN.md")
 
 
 if __name__ == "__main__":

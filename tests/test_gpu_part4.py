@@ -166,3 +166,37 @@ def test_part4_trains_through_the_module_surface(tmp_path):
     for name, p in m.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
     assert float(m.deform_grid_mid.encoding.params.grad.abs().sum()) > 0
+
+
+def test_run_py_cli_part4_trains_and_evaluates(tmp_path):
+    """`python run.py --config part4.yaml --data_dir <D-NeRF style root>`: the reference's entry point and YAML keys."""
+    import subprocess
+    import sys
+    import yaml
+    from PIL import Image
+    from conftest import ROOT
+    from src.dataset import look_at_pose, render_analytic_frame
+    root = str(tmp_path / "dyn")
+    size = 24
+    focal = 0.5 * size / np.tan(0.5 * 0.6911112070083618)
+    for split, count in (("train", 5), ("test", 2)):
+        os.makedirs(os.path.join(root, split))
+        frames = []
+        for k in range(count):
+            c2w = torch.tensor(look_at_pose(4.0311 * np.array([np.cos(k + 0.3), np.sin(k + 0.3), 0.5]) / np.sqrt(1.25)), dtype=torch.float32)
+            Image.fromarray((render_analytic_frame(c2w, size, focal, 64).numpy() * 255 + 0.5).astype(np.uint8), "RGBA").save(
+                os.path.join(root, split, f"r_{k}.png"))
+            frames.append({"file_path": f"./{split}/r_{k}", "transform_matrix": c2w.tolist(), "time": k / max(count - 1, 1)})
+        json.dump({"camera_angle_x": 0.6911112070083618, "frames": frames}, open(os.path.join(root, f"transforms_{split}.json"), "w"))
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part4.yaml.example")))
+    cfg.update(train_iters=30, batch_size=512, log_every=10, val_every=30, downscale=1, n_samples=24, render_n_samples=24,
+               log2_hashmap_size=12, deform_log2_hashmap_size=10, grid_resolution=24, grid_warmup_iters=8, log_dir=str(tmp_path / "out"))
+    cfg_path = tmp_path / "part4.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "run.py"), "--config", str(cfg_path), "--data_dir", root, "--render_n", "1"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Test PSNR" in r.stdout
+    ckpt = torch.load(tmp_path / "out" / "dyn" / "best_model.pth", map_location="cpu")
+    assert {"model_state_dict", "config", "step", "val_psnr", "density_grid"} <= set(ckpt)
+    assert "deform_grid_mid.encoding.params" in ckpt["model_state_dict"] and "canonical_repr.encoding.params" in ckpt["model_state_dict"]
