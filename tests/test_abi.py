@@ -91,3 +91,21 @@ def test_argument_validation_returns_error_codes(lib):
     assert h.nerf_sample_rays(None, None, None, 0, 64, 2.0, 6.0, None, None, None, None) == 0
     assert h.nerf_fourier_encode(None, 0, 3, 10, None, None) == 0
     assert h.nerf_active_mask(None, 0, None, 128, 1.5, None, None, None) == 0
+
+
+def test_reference_import_lines_resolve_against_this_package():
+    """The names the reference's own modules import from ``src.*`` (run.py:15-18, src/core.py:3-7 and the lazy
+    imports of DensityGrid / DynamicDataset in run.py) exist at the same module paths here."""
+    import project_nerf_amd  # noqa: F401
+    from src.core import NeuralField  # noqa: F401
+    from src.dataset import BlenderDataset, DynamicDataset  # noqa: F401
+    from src.renderer import DensityGrid, render_image, render_rays, sample_stratified, volume_render  # noqa: F401
+    from src.utils import compute_psnr, compute_psnr_torch, render_image_safe, TensorBoardLogger, get_exp_name  # noqa: F401
+    from src.embeddings import FourierRepresentation, HashRepresentation  # noqa: F401
+    from src.decoders import (StandardMLP, NeRFDecoder, InstantNeRFDecoder, DeformationNetwork,  # noqa: F401
+                              HashDeformationDecoder, TimeModulationNetwork)
+    from src.abstract import BaseDecoder, BaseRepresentation
+    assert issubclass(HashRepresentation, BaseRepresentation) and issubclass(InstantNeRFDecoder, BaseDecoder)
+    assert issubclass(HashDeformationDecoder, BaseDecoder) and issubclass(TimeModulationNetwork, BaseDecoder)
+    with pytest.raises(NotImplementedError):
+        DeformationNetwork(63, 21)              # Part 3's MLP deformation field: named, not built

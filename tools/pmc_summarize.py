@@ -18,7 +18,8 @@ import statistics
 import sys
 
 
-KEEP = {"pack_kernel", "sample_rays_kernel", "sample_pdf_kernel", "adam_kernel"}
+KEEP = {"pack_kernel", "pack16_kernel", "sample_rays_kernel", "sample_pdf_kernel", "adam_kernel", "train_batch_kernel", "bwd_amax_kernel",
+        "sample_compact_kernel", "tv_normsq_kernel", "adamw_clip_kernel", "gather_rays_kernel"}
 
 
 def short(name):
