@@ -351,7 +351,9 @@ def generate(mode):
             if s16:
                 a0, a1 = vr(T + 4 * (2 * (k & 1)), 4), vr(T + 4 * (2 * (k & 1) + 1), 4)
                 emit(f"v_mfma_f32_16x16x32_bf16 {a0}, %[w{j % D}], {g['bops'][k][0]}, {a0}")
-                mid = len(out)            # the fragment read of this slot goes between the two MFMAs (+0.85 %; GEN_NOSPLIT16: after them)
+                # the window register is refilled only AFTER both MFMAs of the pair have issued: a ds_read placed
+                # between them (measured +0.85 %) races the second MFMA's operand fetch whenever another wave holds
+                # the matrix pipe longer than the LDS latency -- wrong results on some boxes, found in round 2
                 emit(f"v_mfma_f32_16x16x32_bf16 {a1}, %[w{j % D}], {g['bops'][k][1]}, {a1}")
             elif "shape32" in ABLATE:
                 # timing probe of the 16x16x32 shape (results are wrong): the same operands feed two half-length MFMAs
@@ -372,8 +374,6 @@ def generate(mode):
                         wait_vm(lambda t, cc=gn["chunk"]: t == ("dma", cc), unknown_ok=False)
                     emit("s_barrier")
                 issue_read(jn)
-                if s16 and not os.environ.get("GEN_NOSPLIT16") and out[-1].startswith("ds_read") and not out[-2].startswith("s_"):
-                    out.insert(mid, out.pop())
             if pending_dma and not (first_of_chunk and k == 0):
                 dma_piece(*pending_dma.popleft())
             if k >= EPI_START or k == ks - 1:

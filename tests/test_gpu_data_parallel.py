@@ -101,5 +101,6 @@ def test_tv_weight_is_independent_of_world_size_in_the_engine():
         eng.g_net *= world                                  # the summing all-reduce over identical shards
         eng.apply_gradients()
         outs.append((eng.table.clone(), eng.net.clone()))
-    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-6
-    assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-6
+    # not bit-equal: the clip norm is an atomic fp32 sum whose order changes from run to run
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-5
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-5
