@@ -157,7 +157,8 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
         "imlp_fwd": event_ms(lambda: lib.nerf_imlp_fwd(P(eng.packed), P(ws), P(dirs), n, P(rgb), P(sigma), 1, stv), 20),
         "imlp_bwd": event_ms(lambda: lib.nerf_imlp_bwd(P(eng.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
                                                        P(eng.g_net), P(d_feat), stv), 20),
-        "hash_bwd": event_ms(lambda: ops.hash_encode_bwd(pts, eng.levels, eng.bound, d_feat, eng.g_table), 20),
+        "hash_bwd": event_ms(lambda: ops.hash_encode_bwd(pts, eng.levels, eng.bound, d_feat, eng.g_table,
+                                                         workspace=eng._hash_bwd_workspace(n)), 20),
         "tv_clip_adamw(table)": event_ms(lambda: ops.tv_clip_adamw_step(eng.table, eng.g_table, *eng.state["table"], 1, 0.0,
                                                                          tv_weight=eng.tv_weight, max_norm=1.0, weight_decay=eng.wd,
                                                                          grad_scale=1.0, scratch=eng._scratch), 20),
@@ -169,8 +170,10 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
     roof = {
         "hash_fwd": {"bound": "hbm", "kernel": "hash_fwd_kernel", "achieved": (gather + n * (12 + 2 * L * 2)) / k["hash_fwd"] * 1e-6,
                      "note": "table gathers (mostly L2 / Infinity Cache hits: the 52 MB table is re-read by every batch)"},
-        "hash_bwd": {"bound": "hbm", "kernel": "hash_bwd_kernel", "achieved": (gather + n * (12 + 2 * L * 4)) / k["hash_bwd"] * 1e-6,
-                     "note": "fp32 atomics: the chip retires ~21 G atomic LINE requests/s (tools/probe/atomic_rate.hip)"},
+        "hash_bwd": {"bound": "hbm", "kernel": "hash_bin_count + _plan + _scatter + _reduce kernels",
+                     "achieved": (gather + n * (12 + 2 * L * 4)) / k["hash_bwd"] * 1e-6,
+                     "note": "binned scatter: 12-byte corner records written once and read once (24 B per corner against the 8 B "
+                             "counted here), slice sums in LDS (64-bit fixed point), plain read-modify-write of the table"},
         "tv_clip_adamw(table)": {"bound": "hbm", "kernel": "tv_normsq_kernel + adamw_clip_kernel",
                                  "achieved": n_tab * 4 * 9 / k["tv_clip_adamw(table)"] * 1e-6},
         "imlp_fwd": {"bound": "hbm", "kernel": "imlp_fwd_kernel<true>", "achieved": n * (64 + 12 + 16 + 2 * (64 + 16 + 64 + 64 + 48)) / k["imlp_fwd"] * 1e-6,

@@ -44,7 +44,7 @@ int nerf_abi_version(void);
  * environment ONCE per process (NERF_CHAIN_LEGACY, NERF_FWD_CYCLES, NERF_WGRAD_OVH,
  * NERF_WGRAD_DEBUG, NERF_WGRAD_ONLY, NERF_HASH_BWD_ONLY_LEVEL, NERF_STASH_BF16); afterwards they
  * change only through nerf_set_option.  Names: "chain_legacy", "fwd_cycles", "wgrad_overhead",
- * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "stash_bf16", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed".  No hot-path launch reads the
+ * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "stash_bf16", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed".  No hot-path launch reads the
  * environment. */
 int nerf_set_option(const char* name, int value);
 int nerf_get_option(const char* name, int* value_out);
@@ -281,6 +281,17 @@ int nerf_hash_encode_bwd_levels(const float* pts, int64_t n, int n_levels, const
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table, int first_level, int end_level,
                          nerf_stream_t stream);
+/* the same with a workspace (nerf_hash_encode_bwd_workspace_bytes(n, n_levels), 256-B aligned; NULL = the
+ * atomic form above): the levels whose table exceeds the LDS pass are scattered as a partial SORT --
+ * contributions binned by 8192-entry table slice (12-byte records in the workspace), each slice summed in LDS
+ * by the workgroup that owns it and added to d_table with plain coalesced read-modify-writes.  No global
+ * float atomics on the hashed levels (they retire per line request, ~20 G/s, wherever they land).  d_table
+ * must not be updated by another stream during the call.  Same sums as the atomic form up to fp32 order. */
+size_t nerf_hash_encode_bwd_workspace_bytes(int64_t n, int n_levels);
+int nerf_hash_encode_bwd_ws(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                         const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                         const unsigned* dense_host, float bound, const float* d_feat, float* d_table, int first_level, int end_level,
+                         void* workspace, size_t workspace_bytes, nerf_stream_t stream);
 /* gradient with respect to the encoded positions (dynamic fields encode x + delta_x: reference
  * src/core.py:268-271, 341-344): d_pts [n,3] = d_feat . d features / d x, zero along an axis on which
  * HashRepresentation's clamp is active; d_pts is OVERWRITTEN. */

@@ -27,6 +27,7 @@ static const OptionSlot kSlots[] = {
     {"wgrad_debug", "NERF_WGRAD_DEBUG", &Options::wgrad_debug},
     {"wgrad_only", "NERF_WGRAD_ONLY", &Options::wgrad_only},
     {"hash_bwd_only_level", "NERF_HASH_BWD_ONLY_LEVEL", &Options::hash_bwd_only_level},
+    {"hash_bwd_atomic", "NERF_HASH_BWD_ATOMIC", &Options::hash_bwd_atomic},
     {"infer_shape32", "NERF_INFER_SHAPE32", &Options::infer_shape32},
     {"stash_bf16", "NERF_STASH_BF16", &Options::stash_bf16},
 };

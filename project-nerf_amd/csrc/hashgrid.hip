@@ -218,6 +218,264 @@ hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0
   }
 }
 
+// ---- binned scatter (workspace form) --------------------------------------------------------------------
+// Float atomics retire per line REQUEST wherever they land (tools/probe/atomic_scope.hip: 20 G/s, the same in a
+// 0.5 MB table and under workgroup scope), and the hashed levels scatter every corner into its own line.  The
+// workspace form turns the scatter into one partial sort: the contributions of a level are binned by table
+// SLICE (kSlice entries = 64 KiB of float2), a workgroup then owns a slice, sums its bin in LDS and adds the
+// slice to d_table with plain coalesced read-modify-writes -- no global float atomics on the hot part.
+//   1 count   : corners per (level, slice), LDS histogram per workgroup, one global add per bin and workgroup
+//   2 plan    : exclusive scan -> bin starts / write cursors; work items = (bin, <= kChunk records); a bin cut
+//               into several items (dense coarse levels: thousands of samples per cell) flushes with atomics
+//   3 scatter : records {slot in slice, w g0, w g1} (12 B) to cursor positions, ranges reserved per workgroup
+//   4 reduce  : one workgroup per item sums its records into the LDS slice, flush of the non-zero entries
+// The LDS sums are 64-bit FIXED POINT (ds_add_u64): ds_add_f32 retires one lane every three clocks whatever the
+// addresses (tools/probe/lds_atomic_rate.hip: 0.33 lanes/clk/CU against 4.7 for ds_add_u64, 7.8 for ds_add_u32).
+// The scale is a power of two taken from the largest |d_feat| of the call (found by the count pass), so that a
+// term keeps 38 bits below that maximum -- finer than the fp32 sum it replaces -- and 2^25 terms cannot overflow;
+// integer sums also make the result independent of the order of the records.
+constexpr unsigned kSliceLog2 = 12, kSlice = 1u << kSliceLog2;   // 4096 entries x 2 features x 8 B = 64 KiB of LDS
+constexpr unsigned kChunk = 32768;             // records per work item
+constexpr unsigned kMaxSlices = 4096;          // per level (LDS histogram); larger tables use the atomic form
+constexpr int kMaxBins = 65536;
+constexpr int kFixedBits = 38;
+
+struct BinPlan {
+  int first, count;                            // levels [first, first + count)
+  unsigned bin0[kMaxLevels + 1];               // first bin of level first + i; bin0[count] = number of bins
+};
+
+struct BinHeader {                             // start of the workspace
+  unsigned n_items, n_records, amax_bits, pad;  // amax_bits: largest |d_feat| of the call as fp32 bits
+};
+struct BinItem {
+  unsigned entry0, begin, end, atomic;         // first table entry of the slice, record range, flush mode
+};
+struct BinRecord {
+  unsigned slot;
+  float g0, g1;
+};
+
+struct BinWorkspace {
+  BinHeader* header;
+  unsigned* count;                             // [bins]
+  unsigned* cursor;                            // [bins]
+  BinItem* items;                              // [max_items]
+  BinRecord* records;
+};
+
+static size_t bin_max_items(int64_t n, int n_levels) { return (size_t)(n * 8 * n_levels / kChunk) + kMaxBins; }
+
+static BinWorkspace carve(void* base, int64_t n, int n_levels) {
+  char* p = static_cast<char*>(base);
+  BinWorkspace w;
+  w.header = reinterpret_cast<BinHeader*>(p);                 p += 256;
+  w.count = reinterpret_cast<unsigned*>(p);                   p += sizeof(unsigned) * kMaxBins;
+  w.cursor = reinterpret_cast<unsigned*>(p);                  p += sizeof(unsigned) * kMaxBins;
+  w.items = reinterpret_cast<BinItem*>(p);                    p += (sizeof(BinItem) * bin_max_items(n, n_levels) + 255) / 256 * 256;
+  w.records = reinterpret_cast<BinRecord*>(p);
+  return w;
+}
+
+static size_t bin_workspace_bytes(int64_t n, int n_levels) {
+  return 256 + 2 * sizeof(unsigned) * kMaxBins + (sizeof(BinItem) * bin_max_items(n, n_levels) + 255) / 256 * 256 +
+         sizeof(BinRecord) * (size_t)n * 8 * (size_t)n_levels;
+}
+
+__device__ __forceinline__ bool point_gradient(const float* __restrict__ d_feat, int64_t p, int n_levels, int lvl, float& g0, float& g1) {
+  const float2 g = *reinterpret_cast<const float2*>(d_feat + p * (2 * n_levels) + 2 * lvl);
+  g0 = g.x;
+  g1 = g.y;
+  return g0 != 0.0f || g1 != 0.0f;
+}
+
+__global__ void __launch_bounds__(512)
+hash_bin_count_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
+                      unsigned* __restrict__ count, BinHeader* __restrict__ header) {
+  __shared__ unsigned hist[kMaxSlices];
+  __shared__ unsigned wg_amax;
+  const int lvl = plan.first + blockIdx.y;
+  const unsigned bins = plan.bin0[blockIdx.y + 1] - plan.bin0[blockIdx.y], offset = L.offset[lvl];
+  for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) hist[i] = 0;
+  if (threadIdx.x == 0) wg_amax = 0;
+  __syncthreads();
+  float amax = 0.0f;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    float g0, g1;
+    if (!point_gradient(d_feat, p, L.n_levels, lvl, g0, g1)) continue;
+    amax = fmaxf(amax, fmaxf(fabsf(g0), fabsf(g1)));
+    const Corner c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&hist[(c.idx[k] - offset) >> kSliceLog2], 1u);
+  }
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if ((threadIdx.x & 63) == 0 && amax > 0.0f && amax <= 3.0e38f) atomicMax(&wg_amax, __float_as_uint(amax));
+  __syncthreads();
+  // one contended global atomic per workgroup at most, none once a larger value is visible
+  if (threadIdx.x == 0 && wg_amax > __hip_atomic_load(&header->amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(&header->amax_bits, wg_amax);
+  for (unsigned i = threadIdx.x; i < bins; i += blockDim.x)
+    if (hist[i] != 0) atomicAdd(count + plan.bin0[blockIdx.y] + i, hist[i]);
+}
+
+// 2^s with |v| 2^s < 2^kFixedBits for every |v| <= amax; s clamped so that both 2^s and 2^-s are normal fp32
+__device__ __forceinline__ int fixed_shift(unsigned amax_bits) {
+  const int e = (int)(amax_bits >> 23) - 126;                     // amax < 2^e
+  int s = kFixedBits - e;
+  return s > 100 ? 100 : (s < -80 ? -80 : s);
+}
+
+// one workgroup of 1024: bins in rounds of 1024 with a carried total
+__global__ void __launch_bounds__(1024)
+hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ count, unsigned* __restrict__ cursor,
+                     BinItem* __restrict__ items, BinHeader* __restrict__ header) {
+  __shared__ unsigned scan_r[1024], scan_i[1024];
+  __shared__ unsigned carry_r, carry_i;
+  const unsigned n_bins = plan.bin0[plan.count];
+  if (threadIdx.x == 0) carry_r = carry_i = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < n_bins; base += 1024) {
+    const unsigned b = base + threadIdx.x;
+    const unsigned c = b < n_bins ? count[b] : 0u;
+    const unsigned it = (c + kChunk - 1) / kChunk;
+    scan_r[threadIdx.x] = c;
+    scan_i[threadIdx.x] = it;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {                 // inclusive Hillis-Steele scan of both columns
+      const unsigned ar = threadIdx.x >= d ? scan_r[threadIdx.x - d] : 0u, ai = threadIdx.x >= d ? scan_i[threadIdx.x - d] : 0u;
+      __syncthreads();
+      scan_r[threadIdx.x] += ar;
+      scan_i[threadIdx.x] += ai;
+      __syncthreads();
+    }
+    const unsigned r0 = carry_r + scan_r[threadIdx.x] - c, i0 = carry_i + scan_i[threadIdx.x] - it;
+    if (b < n_bins) {
+      cursor[b] = r0;
+      int li = 0;
+      while (li + 1 < plan.count && plan.bin0[li + 1] <= b) ++li;
+      const unsigned entry0 = L.offset[plan.first + li] + ((b - plan.bin0[li]) << kSliceLog2);
+      for (unsigned j = 0; j < it; ++j) {
+        BinItem item;
+        item.entry0 = entry0;
+        item.begin = r0 + j * kChunk;
+        item.end = r0 + min(c, (j + 1) * kChunk);
+        item.atomic = it > 1 ? 1u : 0u;
+        items[i0 + j] = item;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) {
+      carry_r += scan_r[1023];
+      carry_i += scan_i[1023];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    header->n_items = carry_i;
+    header->n_records = carry_r;
+  }
+}
+
+__global__ void __launch_bounds__(512)
+hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
+                        unsigned* __restrict__ cursor, BinRecord* __restrict__ records) {
+  __shared__ unsigned cnt[kMaxSlices], base[kMaxSlices];
+  const int lvl = plan.first + blockIdx.y;
+  const unsigned bins = plan.bin0[blockIdx.y + 1] - plan.bin0[blockIdx.y], offset = L.offset[lvl];
+  for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) cnt[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p0 = blockIdx.x * (int64_t)blockDim.x; p0 < n; p0 += stride) {     // uniform trip count: barriers inside
+    const int64_t p = p0 + threadIdx.x;
+    float g0 = 0.0f, g1 = 0.0f;
+    const bool live = p < n && point_gradient(d_feat, p, L.n_levels, lvl, g0, g1);
+    Corner c;
+    unsigned slot[8];
+    if (live) {
+      c = corners_of(L, lvl, pts[p * 3 + 0], pts[p * 3 + 1], pts[p * 3 + 2]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) slot[k] = atomicAdd(&cnt[(c.idx[k] - offset) >> kSliceLog2], 1u);
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) {
+      const unsigned v = cnt[i];
+      if (v != 0) base[i] = atomicAdd(cursor + plan.bin0[blockIdx.y] + i, v);
+      cnt[i] = 0;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const unsigned local = c.idx[k] - offset;
+        BinRecord r;
+        r.slot = local & (kSlice - 1);
+        r.g0 = c.w[k] * g0;
+        r.g1 = c.w[k] * g1;
+        records[base[local >> kSliceLog2] + slot[k]] = r;
+      }
+    }
+    __syncthreads();                          // base[] is rewritten by the next round
+  }
+}
+
+__global__ void __launch_bounds__(512)
+hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __restrict__ items, const BinRecord* __restrict__ records,
+                       float* __restrict__ d_table, unsigned table_entries) {
+  __shared__ unsigned long long acc[2 * kSlice];            // 64 KiB of 64-bit fixed-point sums
+  const int shift = fixed_shift(header->amax_bits);
+  const float scale = __uint_as_float((unsigned)(127 + shift) << 23), inv_scale = __uint_as_float((unsigned)(127 - shift) << 23);
+  for (unsigned item_id = blockIdx.x; item_id < header->n_items; item_id += gridDim.x) {
+    const BinItem item = items[item_id];
+    for (unsigned i = threadIdx.x; i < 2 * kSlice; i += blockDim.x) acc[i] = 0ull;
+    __syncthreads();
+    // kUnroll independent record loads in flight per lane: the loop is latency-bound otherwise (49 records per lane)
+    constexpr int kUnroll = 8;
+    for (unsigned r0 = item.begin + threadIdx.x; r0 < item.end; r0 += kUnroll * blockDim.x) {
+      BinRecord rec[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const unsigned r = r0 + u * blockDim.x;
+        rec[u] = records[r < item.end ? r : item.end - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (r0 + u * blockDim.x < item.end) {
+          atomicAdd(&acc[2 * rec[u].slot + 0], (unsigned long long)__float2ll_rn(rec[u].g0 * scale));
+          atomicAdd(&acc[2 * rec[u].slot + 1], (unsigned long long)__float2ll_rn(rec[u].g1 * scale));
+        }
+      }
+    }
+    __syncthreads();
+    float2* dst = reinterpret_cast<float2*>(d_table) + item.entry0;
+    const unsigned live = min(kSlice, table_entries - item.entry0);
+    if (item.atomic) {
+      for (unsigned i = threadIdx.x; i < live; i += blockDim.x) {
+        const long long a0 = (long long)acc[2 * i], a1 = (long long)acc[2 * i + 1];
+        if (a0 != 0) atomicAdd(&dst[i].x, __ll2float_rn(a0) * inv_scale);
+        if (a1 != 0) atomicAdd(&dst[i].y, __ll2float_rn(a1) * inv_scale);
+      }
+    } else {
+      // the slice belongs to this workgroup for the whole launch: plain read-modify-write, all loads first
+      static_assert(kSlice % 512 == 0, "flush");
+      constexpr int kPer = kSlice / 512;
+      float2 t[kPer];
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const unsigned i = threadIdx.x + u * 512;
+        t[u] = i < live ? dst[i] : make_float2(0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const unsigned i = threadIdx.x + u * 512;
+        const long long a0 = (long long)acc[2 * i], a1 = (long long)acc[2 * i + 1];
+        if (i < live && (a0 != 0 || a1 != 0))
+          dst[i] = make_float2(t[u].x + __ll2float_rn(a0) * inv_scale, t[u].y + __ll2float_rn(a1) * inv_scale);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 static int fill_levels(HashLevels& L, int n_levels, const float* scale, const unsigned* res, const unsigned* size,
                        const unsigned* offset, const unsigned* dense, float bound) {
   if (n_levels < 1 || n_levels > kMaxLevels) return fail(NERF_EINVAL, "hash grid: n_levels=%d (1..16)", n_levels);
@@ -257,7 +515,7 @@ extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* ta
 static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float* scale_host,
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
-                         int level0, int level1, nerf_stream_t stream) {
+                         int level0, int level1, nerf_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
   NERF_REQUIRE(level0 >= 0 && level0 <= level1 && level1 <= n_levels, "nerf_hash_encode_bwd: levels [%d, %d) of %d", level0, level1, n_levels);
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
@@ -270,14 +528,51 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
   if (rc != NERF_OK) return rc;
   int n_small = 0;                      // leading levels whose table fits in LDS
   while (n_small < n_levels && size_host[n_small] <= (unsigned)kLdsEntries) ++n_small;
-  if (level0 < n_small) {
+  // the workspace form bins EVERY level (the small dense ones too: their LDS pass is ds_add_f32-bound)
+  const int first_big = level0;
+  bool binned = workspace != nullptr && first_big < level1 && options().hash_bwd_only_level < 0 && !options().hash_bwd_atomic;
+  BinPlan plan;
+  if (binned) {
+    plan.first = first_big;
+    plan.count = level1 - first_big;
+    plan.bin0[0] = 0;
+    unsigned table_entries = 0;
+    for (int i = 0; i < n_levels; ++i) table_entries = offset_host[i] + size_host[i] > table_entries ? offset_host[i] + size_host[i] : table_entries;
+    for (int i = 0; i < plan.count; ++i) {
+      const unsigned slices = (size_host[first_big + i] + kSlice - 1) / kSlice;
+      if (slices > kMaxSlices) binned = false;
+      plan.bin0[i + 1] = plan.bin0[i] + slices;
+    }
+    if (binned && plan.bin0[plan.count] > (unsigned)kMaxBins) binned = false;
+    if (binned) {
+      NERF_REQUIRE(workspace_bytes >= bin_workspace_bytes(n, n_levels), "nerf_hash_encode_bwd_ws: workspace of %zu bytes, need %zu",
+                   workspace_bytes, bin_workspace_bytes(n, n_levels));
+      NERF_REQUIRE((size_t)n * 8 * (size_t)n_levels < 0xffffffffull, "nerf_hash_encode_bwd_ws: n=%lld too large for 32-bit record offsets", (long long)n);
+      const BinWorkspace w = carve(workspace, n, n_levels);
+      const unsigned n_bins = plan.bin0[plan.count];
+      if (hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * n_bins, as_stream(stream)) != hipSuccess)   // header + counts
+        return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws: memset failed");
+      int64_t bx = (n + 511) / 512;
+      const int64_t bx_count = bx > 256 ? 256 : bx, bx_scatter = bx > 128 ? 128 : bx;
+      hipLaunchKernelGGL(hash_bin_count_kernel, dim3((int)bx_count, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan, d_feat,
+                         w.count, w.header);
+      hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header);
+      hipLaunchKernelGGL(hash_bin_scatter_kernel, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
+                         d_feat, w.cursor, w.records);
+      size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
+      if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
+      hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,
+                         d_table, table_entries);
+    }
+  }
+  if (level0 < n_small && !binned) {
     const int hi = level1 < n_small ? level1 : n_small;
     int64_t bx = (n + 511) / 512;
     if (bx > 128) bx = 128;             // each workgroup flushes its whole LDS table once
     hipLaunchKernelGGL(hash_bwd_kernel<true>, dim3((int)bx, hi - level0), dim3(512), kLdsEntries * 8, as_stream(stream), pts, n, L,
                        level0, d_feat, d_table);
   }
-  if (n_small < level1) {
+  if (n_small < level1 && !binned) {
     int64_t bx = (4 * n + 511) / 512;
     if (bx > 1024) bx = 1024;
     int first = level0 > n_small ? level0 : n_small, count = level1 - first;
@@ -306,6 +601,20 @@ extern "C" int nerf_hash_encode_bwd_levels(const float* pts, int64_t n, int n_le
                                            int first_level, int end_level, nerf_stream_t stream) {
   return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table,
                        first_level, end_level, stream);
+}
+
+extern "C" size_t nerf_hash_encode_bwd_workspace_bytes(int64_t n, int n_levels) {
+  if (n <= 0 || n_levels < 1 || n_levels > kMaxLevels) return 0;
+  return bin_workspace_bytes(n, n_levels);
+}
+
+extern "C" int nerf_hash_encode_bwd_ws(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                       const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                       const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                                       int first_level, int end_level, void* workspace, size_t workspace_bytes,
+                                       nerf_stream_t stream) {
+  return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table,
+                       first_level, end_level, stream, workspace, workspace_bytes);
 }
 
 extern "C" int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const float* table, int n_levels,

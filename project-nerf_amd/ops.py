@@ -545,14 +545,31 @@ def hash_encode_fwd(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: f
     return out, idx
 
 
+def _hash_bwd_scratch(pts: Tensor, levels: "HashLevelTable") -> Tensor:
+    """workspace of the binned scatter for the autograd paths (torch's caching allocator hands the block back)"""
+    return torch.empty(_lib.load().nerf_hash_encode_bwd_workspace_bytes(pts.shape[0], levels.n_levels), dtype=torch.uint8,
+                       device=pts.device)
+
+
+def hash_encode_bwd_workspace_bytes(n: int, n_levels: int) -> int:
+    return _lib.load().nerf_hash_encode_bwd_workspace_bytes(n, n_levels)
+
+
 def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor, d_table: Tensor,
-                    level_range: Optional[Tuple[int, int]] = None) -> None:
-    """Scatter-add into ``d_table`` (caller zeroes it); ``level_range`` (lo, hi) restricts the pass to those levels."""
+                    level_range: Optional[Tuple[int, int]] = None, workspace: Optional[Tensor] = None) -> None:
+    """Scatter-add into ``d_table`` (caller zeroes it); ``level_range`` (lo, hi) restricts the pass to those levels.
+    ``workspace`` (uint8, >= hash_encode_bwd_workspace_bytes(n, L)) selects the binned form: partial sort by
+    table slice + LDS sums instead of global float atomics."""
     lib = _lib.load()
     pts, d_feat = _dev(pts, "pts"), _dev(d_feat, "d_feat")
     lo, hi = level_range if level_range is not None else (0, levels.n_levels)
-    _lib.check(lib.nerf_hash_encode_bwd_levels(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
-                                               _p(d_feat), _p(d_table), lo, hi, _stream()), "nerf_hash_encode_bwd")
+    if workspace is None:
+        _lib.check(lib.nerf_hash_encode_bwd_levels(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
+                                                   _p(d_feat), _p(d_table), lo, hi, _stream()), "nerf_hash_encode_bwd")
+    else:
+        _lib.check(lib.nerf_hash_encode_bwd_ws(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
+                                               _p(d_feat), _p(d_table), lo, hi, _p(workspace), workspace.numel(), _stream()),
+                   "nerf_hash_encode_bwd_ws")
 
 
 IMLP_PARAM_COUNT = 11264
@@ -598,7 +615,7 @@ class _InstantField(torch.autograd.Function):
         _lib.check(lib.nerf_imlp_bwd(_p(packed), _p(ws), _p(rgb), _p(sigma), _p(d_rgb.contiguous()),
                                      _p(d_sigma.contiguous()), n, _p(g_net), _p(d_feat), _stream()), "nerf_imlp_bwd")
         g_table = torch.zeros(ctx.table_shape, device=pts.device)
-        hash_encode_bwd(pts, ctx.levels, ctx.bound, d_feat, g_table)
+        hash_encode_bwd(pts, ctx.levels, ctx.bound, d_feat, g_table, workspace=_hash_bwd_scratch(pts, ctx.levels))
         return g_table, g_net, None, None, None, None, None, None
 
 
@@ -619,7 +636,7 @@ class _HashEncode(torch.autograd.Function):
         g = d_pts = None
         if ctx.needs_input_grad[0]:
             g = torch.zeros(table.shape, device=pts.device)
-            hash_encode_bwd(pts, ctx.levels, ctx.bound, d_out, g)
+            hash_encode_bwd(pts, ctx.levels, ctx.bound, d_out, g, workspace=_hash_bwd_scratch(pts, ctx.levels))
         if ctx.needs_input_grad[1]:
             d_pts = hash_encode_bwd_input(pts, table, ctx.levels, ctx.bound, d_out)
         return g, d_pts, None, None

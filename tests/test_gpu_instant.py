@@ -57,8 +57,11 @@ def test_hash_indices_bit_exact_and_features(ops, n):
     np.testing.assert_allclose(feat.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("form", ["atomic", "binned"])
 @pytest.mark.parametrize("n", [300, 5000])
-def test_hash_backward_scatter_vs_autograd(ops, n):
+def test_hash_backward_scatter_vs_autograd(ops, n, form):
+    """atomic: global float atomics; binned: the workspace form (partial sort by table slice, 64-bit fixed-point
+    LDS sums, plain read-modify-write of d_table)."""
     lv = O.hash_grid_levels(16, 19, 16, 1.5)
     t = ops.HashLevelTable(16, 19, 16, 1.5)
     pts, _ = make_inputs(n, 3)
@@ -67,8 +70,52 @@ def test_hash_backward_scatter_vs_autograd(ops, n):
     table = torch.zeros(t.entries, 2, requires_grad=True)
     (O.hash_encode(lv, table, O.hash_normalise(pts, 1.5)) * d_feat).sum().backward()
     g = torch.zeros(t.entries, 2, device="cuda")
-    ops.hash_encode_bwd(pts.cuda(), t, 1.5, d_feat.cuda(), g)
+    ws = torch.empty(ops.hash_encode_bwd_workspace_bytes(n, 16), dtype=torch.uint8, device="cuda") if form == "binned" else None
+    ops.hash_encode_bwd(pts.cuda(), t, 1.5, d_feat.cuda(), g, workspace=ws)
     np.testing.assert_allclose(g.cpu().numpy(), table.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_hash_backward_binned_form_properties(ops):
+    """The workspace form of the scatter: (i) accumulates into d_table like the atomic form, (ii) level ranges
+    compose, (iii) the fixed-point scale follows the gradient magnitude (1e-12 and 1e+12 times the same gradient
+    give 1e-12 and 1e+12 times the same table gradient), (iv) a bin that is cut into several work items (all
+    points in one cell of a coarse level: thousands of records per slot) sums correctly, (v) results repeat bit
+    for bit as long as no bin is cut (integer sums), (vi) an all-zero gradient is a no-op."""
+    t = ops.HashLevelTable(16, 19, 16, 1.5)
+    n = 40000
+    gen = torch.Generator().manual_seed(11)
+    pts = ((torch.rand(n, 3, generator=gen) - 0.5) * 0.05 + torch.tensor([0.31, -0.22, 0.4])).cuda()   # one coarse cell
+    d_feat = torch.randn(n, 32, generator=gen).cuda()
+    ws = torch.empty(ops.hash_encode_bwd_workspace_bytes(n, 16), dtype=torch.uint8, device="cuda")
+    ref = torch.zeros(t.entries, 2, device="cuda")
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, ref)
+    scale = float(ref.abs().max())
+    a = torch.zeros_like(ref)
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, a, workspace=ws)
+    assert float((a - ref).abs().max()) < 2e-5 * scale                 # (iv): fp32 atomics in `ref` carry the error
+    b = torch.zeros_like(ref)
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, b, workspace=ws)
+    assert float((a - b).abs().max()) < 1e-6 * scale                   # cut bins meet in d_table through float atomics
+    up, ug = make_inputs(3000, 8)[0].cuda(), torch.randn(3000, 32, generator=gen).cuda()
+    u = [torch.zeros_like(ref) for _ in range(2)]
+    for out in u:
+        ops.hash_encode_bwd(up, t, 1.5, ug, out, workspace=ws)
+    assert torch.equal(u[0], u[1])                                     # (v): no bin is cut at 24,000 records per level
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, b, workspace=ws)          # (i) += on top of the first pass
+    assert float((b - 2 * a).abs().max()) < 1e-6 * scale
+    c = torch.zeros_like(ref)
+    for lo, hi in ((0, 3), (3, 4), (4, 11), (11, 16)):                 # (ii)
+        ops.hash_encode_bwd(pts, t, 1.5, d_feat, c, level_range=(lo, hi), workspace=ws)
+    assert float((a - c).abs().max()) < 1e-6 * scale
+    for factor in (1e-12, 1e12):                                       # (iii)
+        d = torch.zeros_like(ref)
+        ops.hash_encode_bwd(pts, t, 1.5, d_feat * factor, d, workspace=ws)
+        assert float((d / factor - a).abs().max()) < 1e-5 * scale, factor
+    e = torch.zeros_like(ref)
+    ops.hash_encode_bwd(pts, t, 1.5, torch.zeros_like(d_feat), e, workspace=ws)   # (vi)
+    assert float(e.abs().max()) == 0.0
+    with pytest.raises(ops._lib.NerfHipError):
+        ops.hash_encode_bwd(pts, t, 1.5, d_feat, e, workspace=ws[:1 << 20])
 
 
 def q(x):
