@@ -1,13 +1,73 @@
 """Part 4 training / evaluation loop (mode part4; reference run.py:1562-2331 run_part4): DynamicDataset,
 NeuralField('part4'), render_rays with per-ray times, AdamW + cosine LR, occupancy grid refreshed at the three
-time anchors, best-on-validation checkpoints.  The reference's optional regularisers (temporal smoothness,
-unsupervised deformation consistency, total variation on the deformation grids) are outside the built scope
-(the path is sampling -> encodings -> decoders -> compositing); the displacement-magnitude term on
-``mean_delta_x`` is kept because it is part of render_rays' contract."""
+time anchors, best-on-validation checkpoints, and the loss terms of the reference's loop
+(``part4_regularisers``: displacement magnitude, total variation on the deformation grids and on the canonical
+grid, temporal smoothness, unsupervised consistency, tri-grid anchor; run.py:1832-1938) with its YAML keys,
+defaults and every-n-steps schedule.  They are compositions of the field's own operators -- the hash encodings
+run in HIP with their table gradients, the small MLPs as library GEMMs."""
 import os
 
 import numpy as np
 import torch
+
+
+def _total_variation(params):
+    """mean |p[i+1] - p[i]| over the flat parameter vector (run.py:1849-1851, 1857-1859)"""
+    return torch.mean(torch.abs(params[1:] - params[:-1]))
+
+
+def part4_regularisers(model, cfg, step, mean_delta_x, generator=None, probes=None):
+    """The non-photometric loss terms of the reference's Part 4 loop (run.py:1835-1938) as a dict of scalars; the
+    caller adds them to the RGB loss.  Same YAML keys, defaults, sample counts and compensation factors (a term
+    evaluated every k-th step is weighted by k).  ``generator``: optional torch.Generator for the random probes;
+    ``probes``: the probe points themselves (temporal_x/_t, unsup_x/_t, anchor_x) instead of fresh draws."""
+    device = mean_delta_x.device
+    zero = torch.zeros((), device=device)
+    bound = float(cfg.get("scene_bound", 1.5))
+    warm = cfg.get("grid_warmup_iters", 256)
+    rand = lambda *shape: torch.rand(*shape, device=device, generator=generator)
+    terms = {"reg": torch.mean(mean_delta_x ** 2) * float(cfg.get("deformation_reg_weight", 0.01))}
+    # total variation: the three displacement grids (averaged), then the canonical grid
+    terms["tv_disp"] = zero
+    if cfg.get("use_tv_displacement", True):
+        grids = [getattr(model, n) for n in ("deform_grid_start", "deform_grid_mid", "deform_grid_end") if hasattr(model, n)]
+        tv = sum(_total_variation(g.encoding.params) for g in grids)
+        terms["tv_disp"] = tv * float(cfg.get("tv_displacement_weight", 0.001)) / 3.0
+    terms["tv_canon"] = zero
+    tv_w = float(cfg.get("tv_loss_weight", 1e-5))
+    if tv_w > 0 and hasattr(model, "canonical_repr"):
+        terms["tv_canon"] = _total_variation(model.canonical_repr.encoding.params) * tv_w
+
+    def displacement(grid, x, t):
+        return model.deform_decoder(grid(x), model.time_modulation(model.time_encoder(t)))
+
+    # temporal smoothness: the displacement of a point changes little over eps (every 16th step, 64 probes)
+    terms["temporal"] = zero
+    if cfg.get("use_temporal_smooth", True) and step > warm and step % 16 == 0:
+        eps = float(cfg.get("temporal_epsilon", 0.02))
+        x = probes["temporal_x"] if probes else (rand(64, 3) * 2 - 1) * bound
+        t = probes["temporal_t"] if probes else rand(64, 1) * (1.0 - eps)
+        feat = model.deformation_grid(x)
+        d0 = model.deform_decoder(feat, model.time_modulation(model.time_encoder(t)))
+        d1 = model.deform_decoder(feat, model.time_modulation(model.time_encoder(t + eps)))
+        terms["temporal"] = torch.mean((d0 - d1) ** 2) * float(cfg.get("temporal_smooth_weight", 1e-4)) * 16
+    # unsupervised consistency: no net drift of the whole volume (every 32nd step, 128 probes)
+    terms["unsup"] = zero
+    if cfg.get("use_unsupervised_consistency", False) and step > warm and step % 32 == 0:
+        t = probes["unsup_t"] if probes else rand(128, 1)
+        x = probes["unsup_x"] if probes else (rand(128, 3) * 2 - 1) * bound
+        d = displacement(model.deformation_grid, x, t)
+        terms["unsup"] = torch.mean(torch.abs(d.mean(dim=0))) * float(cfg.get("unsup_consistency_weight", 0.001)) * 32
+    # tri-grid anchor: zero displacement at t = 0 on the start grid, start and mid grids agree at t = 1/6
+    terms["anchor"] = zero
+    if cfg.get("use_static_anchor", True) and step > warm and step % 16 == 0:
+        x = probes["anchor_x"] if probes else (rand(128, 3) * 2 - 1) * bound
+        at0 = displacement(model.deform_grid_start, x, torch.zeros(128, 1, device=device))
+        t6 = torch.full((128, 1), 1.0 / 6.0, device=device)
+        d_start, d_mid = displacement(model.deform_grid_start, x, t6), displacement(model.deform_grid_mid, x, t6)
+        consistency = torch.mean((d_start - d_mid) ** 2) * 0.1
+        terms["anchor"] = (torch.mean(at0 ** 2) + consistency) * float(cfg.get("static_anchor_weight", 0.01)) * 16
+    return terms
 
 
 def run_dynamic(cfg, args):
@@ -61,7 +121,6 @@ def run_dynamic(cfg, args):
     if not args.eval_only:
         opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=cfg.get("weight_decay", 1e-5))
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=cfg.get("eta_min", 1e-4))
-        reg_w = float(cfg.get("deformation_reg_weight", 1e-4))
         warm, stop, decay = cfg.get("grid_warmup_iters", 256), cfg.get("grid_stop_ratio", 0.9), cfg.get("grid_decay", 0.95)
         active = 1.0
         model.train()
@@ -70,10 +129,10 @@ def run_dynamic(cfg, args):
             target = rgba[:, :3] * rgba[:, 3:4] + bg * (1 - rgba[:, 3:4])
             pred, _, _, extras = render_rays(model, o, d, near, far, n_samples, True, density_grid=grid, times=t, bg_color=bg)
             loss_rgb = torch.nn.functional.mse_loss(pred, target)
-            loss = loss_rgb + reg_w * extras["mean_delta_x"].abs().mean()
+            loss = loss_rgb + sum(part4_regularisers(model, cfg, step, extras["mean_delta_x"]).values())
             opt.zero_grad()
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=float(cfg.get("max_grad_norm", 1.0)))
             opt.step()
             sched.step()
             if grid is not None and step < iters * stop:

@@ -391,7 +391,36 @@ def g14_part4():
         dg = DensityGrid(resolution=24, bound=1.5, threshold=0.05)
         r1 = dg.update(model, device="cpu", decay=0.95)
         r2 = dg.update(model, device="cpu", decay=0.95)
+    # ---- the loss terms of run_part4 (run.py:1835-1938) composed from the REFERENCE's operators on stored probes:
+    # the loop draws them with torch.rand on the device; the terms themselves are deterministic functions of them
+    reg_gen = torch.Generator().manual_seed(77)
+    eps = 0.02
+    probes = {"temporal_x": (torch.rand(64, 3, generator=reg_gen) * 2 - 1) * 1.5, "temporal_t": torch.rand(64, 1, generator=reg_gen) * (1 - eps),
+              "unsup_x": (torch.rand(128, 3, generator=reg_gen) * 2 - 1) * 1.5, "unsup_t": torch.rand(128, 1, generator=reg_gen),
+              "anchor_x": (torch.rand(128, 3, generator=reg_gen) * 2 - 1) * 1.5}
+    disp = lambda grid_, x_, t_: model.deform_decoder(grid_(x_), model.time_modulation(model.time_encoder(t_)))
+    model.zero_grad()
+    tv = lambda p_: torch.mean(torch.abs(p_[1:] - p_[:-1]))
+    reg = {
+        "reg": torch.mean(extras["mean_delta_x"] ** 2) * 0.01,
+        "tv_disp": sum(tv(getattr(model, n_).encoding.params) for n_ in ("deform_grid_start", "deform_grid_mid", "deform_grid_end")) * 0.001 / 3.0,
+        "tv_canon": tv(model.canonical_repr.encoding.params) * 1e-5,
+    }
+    feat_ = model.deformation_grid(probes["temporal_x"])
+    d0_ = model.deform_decoder(feat_, model.time_modulation(model.time_encoder(probes["temporal_t"])))
+    d1_ = model.deform_decoder(feat_, model.time_modulation(model.time_encoder(probes["temporal_t"] + eps)))
+    reg["temporal"] = torch.mean((d0_ - d1_) ** 2) * 1e-4 * 16
+    reg["unsup"] = torch.mean(torch.abs(disp(model.deformation_grid, probes["unsup_x"], probes["unsup_t"]).mean(dim=0))) * 0.001 * 32
+    at0_ = disp(model.deform_grid_start, probes["anchor_x"], torch.zeros(128, 1))
+    t6_ = torch.full((128, 1), 1.0 / 6.0)
+    cons_ = torch.mean((disp(model.deform_grid_start, probes["anchor_x"], t6_) - disp(model.deform_grid_mid, probes["anchor_x"], t6_)) ** 2) * 0.1
+    reg["anchor"] = (torch.mean(at0_ ** 2) + cons_) * 0.01 * 16
+    (reg["temporal"] + reg["unsup"] + reg["anchor"]).backward()
+    reg_grads = {"rg:" + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None and "encoding.params" not in k}
+    reg_grads["rgn:deform_grid_start"] = model.deform_grid_start.encoding.params.grad.norm()
+    reg_grads["rgn:deform_grid_mid"] = model.deform_grid_mid.encoding.params.grad.norm()
     save("g14_part4", pts=pts, dirs=dirs, times=times, rgb=rgb, sigma=sigma, delta=delta, w_rgb=w_rgb, w_dx=w_dx,
+         **{"probe:" + k: v for k, v in probes.items()}, **{"reg:" + k: v.detach() for k, v in reg.items()}, **reg_grads,
          rays_o=o, rays_d=d, ray_t=ray_t, r_rgb=c, r_depth=dep, r_acc=acc, r_mean_delta=extras["mean_delta_x"],
          r3_rgb=c3[0], n_tuple3=np.int64(len(c3)), grid=dg.grid, binary=dg.binary_grid, ratios=np.array([r1, r2]),
          **{"w:" + k: v for k, v in sd.items()}, **grads)

@@ -126,6 +126,42 @@ def test_part4_render_rays_and_density_grid_vs_reference_golden(model):
     np.testing.assert_allclose(ratios, g["ratios"], atol=3e-4)
 
 
+def test_part4_loss_terms_vs_reference_operators(model):
+    """dynamic.part4_regularisers -- the non-photometric terms of run_part4 (run.py:1835-1938): displacement
+    magnitude, TV on the three deformation grids and the canonical grid, temporal smoothness, unsupervised
+    consistency, tri-grid anchor -- on the golden's probe points, against the same formulas evaluated with the
+    REFERENCE's operators (make_golden.py::g14_part4), values and gradients; and their every-n-steps schedule."""
+    from project_nerf_amd.dynamic import part4_regularisers
+    m, g = model
+    cfg = dict(PART4_CFG, use_unsupervised_consistency=True, grid_warmup_iters=8)
+    probes = {k[len("probe:"):]: T(v).cuda() for k, v in g.items() if k.startswith("probe:")}
+    mean_dx = T(g["r_mean_delta"]).cuda()
+    m.zero_grad()
+    terms = part4_regularisers(m, cfg, 32, mean_dx, probes=probes)
+    assert set(terms) == {"reg", "tv_disp", "tv_canon", "temporal", "unsup", "anchor"}
+    for k, v in terms.items():
+        np.testing.assert_allclose(float(v.detach()), float(g["reg:" + k]), rtol=2e-3, atol=1e-12, err_msg=k)
+    (terms["temporal"] + terms["unsup"] + terms["anchor"]).backward()
+    params = dict(m.named_parameters())
+    for k, v in g.items():
+        if k.startswith("rg:"):
+            got, want = params[k[3:]].grad.cpu(), T(v)
+            assert float((got - want).norm() / (want.norm() + 1e-20)) < 3e-3, k
+    for name in ("deform_grid_start", "deform_grid_mid"):
+        got = float(getattr(m, name).encoding.params.grad.norm())
+        assert abs(got - float(g["rgn:" + name])) < 3e-3 * float(g["rgn:" + name]), name
+    assert m.deform_grid_end.encoding.params.grad is None or float(m.deform_grid_end.encoding.params.grad.abs().sum()) == 0.0
+    m.zero_grad()
+    # schedule: nothing but reg + TV before the warm-up or off the 16 / 32 step lattice; fresh draws otherwise
+    early = part4_regularisers(m, cfg, 8, mean_dx)
+    assert float(early["temporal"]) == 0.0 and float(early["unsup"]) == 0.0 and float(early["anchor"]) == 0.0
+    off = part4_regularisers(m, cfg, 33, mean_dx)
+    assert float(off["temporal"]) == 0.0 and float(off["anchor"]) == 0.0 and float(off["tv_disp"]) > 0.0
+    s16 = part4_regularisers(m, cfg, 48, mean_dx, generator=torch.Generator(device="cuda").manual_seed(1))
+    assert float(s16["temporal"]) > 0.0 and float(s16["anchor"]) > 0.0 and float(s16["unsup"]) == 0.0
+    assert float(part4_regularisers(m, dict(cfg, use_tv_displacement=False, tv_loss_weight=0.0), 33, mean_dx)["tv_disp"]) == 0.0
+
+
 def test_part4_trains_through_the_module_surface(tmp_path):
     """DynamicDataset + NeuralField('part4') + render_rays(times=...) + AdamW, as in reference run_part4: the loss
     falls and every parameter group (incl. the three deformation grids) receives gradients."""
