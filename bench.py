@@ -338,6 +338,11 @@ def main():
     blocking = os.environ.get("NERF_BENCH_SYNC_ALLREDUCE") is not None
     sync = parallel.allreduce_sum_ if world > 1 and blocking else None
     sync_async = parallel.allreduce_sum_async if world > 1 and not blocking else None
+    if world > 1 and os.environ.get("NERF_BENCH_NATIVE_COMM") is not None:
+        # A/B: the same two-range overlapped all-reduce through libnerf_comm.so (include/nerf_comm.h) instead of
+        # torch.distributed's process group; the bootstrap token travels through the process group
+        from project_nerf_amd._comm import NativeComm
+        sync, sync_async = None, parallel.native_allreduce_sum_async(NativeComm.from_torch_distributed())
 
     def barrier():
         if world > 1:

@@ -12,6 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libnerf_hip.so")
+COMM_SRC = os.path.join(HERE, "csrc_comm", "comm.cpp")
+COMM_LIB = os.path.join(HERE, "libnerf_comm.so")
+ROCM_LIB = os.environ.get("ROCM_LIB", "/opt/rocm/lib")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
@@ -88,7 +91,23 @@ def build(verbose=False, jobs=None):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    build_comm(verbose)
     return LIB
+
+
+def build_comm(verbose=False):
+    """libnerf_comm.so: the RCCL exchange step behind include/nerf_comm.h (host code only; links librccl)"""
+    header = os.path.join(HERE, "..", "include", "nerf_comm.h")
+    if os.path.exists(COMM_LIB) and os.path.getmtime(COMM_LIB) > max(os.path.getmtime(COMM_SRC), os.path.getmtime(header)):
+        return COMM_LIB
+    cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(HERE, "..", "include"), COMM_SRC, "-o", COMM_LIB,
+           "-L" + ROCM_LIB, "-lrccl", "-Wl,-rpath," + ROCM_LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building libnerf_comm.so failed:\n{r.stdout}\n{r.stderr}")
+    return COMM_LIB
 
 
 if __name__ == "__main__":

@@ -71,3 +71,27 @@ def gather_row_bands(band: torch.Tensor, rows_total: int, dst: int = 0) -> Optio
     if rank != dst:
         return None
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def native_allreduce_sum_async(comm):
+    """The engines' ``sync_grads_async`` callback over libnerf_comm.so (``_comm.NativeComm``) instead of
+    torch.distributed: the collective is enqueued on a side stream behind the work already queued on the
+    current one; ``handle.wait()`` orders the current stream after it."""
+    side = torch.cuda.Stream()
+
+    class _Handle:
+        def __init__(self, event):
+            self.event = event
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.event)
+
+    def start(flat: torch.Tensor):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            comm.allreduce_sum_(flat)
+            event = torch.cuda.Event()
+            event.record(side)
+        return _Handle(event)
+
+    return start

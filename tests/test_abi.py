@@ -109,3 +109,35 @@ def test_reference_import_lines_resolve_against_this_package():
     assert issubclass(HashDeformationDecoder, BaseDecoder) and issubclass(TimeModulationNetwork, BaseDecoder)
     with pytest.raises(NotImplementedError):
         DeformationNetwork(63, 21)              # Part 3's MLP deformation field: named, not built
+
+
+def comm_declared_functions():
+    text = open(os.path.join(ROOT, "include", "nerf_comm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nerf_comm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_comm_library_exports_every_declared_symbol_and_validates_arguments(lib):
+    """libnerf_comm.so (include/nerf_comm.h, the RCCL exchange step): symbols, ctypes table, host-side argument
+    checks.  No communicator is created without a GPU."""
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import _comm
+    names = comm_declared_functions()
+    assert "nerf_comm_init" in names and "nerf_comm_allreduce_sum" in names and "nerf_comm_gather_tiles" in names
+    handle = ctypes.CDLL(_comm.LIB_PATH)
+    assert not [n for n in names if not hasattr(handle, n)]
+    assert sorted(_comm.PROTOTYPES) == names
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nerf_comm.h")).read(), flags=re.S)
+    for name, (_, argtypes) in _comm.PROTOTYPES.items():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, text, flags=re.S)
+        args = m.group(1).strip()
+        assert (0 if args in ("", "void") else len(args.split(","))) == len(argtypes), name
+    h = _comm.load()
+    assert h.nerf_comm_abi_version() == 1 and h.nerf_comm_unique_id_bytes() == 128
+    assert h.nerf_comm_init(None, 0, 1, None) == -22
+    buf = ctypes.create_string_buffer(128)
+    out = ctypes.c_void_p()
+    assert h.nerf_comm_init(buf, 3, 2, ctypes.byref(out)) == -22 and b"rank 3 of 2" in h.nerf_comm_last_error()
+    assert h.nerf_comm_allreduce_sum(None, None, 4, 0, None) == -22
+    assert h.nerf_comm_gather_tiles(None, None, None, None, 0, None) == -22
+    assert h.nerf_comm_destroy(None) == 0
