@@ -67,8 +67,19 @@ struct BwdLayout {
   size_t dfeat;    // blocked [n_pad,256]
   size_t dh;       // 8 x blocked [n_pad,256], layer l at dh + l * n_pad * 256 * element bytes
   size_t amax;     // one fp32: max |output-layer derivative| of this launch (8-bit images only)
+  size_t slab;     // partial weight-gradient tiles of the split-K wgrad (slab_bytes; 0 = float atomics instead)
+  size_t slab_bytes;
   size_t total;
 };
+
+// Partial sums of the split-K weight-gradient kernel: one tile per (workgroup, layer job) written with plain
+// stores and summed by a second small kernel in a fixed order, instead of ~18 M float atomics per step (they
+// retire per line request, ~20 G/s: 0.06 ms exposed at the end of the kernel).  Capacity: every workgroup's
+// largest tile (pts_layers.4: 256 x 319 + 256 floats) plus one extra tile per job.  Launches below
+// kSlabMinSamples keep the atomic flush (their grids are small and the workspace stays small).
+constexpr int64_t kSlabMinSamples = 65536;
+constexpr size_t kSlabMaxWorkgroups = 320, kSlabMaxTileFloats = 256 * 319 + 256;
+constexpr size_t kSlabBytes = (kSlabMaxWorkgroups + 12) * kSlabMaxTileFloats * sizeof(float);
 
 inline BwdLayout bwd_layout(int64_t n) {
   BwdLayout s{};
@@ -81,6 +92,9 @@ inline BwdLayout bwd_layout(int64_t n) {
   s.dfeat = o;  o += np * 256 * eb;
   s.dh = o;     o += np * 256 * eb * 8;
   s.amax = o;   o += 256;
+  s.slab = o;
+  s.slab_bytes = (n >= kSlabMinSamples && !options().wgrad_atomic) ? kSlabBytes : 0;
+  o += s.slab_bytes;
   s.total = o;
   return s;
 }

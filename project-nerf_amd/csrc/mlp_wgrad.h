@@ -31,6 +31,10 @@ struct WgradJob {
   int bias_off, bias_nat_col;   // bias_nat_col < 0: bias comes from the ones tile
   long long cost0;      // prefix sum of cost (bytes per wave tile * wave tiles) before this job
   int cost;             // bytes per wave tile
+  // slab mode (WgradArgs::slab): workgroups part0 .. part0 + n_parts - 1 hold a partial tile of this job, tile
+  // t at slab[slab_off + t * p_stride], element (o, col) at o * w_ld + col, bias o at o_valid * w_ld + o
+  long long slab_off;
+  int part0, n_parts, p_stride;
 };
 
 struct WgradArgs {
@@ -39,12 +43,16 @@ struct WgradArgs {
   int wave_tiles;       // ring stages per job: 32-sample wave tiles (bf16) or 64-sample pairs (8-bit)
   long long total_cost;
   float* grads;
+  float* slab;          // non-null: partial tiles go here with plain stores, wgrad_reduce_kernel sums them
   const float* amax;    // non-null: 8-bit images; *amax = the dgrad launch's largest output-layer derivative
   int debug;            // development aid (NERF_WGRAD_DEBUG): bit0 skip MFMA/LDS reads, bit1 skip DMA, bit2 skip flush
 };
 
 
 // fills cost0 / total_cost / wave_tiles / grads and launches; jobs[0..n_jobs) must be set
-int wgrad_launch(WgradArgs& args, int64_t n_samples, float* grads, hipStream_t stream);
+// slab: partial-tile memory of slab_bytes (mlp_stash.h::kSlabBytes) or null for the atomic flush; in slab mode
+// every parameter of the launched jobs is OVERWRITTEN (no memset needed), in atomic mode accumulated
+int wgrad_launch(WgradArgs& args, int64_t n_samples, float* grads, hipStream_t stream, float* slab = nullptr,
+                 size_t slab_bytes = 0);
 
 }  // namespace nerf

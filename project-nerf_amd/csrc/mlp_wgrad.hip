@@ -97,6 +97,19 @@ __device__ __forceinline__ void flush_tiles(const WgradArgs& args, const WgradJo
     }
     if (!use) continue;
     const bool ones_tile = SPLIT ? k == 1 : k == NT_ACC + NT_NAT;
+    if (args.slab != nullptr) {      // plain stores into this workgroup's partial tile (two 128-byte segments per instruction)
+      float* tile = args.slab + job.slab_off + (long long)((int)blockIdx.x - job.part0) * job.p_stride;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hrow;
+        const int o = 32 * m_tile + ((FP8 && !SPLIT) ? phi8(row) : row) - job.o_row0;
+        if (o >= 0 && o < job.o_valid) {
+          if (col >= 0) tile[o * job.w_ld + col] = acc[k][r] * w_scale;
+          if (bias_here) tile[job.o_valid * job.w_ld + o] = acc[k][r] * (ones_tile ? b_scale : w_scale);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hrow;
@@ -409,6 +422,27 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
   }
 }
 
+// slab mode: grads[parameter] = sum over the job's partial tiles, in tile order (the same sum every run)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradArgs args) {
+  const WgradJob& job = args.jobs[blockIdx.y];
+  const int n_w = job.o_valid * job.w_ld, n_all = n_w + job.o_valid;
+  const float* tile = args.slab + job.slab_off;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += gridDim.x * blockDim.x) {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int t = 0;
+    for (; t + 4 <= job.n_parts; t += 4) {       // four independent loads in flight
+      s0 += tile[(long long)(t + 0) * job.p_stride + i];
+      s1 += tile[(long long)(t + 1) * job.p_stride + i];
+      s2 += tile[(long long)(t + 2) * job.p_stride + i];
+      s3 += tile[(long long)(t + 3) * job.p_stride + i];
+    }
+    for (; t < job.n_parts; ++t) s0 += tile[(long long)t * job.p_stride + i];
+    const float sum = (s0 + s1) + (s2 + s3);
+    if (i < n_w) args.grads[job.w_off + i] = sum;
+    else args.grads[job.bias_off + (i - n_w)] = sum;
+  }
+}
+
 }  // namespace nerf
 
 using namespace nerf;
@@ -490,10 +524,11 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
     nj = hi - lo;
   }
   args.n_jobs = nj;
-  return wgrad_launch(args, n, grads, stream);
+  float* slab = bl.slab_bytes ? reinterpret_cast<float*>(const_cast<char*>(work) + bl.slab) : nullptr;
+  return wgrad_launch(args, n, grads, stream, slab, bl.slab_bytes);
 }
 
-int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t stream) {
+int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t stream, float* slab, size_t slab_bytes) {
   int nj = args.n_jobs;
   // span cost of one wave tile = its bytes + a fixed per-iteration share (barrier, counted waits,
   // DMA issue, LDS reads + MFMAs of the stage).  Measured on MI355X: the iteration time is nearly
@@ -540,6 +575,39 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   if (int rc = ensure_dynamic_lds((const void*)mlp_wgrad_kernel, kWgLds, "nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
   long long want = (long long)args.wave_tiles * nj / 4;   // at least ~4 wave tiles per span
   int grid = (int)(want < 1 ? 1 : (want > n_cu ? n_cu : want));
+  // slab mode: which workgroups hold a partial tile of which job -- the kernel's own span arithmetic, replayed
+  args.slab = nullptr;
+  if (slab != nullptr && args.n_jobs > 0 && args.total_cost > 0) {
+    bool ok = true;
+    long long off = 0;
+    for (int j = 0; j < args.n_jobs && ok; ++j) {
+      WgradJob& jb = args.jobs[j];
+      const long long j0 = jb.cost0, j1 = jb.cost0 + (long long)jb.cost * args.wave_tiles;
+      int first = -1, last = -1, count = 0;
+      for (int b = 0; b < grid; ++b) {
+        const long long lo = args.total_cost * b / grid, hi = args.total_cost * (b + 1) / grid;
+        if (hi <= j0 || lo >= j1) continue;
+        const long long a0 = lo > j0 ? lo - j0 : 0, a1 = (hi < j1 ? hi : j1) - j0;
+        const int wt0 = (int)((a0 + jb.cost - 1) / jb.cost), wt1 = (int)((a1 + jb.cost - 1) / jb.cost);
+        if (wt0 >= wt1) continue;
+        if (first < 0) first = b;
+        last = b;
+        ++count;
+      }
+      ok = count > 0 && count == last - first + 1;          // contiguous (a tiny launch can leave holes: atomics then)
+      jb.part0 = first;
+      jb.n_parts = count;
+      jb.p_stride = (jb.o_valid * jb.w_ld + jb.o_valid + 63) / 64 * 64;
+      jb.slab_off = off;
+      off += (long long)count * jb.p_stride;
+    }
+    if (ok && (size_t)off * sizeof(float) <= slab_bytes) args.slab = slab;
+  }
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid), dim3(512), kWgLds, stream, args);
+  if (args.slab != nullptr) {
+    if (int rc = check_launch("nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(80, args.n_jobs), dim3(256), 0, stream, args);
+    return check_launch("nerf_mlp_bwd (wgrad reduce)");
+  }
   return check_launch("nerf_mlp_bwd (wgrad)");
 }

@@ -611,3 +611,45 @@ def test_chain_kernels_bit_identical_under_full_chip_load(ops, option):
     finally:
         if option:
             ops._lib.set_option(option, 0)
+
+
+def test_wgrad_partial_tiles_equal_the_atomic_flush_and_repeat_bit_for_bit(ops):
+    """From 65,536 samples on, the split-K weight-gradient kernel writes one partial tile per (workgroup, layer)
+    and a second kernel sums them in a fixed order (option wgrad_atomic = 1: float atomics as before).  Same
+    gradients up to fp32 summation order; the slab form repeats bit for bit; the two-range form used by the
+    data-parallel step (parts 1 and 2) fills the same vector."""
+    params = O.nerf_init_params(seed=21)
+    R, S = 2048, 64
+    n = R * S
+    o, d = synth_rays(R, 4)
+    z = dev(O.stratified_depths(2.0, 6.0, S, R, False).contiguous())
+    o, d = dev(o), dev(d)
+    packed = ops.mlp_pack(dev(flat_params(params)))
+    gen = torch.Generator().manual_seed(2)
+    d_rgb, d_sigma = dev(torch.randn(n, 3, generator=gen)), dev(torch.randn(n, generator=gen))
+    stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
+    rgb, sigma = ops.mlp_fwd(packed, o, d, z, stash)
+    out = {}
+    for mode in (1, 0):
+        ops._lib.set_option("wgrad_atomic", mode)
+        try:
+            nbytes = ops.mlp_bwd_workspace_bytes(n)
+            out[mode] = [ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb, d_sigma).clone() for _ in range(2)]
+            out[(mode, "bytes")] = nbytes
+        finally:
+            ops._lib.set_option("wgrad_atomic", 0)
+    assert out[(0, "bytes")] > out[(1, "bytes")] + 64 * 1024 * 1024          # the slab is part of the workspace
+    a, s0, s1 = out[1][0], out[0][0], out[0][1]
+    assert torch.equal(s0, s1)
+    off = 0
+    for name, shape in O.nerf_param_shapes():
+        cnt = int(np.prod(shape))
+        ga, gs = a[off:off + cnt], s0[off:off + cnt]
+        off += cnt
+        assert float((ga - gs).norm() / (ga.norm() + 1e-20)) < 2e-6, name
+    # two-range form
+    ws = torch.empty(ops.mlp_bwd_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    grads = torch.full_like(s0, float("nan"))
+    ops.mlp_bwd_overlapped(packed, stash, rgb, sigma, d_rgb, d_sigma, grads, ws, lambda view: None)
+    assert bool(torch.isfinite(grads).all())                               # every parameter was written
+    assert float((grads - s0).norm() / s0.norm()) < 2e-6                   # other spans, hence another summation order
