@@ -117,9 +117,25 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
             vals.append(-10 * np.log10(float(((img.clamp(0, 1) - tgt) ** 2).mean())))
         return float(np.mean(vals))
 
-    def step():
+    # one batch ahead: the draw, the rays and the compaction of batch i+1 are queued BEFORE step i's kernels, so
+    # the active count of batch i+1 is on the host by the time step i ends and no step waits for its own count
+    # (NERF_BENCH_NO_PREFETCH=1: draw and compact in line, one host wait per step as in the reference)
+    pipelined = os.environ.get("NERF_BENCH_NO_PREFETCH") is None
+    ahead = []
+
+    def draw():
         o, d, target = ds.sample_batch(batch, bg)
-        return eng.train_step(o, d, target, S)
+        return o, d, target, eng.prepare_batch(o, d, S)
+
+    def step():
+        if not pipelined:
+            o, d, target = ds.sample_batch(batch, bg)
+            return eng.train_step(o, d, target, S)
+        if not ahead:
+            ahead.append(draw())
+        o, d, target, prepared = ahead.pop()
+        ahead.append(draw())
+        return eng.train_step(o, d, target, S, prepared=prepared)
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -129,6 +145,7 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
         interval = 32 if it < iters * 0.1 else (128 if it < iters * 0.5 else 512)      # run.py:636-641
         if it < iters * 0.9 and it >= 256 and it % interval == 0:
             active = eng.update_grid()
+            ahead.clear()                      # the waiting batch was compacted against the previous grid
         if it in (300, 600, iters):
             torch.cuda.synchronize()
             curve.append({"step": it, "train_seconds": time.perf_counter() - t0, "test_psnr_db": psnr()})
@@ -230,14 +247,24 @@ def bench_instant_dp(args, device, rank, world, dist):
     eng = InstantNgpEngine(cfg, device=str(device), seed=0, world_size=world)
     wire = None if os.environ.get("NERF_BENCH_REDUCE_FP32") else torch.bfloat16
 
-    def step():
+    ahead = []
+
+    def draw():
         o, d, target = ds.sample_batch(batch, eng.bg)
-        return eng.train_step(o, d, target, S, sync_grads_async=parallel.allreduce_sum_async, reduce_dtype=wire)
+        return o, d, target, eng.prepare_batch(o, d, S)
+
+    def step():                                                             # one batch ahead, as in bench_instant
+        if not ahead:
+            ahead.append(draw())
+        o, d, target, prepared = ahead.pop()
+        ahead.append(draw())
+        return eng.train_step(o, d, target, S, sync_grads_async=parallel.allreduce_sum_async, reduce_dtype=wire, prepared=prepared)
 
     for it in range(1, iters + 1):
         step()
         if it >= 256 and it % 64 == 0 and it < iters * 0.9:
             eng.update_grid()                                               # replicated: a pure function of the replicated weights
+            ahead.clear()
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

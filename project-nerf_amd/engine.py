@@ -284,8 +284,18 @@ class InstantNgpEngine:
         cuts.append(self.levels.n_levels)
         return [(cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1) if cuts[k] < cuts[k + 1]]
 
+    def prepare_batch(self, rays_o: Tensor, rays_d: Tensor, n_samples: int = 128, u: Optional[Tensor] = None):
+        """Queues the data-only front of a step -- stratified depths, occupancy mask, compaction (rows a1-a4) --
+        and the read-back of the active count WITHOUT waiting for it.  A loop that prepares batch i+1 before it
+        runs step i never stalls on the count: it arrives while step i computes (the reference, and
+        ``compute_gradients`` without ``prepared``, wait at this point of every step).  The batch is compacted
+        against the occupancy grid as it is now; prepare again after ``update_grid`` to use the new one."""
+        if u is None:
+            u = torch.rand(rays_o.shape[0], n_samples, device=self.device)
+        return ops.sample_compact_async(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid, self.bound, u=u)
+
     def compute_gradients(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
-                          u: Optional[Tensor] = None, sync_grads_async=None, reduce_dtype=None) -> Tensor:
+                          u: Optional[Tensor] = None, sync_grads_async=None, reduce_dtype=None, prepared=None) -> Tensor:
         """Forward + backward of one batch (reference run.py:579-619): fills ``g_table`` / ``g_net`` with the
         gradients of the LOCAL mean-squared error and returns the loss.  ``sync_grads_async(view)`` (data
         parallel) starts the all-reduce of a finished gradient range and returns a handle: the tiny-MLP
@@ -294,10 +304,13 @@ class InstantNgpEngine:
         gradient is 52 MB in fp32: a ring all-reduce over xGMI costs about half a step)."""
         lib = ops._lib.load()
         R = rays_o.shape[0]
-        if u is None:
-            u = torch.rand(R, n_samples, device=self.device)
-        z, slots, pts, dirs = ops.sample_compact(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid,
-                                                 self.bound, u=u)
+        if prepared is not None:
+            z, slots, pts, dirs = prepared.get()
+        else:
+            if u is None:
+                u = torch.rand(R, n_samples, device=self.device)
+            z, slots, pts, dirs = ops.sample_compact(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid,
+                                                     self.bound, u=u)
         n = pts.shape[0]
         self.g_table.zero_()
         handles = []
@@ -366,9 +379,9 @@ class InstantNgpEngine:
         ops.imlp_pack(self.net, self.packed)
 
     def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
-                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, reduce_dtype=None) -> Tensor:
+                   u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, reduce_dtype=None, prepared=None) -> Tensor:
         loss = self.compute_gradients(rays_o, rays_d, target, n_samples, u=u, sync_grads_async=sync_grads_async,
-                                      reduce_dtype=reduce_dtype)
+                                      reduce_dtype=reduce_dtype, prepared=prepared)
         if sync_grads is not None:                # blocking form: two collectives after the backward pass
             sync_grads(self.g_table)
             sync_grads(self.g_net)

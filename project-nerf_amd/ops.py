@@ -148,6 +148,46 @@ def sample_compact(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_sa
     return z, slots, pts[:n_act], dirs[:n_act]
 
 
+class CompactedSamples:
+    """Result of ``sample_compact_async``: the kernel and the read-back of the active count are queued, nothing
+    has been waited for.  ``get()`` waits for the count alone (a 4-byte copy into pinned memory, queued right
+    behind the kernel) and returns (z, slots, pts[:n], dirs[:n]) -- by then usually long done, because the caller
+    queued this batch's compaction ahead of the previous step's kernels."""
+
+    def __init__(self, z, slots, pts, dirs, count_host, event):
+        self.z, self.slots, self._pts, self._dirs, self._count, self._event = z, slots, pts, dirs, count_host, event
+
+    def get(self):
+        self._event.synchronize()
+        n = int(self._count[0])
+        return self.z, self.slots, self._pts[:n], self._dirs[:n]
+
+
+def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_samples: int,
+                         binary_grid: Tensor, bound: float, u: Optional[Tensor] = None) -> CompactedSamples:
+    """``sample_compact`` without the host wait: same kernel, same outputs; the count comes back asynchronously."""
+    lib = _lib.load()
+    rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
+    grid = _dev(binary_grid, "binary_grid", torch.bool)
+    R = rays_o.shape[0]
+    n = R * n_samples
+    if u is not None:
+        u = _dev(u, "u")
+    dev = rays_o.device
+    z = torch.empty(R, n_samples, device=dev)
+    slots = torch.empty(n, device=dev, dtype=torch.int32)
+    pts, dirs = torch.empty(max(n, 1), 3, device=dev), torch.empty(max(n, 1), 3, device=dev)
+    count = torch.zeros(1, device=dev, dtype=torch.int32)
+    _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
+                                       float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),
+               "nerf_sample_compact")
+    count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    count_host.copy_(count, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    return CompactedSamples(z, slots, pts, dirs, count_host, event)
+
+
 class _CompositeIndexed(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb_c, sigma_c, slots, z, rays_d, bg):
