@@ -376,12 +376,22 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
   }
 }
 
+// STAGED (levels of at most kStagedBins slices, i.e. tables up to 2^20 entries): the round's 4096 records are
+// grouped by bin in LDS first and leave as contiguous runs -- one bin's records of the round are adjacent in
+// the workspace, so a wave's store covers a few whole lines instead of 64 separate 12-byte pieces.
+constexpr unsigned kStagedBins = 256;
+template <bool STAGED>
 __global__ void __launch_bounds__(512)
 hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
                         unsigned* __restrict__ cursor, BinRecord* __restrict__ records) {
-  __shared__ unsigned cnt[kMaxSlices], base[kMaxSlices];
+  constexpr unsigned kBins = STAGED ? kStagedBins : kMaxSlices;
+  __shared__ unsigned cnt[kBins], base[kBins];
+  __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
+  __shared__ BinRecord stage[STAGED ? 4096 : 1];
+  __shared__ unsigned dest[STAGED ? 4096 : 1];
   const int lvl = plan.first + blockIdx.y;
   const unsigned bins = plan.bin0[blockIdx.y + 1] - plan.bin0[blockIdx.y], offset = L.offset[lvl];
+  if (STAGED != (bins <= kStagedBins)) return;                 // the other instantiation owns this level
   for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) cnt[i] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -397,24 +407,66 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
       for (int k = 0; k < 8; ++k) slot[k] = atomicAdd(&cnt[(c.idx[k] - offset) >> kSliceLog2], 1u);
     }
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) {
-      const unsigned v = cnt[i];
-      if (v != 0) base[i] = atomicAdd(cursor + plan.bin0[blockIdx.y] + i, v);
-      cnt[i] = 0;
-    }
-    __syncthreads();
-    if (live) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const unsigned local = c.idx[k] - offset;
-        BinRecord r;
-        r.slot = local & (kSlice - 1);
-        r.g0 = c.w[k] * g0;
-        r.g1 = c.w[k] * g1;
-        records[base[local >> kSliceLog2] + slot[k]] = r;
+    if constexpr (STAGED) {
+      // reserve the bins' runs in the workspace; exclusive scan of the counts = the runs' places in the stage
+      const unsigned t = threadIdx.x;
+      unsigned v = 0;
+      if (t < kStagedBins) {
+        v = t < bins ? cnt[t] : 0u;
+        if (v != 0) base[t] = atomicAdd(cursor + plan.bin0[blockIdx.y] + t, v);
+        unsigned incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned up = __shfl_up(incl, o);
+          if ((int)(t & 63) >= o) incl += up;
+        }
+        if ((t & 63) == 63) wave_sum[t >> 6] = incl;
+        start[t] = incl - v;                                    // within the wave; the waves before are added below
       }
+      __syncthreads();
+      if (t < kStagedBins) {
+        unsigned before = 0;
+        for (unsigned w = 0; w < (t >> 6); ++w) before += wave_sum[w];
+        start[t] += before;
+        if (t < bins) cnt[t] = 0;
+        if (t == kStagedBins - 1) total = start[t] + v;
+      }
+      __syncthreads();
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned local = c.idx[k] - offset, b = local >> kSliceLog2, pos = start[b] + slot[k];
+          BinRecord r;
+          r.slot = local & (kSlice - 1);
+          r.g0 = c.w[k] * g0;
+          r.g1 = c.w[k] * g1;
+          stage[pos] = r;
+          dest[pos] = base[b] + slot[k];
+        }
+      }
+      __syncthreads();
+      const unsigned count = total;
+      for (unsigned q = threadIdx.x; q < count; q += blockDim.x) records[dest[q]] = stage[q];
+      __syncthreads();                          // stage, start and base are rewritten by the next round
+    } else {
+      for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) {
+        const unsigned v = cnt[i];
+        if (v != 0) base[i] = atomicAdd(cursor + plan.bin0[blockIdx.y] + i, v);
+        cnt[i] = 0;
+      }
+      __syncthreads();
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned local = c.idx[k] - offset;
+          BinRecord r;
+          r.slot = local & (kSlice - 1);
+          r.g0 = c.w[k] * g0;
+          r.g1 = c.w[k] * g1;
+          records[base[local >> kSliceLog2] + slot[k]] = r;
+        }
+      }
+      __syncthreads();                          // base[] is rewritten by the next round
     }
-    __syncthreads();                          // base[] is rewritten by the next round
   }
 }
 
@@ -557,8 +609,14 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
       hipLaunchKernelGGL(hash_bin_count_kernel, dim3((int)bx_count, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan, d_feat,
                          w.count, w.header);
       hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header);
-      hipLaunchKernelGGL(hash_bin_scatter_kernel, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
-                         d_feat, w.cursor, w.records);
+      bool any_staged = false, any_direct = false;
+      for (int i = 0; i < plan.count; ++i) (plan.bin0[i + 1] - plan.bin0[i] <= kStagedBins ? any_staged : any_direct) = true;
+      if (any_staged)
+        hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
+                           plan, d_feat, w.cursor, w.records);
+      if (any_direct)
+        hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
+                           plan, d_feat, w.cursor, w.records);
       size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
       if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
       hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,

@@ -473,3 +473,19 @@ def test_prepared_batch_equals_the_in_line_step():
     assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * float(loss_a)       # the loss is an atomic fp32 sum over rays
     assert float((eng.g_table - ga).abs().max()) <= 1e-6 * float(ga.abs().max())
     assert float((eng.g_net - na).norm() / na.norm()) < 1e-5
+
+
+def test_hash_backward_binned_form_large_tables(ops):
+    """Tables of 2^21 entries per level have 512 slices: the scatter's direct (unstaged) instantiation; 2^19 the
+    LDS-staged one.  Both against the atomic form."""
+    for log2_t in (21, 14):
+        t = ops.HashLevelTable(8, log2_t, 16, 2.0)
+        gen = torch.Generator().manual_seed(log2_t)
+        pts = ((torch.rand(20000, 3, generator=gen) - 0.5) * 3.0).cuda()
+        d_feat = torch.randn(20000, 16, generator=gen).cuda()
+        ref = torch.zeros(t.entries, 2, device="cuda")
+        ops.hash_encode_bwd(pts, t, 1.5, d_feat, ref)
+        out = torch.zeros_like(ref)
+        ws = torch.empty(ops.hash_encode_bwd_workspace_bytes(20000, 8), dtype=torch.uint8, device="cuda")
+        ops.hash_encode_bwd(pts, t, 1.5, d_feat, out, workspace=ws)
+        assert float((out - ref).abs().max()) < 1e-5 * float(ref.abs().max()), log2_t
