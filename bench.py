@@ -510,7 +510,11 @@ def main():
         out["step_frac_of_binding_roofline"] = {"bound": "mfma", "achieved": step_ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": step_ach / MFMA_PEAK_TFLOPS, "work_per_step": R * S * TRAIN_FLOP}
         step_traffic = [traffic(roofs[r]["kernel"]) for r in roofs]
-        out["step_hbm_traffic_bytes"] = sum(step_traffic) if all(t is not None for t in step_traffic) else None
+        # the small kernels of the step, where the committed PMC summary has them (the partial-tile reduce of wgrad,
+        # compositing + loss, batch sampling, Adam, weight repack)
+        extras = [traffic(k_) for k_ in ("wgrad_reduce_kernel", "composite_mse_bwd_kernel<1>", "train_batch_kernel", "adam_kernel", "pack_kernel")]
+        out["step_hbm_traffic_bytes"] = (sum(step_traffic) + sum(t for t in extras if t is not None)
+                                         if all(t is not None for t in step_traffic) else None)
 
     # ---- render: 800x800 rays, 128 samples, rays split into row bands across ranks ----
     if not args.no_render:

@@ -45,6 +45,7 @@ struct WgradArgs {
   float* grads;
   float* slab;          // non-null: partial tiles go here with plain stores, wgrad_reduce_kernel sums them
   const float* amax;    // non-null: 8-bit images; *amax = the dgrad launch's largest output-layer derivative
+  int k16;              // 1: four 32x32x16 MFMAs per stage instead of one 32x32x64 (8-bit images; A/B)
   int debug;            // development aid (NERF_WGRAD_DEBUG): bit0 skip MFMA/LDS reads, bit1 skip DMA, bit2 skip flush
 };
 

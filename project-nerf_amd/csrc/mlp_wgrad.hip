@@ -55,6 +55,7 @@ struct LaneGeo {
 // 8-bit operand of the contraction over samples: ONE transposing read returns, for the lane's feature,
 // the 8 consecutive samples of its k-half (tools/probe/fp8_probe.hip pins the instruction's lane map)
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) i32x2* lds_i32x2_t;
 __device__ __forceinline__ long tr_frag8(const char* p) {
   return __builtin_bit_cast(long, __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2_t)(p)));
@@ -188,6 +189,54 @@ __device__ __forceinline__ void run_job8(const WgradArgs& args, const WgradJob j
   };
   const long ones8 = 0x3838383838383838L;   // 8 x e4m3 1.0
   const bool compute = active && !(args.debug & 1);
+
+  if (!args.k16) {
+    // ONE v_mfma_scale_f32_32x32x64_f8f6f4 per column tile and stage instead of four 32x32x16: the K = 64 form runs
+    // at twice the rate (64 cycles for 4x the K; tools/probe/f8f6f4_probe.hip).  Its 32-byte operands are the four
+    // K = 16 fragments of the stage side by side -- any k order is fine as long as A and B agree, and both come from
+    // the same transposing reads.  A = e5m2 (cbsz 1), B = e4m3 (blgp 0), block scales 2^0 (E8M0 127).
+    auto frag64 = [&](const char* p, int half, int step) {
+      i32x8 v;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const long f = tr_frag8(p + (s4 >> 1) * half + step * (s4 & 1));
+        v[2 * s4] = (int)f;
+        v[2 * s4 + 1] = (int)(f >> 32);
+      }
+      return v;
+    };
+    auto col_tile = [&](const char* stage, int k) {
+      return k < NT_ACC ? frag64(stage + kWgStageA + g.off_acc8 + k * 1024, half_b, 512)
+                        : frag64(stage + kWgStageA + kWgStageB + g.off_nat8 + (k - NT_ACC) * 1024, half_n, 256);
+    };
+    i32x8 ones64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones64[e] = 0x38383838;
+    __builtin_amdgcn_s_barrier();   // previous span's readers are done with the ring
+    if (wt0 + 0 < wt1) issue(wt0 + 0);
+    if (wt0 + 1 < wt1) issue(wt0 + 1);
+    if (wt0 + 2 < wt1) issue(wt0 + 2);
+    for (int wt = wt0; wt < wt1; ++wt) {
+      wait_in_flight((wt + 1 < wt1) + (wt + 2 < wt1));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (wt + 3 < wt1 && !(args.debug & 2)) issue(wt + 3);
+      if (!compute) continue;
+      const char* stage = smem + (wt & (kWgStages - 1)) * kWgStageBytes;
+      const i32x8 a = frag64(stage + wave * 1024 + g.off_acc8, half_a, 512);
+      i32x8 b_cur = NB > 0 ? col_tile(stage, 0) : ones64;
+      static_for<NB>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        i32x8 b_nxt = ones64;
+        if constexpr (k + 1 < NB) b_nxt = col_tile(stage, k + 1);       // the next tile's reads ride under this MFMA
+        acc[k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b_cur, acc[k], 1, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        b_cur = b_nxt;
+      });
+      if constexpr (ONES) acc[NB] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, ones64, acc[NB], 1, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+    flush_tiles<NT_ACC, NT_NAT, ONES, false, true, NT>(args, job, acc, g, active);
+    return;
+  }
 
   __builtin_amdgcn_s_barrier();   // previous span's readers are done with the ring
   if (wt0 + 0 < wt1) issue(wt0 + 0);
@@ -559,6 +608,7 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   args.total_cost = c;
   args.grads = grads;
   args.debug = options().wgrad_debug;
+  args.k16 = options().wgrad_k16;
   if (options().wgrad_only >= 0) {   // development aid: keep one job kind
     const int kind = options().wgrad_only;
     int m = 0;

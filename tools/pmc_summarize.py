@@ -39,7 +39,7 @@ def main(src, dst):
     fetch, write, sq = (load(f"{src}/{n}_counter_collection.csv") for n in ("fetch", "write", "sq"))
     out = {}
     for k in fetch:
-        if k not in KEEP and not k.startswith(("mlp_", "composite_", "imlp_", "hash_")):
+        if k not in KEEP and not k.startswith(("mlp_", "composite_", "imlp_", "hash_", "wgrad_", "adam")):
             continue
         f = statistics.median(fetch[k]["FETCH_SIZE"])
         w = statistics.median(write[k]["WRITE_SIZE"]) if k in write else 0.0
