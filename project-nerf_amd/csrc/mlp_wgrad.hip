@@ -595,7 +595,8 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
       // busiest SIMD (waves w and w+4 share one; four k-steps per stage)
       const int nt = jb.nt_acc + jb.nt_nat + jb.ones;
       const int per_simd = jb.split_n ? (jb.nt_acc > 4 ? 3 : 2) : (jb.mt_a > 4 ? 2 : 1) * nt;
-      const int t_mfma = 32 * 4 * per_simd, t_dma = bytes * 16 / options().wgrad_bw_x16;
+      // owner-mode jobs run one K = 64 MFMA (64 cycles) per column tile and stage, the split ones four K = 16 (32 each)
+      const int t_mfma = (jb.split_n || options().wgrad_k16 ? 32 * 4 : 64) * per_simd, t_dma = bytes * 16 / options().wgrad_bw_x16;
       jb.cost = (t_mfma > t_dma ? t_mfma : t_dma) + options().wgrad_fixed;
     }
   }

@@ -26,6 +26,11 @@ for dbg in (0, 1, 2, 3):
     ms = t()
     print(f"debug={dbg}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s", flush=True)
 ops._lib.set_option("wgrad_debug", 0)
-for bw, fixed in ((192, 400), (128, 400), (256, 400), (384, 400), (192, 0), (192, 1000), (192, 2000), (100000, 400), (100000, 0), (96, 400)):
+for bw, fixed in ((192, 2000), (192, 400), (192, 1000), (192, 3000), (128, 2000), (256, 2000), (384, 2000), (160, 2000), (224, 1500), (100000, 2000)):
     ops._lib.set_option("wgrad_bw_x16", bw); ops._lib.set_option("wgrad_fixed", fixed)
     print(f"bw_x16 {bw} fixed {fixed}: {t():.3f} ms", flush=True)
+ops._lib.set_option("wgrad_bw_x16", 192); ops._lib.set_option("wgrad_fixed", 2000)
+for name in ("wgrad_k16", "wgrad_atomic"):
+    ops._lib.set_option(name, 1)
+    print(f"{name}=1: {t():.3f} ms", flush=True)
+    ops._lib.set_option(name, 0)
