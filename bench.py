@@ -239,7 +239,7 @@ def bench_instant_dp(args, device, rank, world, dist):
     from project_nerf_amd import parallel
     from project_nerf_amd.engine import InstantNgpEngine
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
-    batch, S, iters = 16384, 128, 600
+    batch, S, iters = 16384, 128, int(os.environ.get("NERF_BENCH_DP_ITERS", 600))      # the override shortens the rehearsal test
     cfg["train_iters"] = iters
     images, poses = synthetic_frames(12, 400, device, n_samples=128)          # every rank renders the same frames (same seed)
     ds = BlenderDataset.from_tensors(images, poses, SYNTHETIC_CAMERA_ANGLE)
@@ -416,24 +416,27 @@ def main():
         "final_loss": float(loss.item()),
     }
 
+    # ---- every phase timed INSIDE the step: a HIP event on the launch stream after each phase.  EVERY rank runs
+    # these steps (they contain the gradient all-reduce: a rank-0-only loop would wait for its peers for ever)
+    phases = ["batch_sampling", "fwd", "loss", "dgrad", "wgrad", "adam+pack"]
+    acc = {p: 0.0 for p in phases}
+    reps = max(10, min(args.steps, 30))
+    for _ in range(reps):
+        evs = [("start", torch.cuda.Event(enable_timing=True))]
+        evs[0][1].record()
+
+        def mark(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append((name, e))
+        step(mark)
+        torch.cuda.synchronize()
+        for (_, e0), (name, e1) in zip(evs[:-1], evs[1:]):
+            acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
+    barrier()
+
     if rank == 0:
         n = R * S
-        # ---- every phase timed INSIDE the step: a HIP event on the launch stream after each phase ----
-        phases = ["batch_sampling", "fwd", "loss", "dgrad", "wgrad", "adam+pack"]
-        acc = {p: 0.0 for p in phases}
-        reps = max(10, min(args.steps, 30))
-        for _ in range(reps):
-            evs = [("start", torch.cuda.Event(enable_timing=True))]
-            evs[0][1].record()
-
-            def mark(name):
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()
-                evs.append((name, e))
-            step(mark)
-            torch.cuda.synchronize()
-            for (_, e0), (name, e1) in zip(evs[:-1], evs[1:]):
-                acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
         in_step = {p: acc[p] / reps for p in acc}
         out["kernels_in_step"] = {p: {"ms": v} for p, v in in_step.items()}
         out["kernels_in_step_note"] = ("HIP events on the launch stream between the phases of the timed step; "

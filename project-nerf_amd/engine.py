@@ -145,7 +145,7 @@ class VanillaNerfEngine:
             # weight gradients in two launches: the late layers' range is all-reduced (RCCL) while the
             # early layers' is still being computed; both are averaged by grad_scale below
             ops.mlp_bwd_overlapped(self.packed, stash, rgb, sigma, d_rgb.view(n, 3), d_sigma.view(n), self.grads,
-                                   self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)), sync_grads_async, amax=amax)
+                                   self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)), sync_grads_async, amax=amax, mark=mark)
         else:
             ops.mlp_bwd(self.packed, stash, rgb, sigma, d_rgb.view(n, 3), d_sigma.view(n), self.grads,
                         self._buf("bwd", ops.mlp_bwd_workspace_bytes(n)), amax=amax, mark=mark)

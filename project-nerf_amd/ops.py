@@ -460,7 +460,7 @@ def mlp_bwd(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Te
 
 
 def mlp_bwd_overlapped(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor, d_rgb: Tensor, d_sigma: Tensor,
-                       grads: Tensor, workspace: Tensor, reduce_async, amax: Optional[Tensor] = None) -> None:
+                       grads: Tensor, workspace: Tensor, reduce_async, amax: Optional[Tensor] = None, mark=None) -> None:
     """mlp_bwd for data-parallel training: dgrad, then the weight gradients in two launches;
     ``reduce_async(view)`` starts the all-reduce of a finished parameter range and returns a
     handle (``.wait()``) or None -- the first range is on the wire while the second is computed."""
@@ -468,6 +468,8 @@ def mlp_bwd_overlapped(packed: Tensor, stash: Tensor, rgb: Tensor, sigma: Tensor
     n = sigma.numel()
     _lib.check(lib.nerf_mlp_bwd_dgrad_ex(_p(packed), _p(stash), _p(rgb), _p(sigma), _p(d_rgb), _p(d_sigma), n,
                                          _p(workspace), _p(amax), _stream()), "nerf_mlp_bwd_dgrad")
+    if mark is not None:
+        mark("dgrad")
     split = lib.nerf_mlp_wgrad_part_split()
     handles = []
     for part, view in ((1, grads[split:]), (2, grads[:split])):

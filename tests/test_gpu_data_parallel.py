@@ -161,3 +161,35 @@ def test_engine_step_over_the_native_comm_equals_the_plain_step():
         assert float((outs[0] - outs[1]).norm() / outs[0].norm()) < 1e-5
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("workload", ["vanilla", "instant"])
+def test_bench_two_rank_control_flow_on_one_device(workload, tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on
+    the one GPU of the box: both ranks on device 0, gloo instead of RCCL.  Covers what no single-process test
+    can: every rank takes part in every collective of the run (timed steps, the in-step timing repetitions, the
+    replica check, the row-band gather), rank 0 prints ONE JSON line with whole-job throughput."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, NERF_BENCH_SINGLE_DEVICE="1", NERF_DIST_BACKEND="gloo", NERF_BENCH_DP_ITERS="48")
+    port = 29650 + (0 if workload == "vanilla" else 1)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--frames", "6",
+           "--no-cpu-baseline", "--render-frames", "1"]
+    if workload == "instant":
+        cmd += ["--workload", "instant"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 4
+    per_rank = 4096 if workload == "vanilla" else 16384
+    assert abs(out["value"] - 2 * per_rank / (out["ms_per_step"] * 1e-3)) < 1e-3 * out["value"]     # whole-job rays/s
+    assert out["render_fps"] > 0
+    if workload == "instant":
+        assert out["replica_divergence"] == 0.0
+    else:
+        assert set(out["kernels_in_step"]) >= {"fwd", "loss", "dgrad", "wgrad", "adam+pack"}
+        assert all(v["ms"] > 0 for v in out["kernels_in_step"].values())
