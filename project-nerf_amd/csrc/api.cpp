@@ -30,6 +30,7 @@ static const OptionSlot kSlots[] = {
     {"hash_bwd_atomic", "NERF_HASH_BWD_ATOMIC", &Options::hash_bwd_atomic},
     {"wgrad_atomic", "NERF_WGRAD_ATOMIC", &Options::wgrad_atomic},
     {"wgrad_k16", "NERF_WGRAD_K16", &Options::wgrad_k16},
+    {"wgrad_big_only", "NERF_WGRAD_BIG_ONLY", &Options::wgrad_big_only},
     {"infer_shape32", "NERF_INFER_SHAPE32", &Options::infer_shape32},
     {"stash_bf16", "NERF_STASH_BF16", &Options::stash_bf16},
 };

@@ -31,6 +31,7 @@ struct Options {
   int wgrad_debug = 0;           // skeleton timing: 1 no compute, 2 no DMA, 4 no flush
   int wgrad_only = -1;           // keep one job kind
   int hash_bwd_only_level = -1;  // time one level's atomics
+  int wgrad_big_only = 0;        // 1: the Instant tiny-MLP weight gradients on the decoder's one-workgroup-per-CU kernel (A/B)
   int wgrad_k16 = 0;             // 1: the K = 16 8-bit MFMA in the owner-mode wgrad jobs (A/B against the K = 64 form)
   int wgrad_atomic = 0;          // 1: flush the split-K partial sums with float atomics at every size (A/B)
   int hash_bwd_atomic = 0;       // 1: the atomic form of the hash scatter even when a workspace is given (A/B)

@@ -47,6 +47,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// LDS ring geometry of a stage: the decoder's jobs need 16 + 16 + 4 KiB, the Instant tiny-MLP jobs 4 + 4 + 2 KiB
+struct BigStage { static constexpr int A = kWgStageA, B = kWgStageB, Bytes = kWgStageBytes; };
+struct SmallStage { static constexpr int A = 4096, B = 4096, Bytes = 4096 + 4096 + 2048; };
+
 struct LaneGeo {
   int lane, wave, fhalf, off_acc, off_nat;
   int off_acc8, off_nat8;   // 8-bit images (ds_read_b64_tr_b8)
@@ -285,7 +289,7 @@ __device__ __forceinline__ void run_job8(const WgradArgs& args, const WgradJob j
 // block, dsmall): wave w owns column tile w (w < NT_ACC) and wave NT_ACC % 8 the ones tile.
 // FP8: the images are 8-bit (A = e5m2 gradients, B = e4m3 activations); one ring stage then holds TWO wave
 // tiles (64 samples = four k-steps): same bytes per stage as one bf16 wave tile, half the iterations.
-template <int NT_ACC, int NT_NAT, bool ONES, bool SPLIT, bool FP8>
+template <int NT_ACC, int NT_NAT, bool ONES, bool SPLIT, bool FP8, class Stage = BigStage>
 __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob job, int wt0, int wt1,
                                         char* smem, const LaneGeo g) {
   constexpr int NT = SPLIT ? 2 : NT_ACC + NT_NAT + (ONES ? 1 : 0);
@@ -302,7 +306,7 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
   const int per_wave = (pieces + 7) >> 3;    // every wave issues exactly this many (tail duplicates)
   const unsigned smem_lds = lds_addr(smem);
   auto issue = [&](int wt) {
-    const unsigned stage = smem_lds + (wt & (kWgStages - 1)) * kWgStageBytes;
+    const unsigned stage = smem_lds + (wt & (kWgStages - 1)) * Stage::Bytes;
     for (int i = 0; i < per_wave; ++i) {
       int pc = wave + 8 * i;
       pc = pc < pieces ? pc : pieces - 1;
@@ -314,11 +318,11 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
       } else if (pc < pieces_a + pieces_b) {
         const int o = pc - pieces_a;
         src = job.b_acc + (size_t)wt * job.b_acc_bytes + o * 1024;
-        dst = stage + kWgStageA + o * 1024;
+        dst = stage + Stage::A + o * 1024;
       } else {
         const int o = pc - pieces_a - pieces_b;
         src = job.b_nat + (size_t)wt * job.b_nat_bytes + o * 1024;
-        dst = stage + kWgStageA + kWgStageB + o * 1024;
+        dst = stage + Stage::A + Stage::B + o * 1024;
       }
       dma_1k(src + lane * 16, __builtin_amdgcn_readfirstlane(dst));
     }
@@ -349,15 +353,15 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
     asm volatile("" ::: "memory");
     if (wt + 3 < wt1 && !(args.debug & 2)) issue(wt + 3);
     if (!active || (args.debug & 1)) continue;
-    const char* stage = smem + (wt & (kWgStages - 1)) * kWgStageBytes;
+    const char* stage = smem + (wt & (kWgStages - 1)) * Stage::Bytes;
     const char* pa = SPLIT ? stage + g.off_nat - 1024 * g.fhalf : stage + wave * 2048 + g.off_acc;
-    const char* pb = stage + kWgStageA + g.off_acc + (SPLIT ? (wave < NT_ACC ? wave : 0) * 2048 : 0);
-    const char* pn = stage + kWgStageA + kWgStageB + g.off_nat;
+    const char* pb = stage + Stage::A + g.off_acc + (SPLIT ? (wave < NT_ACC ? wave : 0) * 2048 : 0);
+    const char* pn = stage + Stage::A + Stage::B + g.off_nat;
     if constexpr (FP8) {
       const int half_a = job.a_bytes >> 1, half_b = job.b_acc_bytes >> 1, half_n = job.b_nat_bytes >> 1;
       const char* pa8 = SPLIT ? stage + g.off_nat8 - 512 * g.fhalf : stage + wave * 1024 + g.off_acc8;
-      const char* pb8 = stage + kWgStageA + g.off_acc8 + (SPLIT ? (wave < NT_ACC ? wave : 0) * 1024 : 0);
-      const char* pn8 = stage + kWgStageA + kWgStageB + g.off_nat8;
+      const char* pb8 = stage + Stage::A + g.off_acc8 + (SPLIT ? (wave < NT_ACC ? wave : 0) * 1024 : 0);
+      const char* pn8 = stage + Stage::A + Stage::B + g.off_nat8;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int t = s >> 1, ss = s & 1;
@@ -467,6 +471,38 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
       case 7: run_job<2, 0, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant 64-wide layers
       case 8: run_job<1, 1, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant colour-net layer 1
       default: run_job<2, 0, false, true, false>(args, job, wt0, wt1, smem, g); break;   // instant rgb layer
+    }
+  }
+}
+
+// The Instant tiny-MLP jobs (kinds 6..9) on their own: 10 KiB stages and few accumulators, so that several
+// workgroups share a CU -- the loop is barrier- and DMA-latency-bound on such small stages, a second and third
+// workgroup fill the waits of the first (the decoder's kernel holds 256 VGPRs and 144 KiB of LDS: one per CU)
+__global__ void __launch_bounds__(512) mlp_wgrad_small_kernel(const WgradArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  LaneGeo g;
+  g.lane = threadIdx.x & 63;
+  g.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = g.lane >> 4, i16 = g.lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int hh = grp >> 1;
+  g.fhalf = grp & 1;
+  g.off_acc = 512 * hh + 128 * g.fhalf + 64 * (p & 1) + 16 * q + 8 * (p >> 1);
+  g.off_nat = 32 * (8 * hh + q) + 16 * (p >> 1) + 8 * (p & 1) + 1024 * g.fhalf;
+  g.off_acc8 = g.off_nat8 = 0;
+  const long long lo = args.total_cost * blockIdx.x / gridDim.x;
+  const long long hi = args.total_cost * (blockIdx.x + 1) / gridDim.x;
+  for (int j = 0; j < args.n_jobs; ++j) {
+    const WgradJob job = args.jobs[j];
+    const long long j0 = job.cost0, j1 = job.cost0 + (long long)job.cost * args.wave_tiles;
+    if (hi <= j0 || lo >= j1) continue;
+    const long long a0 = lo > j0 ? lo - j0 : 0, a1 = (hi < j1 ? hi : j1) - j0;
+    const int wt0 = (int)((a0 + job.cost - 1) / job.cost), wt1 = (int)((a1 + job.cost - 1) / job.cost);
+    if (wt0 >= wt1) continue;
+    switch (job.kind) {
+      case 6: run_job<0, 1, false, false, false, SmallStage>(args, job, wt0, wt1, smem, g); break;   // sigma-net layer 1
+      case 7: run_job<2, 0, false, false, false, SmallStage>(args, job, wt0, wt1, smem, g); break;   // 64-wide layers
+      case 8: run_job<1, 1, false, false, false, SmallStage>(args, job, wt0, wt1, smem, g); break;   // colour-net layer 1
+      default: run_job<2, 0, false, true, false, SmallStage>(args, job, wt0, wt1, smem, g); break;   // rgb layer
     }
   }
 }
@@ -653,6 +689,17 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
       off += (long long)count * jb.p_stride;
     }
     if (ok && (size_t)off * sizeof(float) <= slab_bytes) args.slab = slab;
+  }
+  bool small = args.amax == nullptr && args.slab == nullptr && !options().wgrad_big_only;
+  for (int j = 0; j < args.n_jobs; ++j) {
+    const WgradJob& jb = args.jobs[j];
+    small = small && jb.kind >= 6 && jb.a_bytes <= SmallStage::A && jb.b_acc_bytes <= SmallStage::B && jb.b_nat_bytes <= 2048;
+  }
+  if (small) {
+    const int lds = kWgStages * SmallStage::Bytes;
+    long long g3 = want < 1 ? 1 : (want > 3LL * n_cu ? 3LL * n_cu : want);
+    hipLaunchKernelGGL(mlp_wgrad_small_kernel, dim3((int)g3), dim3(512), lds, stream, args);
+    return check_launch("nerf_imlp_bwd (wgrad)");
   }
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid), dim3(512), kWgLds, stream, args);
   if (args.slab != nullptr) {
