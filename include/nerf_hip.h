@@ -271,6 +271,14 @@ int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* table, int n_
                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                          const unsigned* offset_host, const unsigned* dense_host, float bound,
                          float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream);
+/* the forward from an fp16 copy of the table ([entries, 2] halves; kept current by nerf_adamw_clip_step_shadow or
+ * made with nerf_f32_to_f16): half the bytes per gather.  tinycudann evaluates its grid from fp16 parameters next
+ * to the fp32 master copy the optimiser updates (reference src/embeddings.py:57-73 leaves its default). */
+int nerf_hash_encode_fwd_f16(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                         const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                         const unsigned* offset_host, const unsigned* dense_host, float bound,
+                         float* out_f32, void* out_nat_bf16, nerf_stream_t stream);
+int nerf_f32_to_f16(const float* src, void* dst_f16, int64_t n, nerf_stream_t stream);
 int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float* scale_host,
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
@@ -375,6 +383,10 @@ int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight
 int nerf_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                          int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                          const float* normsq_dev, float max_norm, float grad_scale, nerf_stream_t stream);
+/* the same step, also writing params_f16_out[n] = fp16(updated params) for nerf_hash_encode_fwd_f16 */
+int nerf_adamw_clip_step_shadow(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         const float* normsq_dev, float max_norm, float grad_scale, void* params_f16_out, nerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,8 @@ PROTOTYPES = {
     "nerf_mlp_wgrad_part_split": (i64, []),
     "nerf_mlp_bwd_wgrad_part": (i32, [c_ptr, c_ptr, i64, c_ptr, i32, c_ptr]),
     "nerf_hash_encode_fwd": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_hash_encode_fwd_f16": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_f32_to_f16": (i32, [c_ptr, c_ptr, i64, c_ptr]),
     "nerf_hash_encode_bwd": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_levels": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, i32, i32, c_ptr]),
     "nerf_hash_encode_bwd_workspace_bytes": (size_t, [i64, i32]),
@@ -74,6 +76,7 @@ PROTOTYPES = {
     "nerf_adam_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, c_ptr]),
     "nerf_tv_normsq": (i32, [c_ptr, c_ptr, i64, f32, f32, c_ptr, c_ptr]),
     "nerf_adamw_clip_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr]),
+    "nerf_adamw_clip_step_shadow": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, c_ptr]),
 }
 
 _lib = None

@@ -21,7 +21,7 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
 template <bool VEC>
 __device__ __forceinline__ void adam_sweep(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                            float* __restrict__ v, int64_t n, float gs, float lr, float beta1, float beta2,
-                                           float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
+                                           float eps, float wd, float inv_bc1, float inv_sqrt_bc2, _Float16* __restrict__ shadow = nullptr) {
   const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n4 = VEC ? n / 4 : 0;
   for (int64_t i = tid; i < n4; i += stride) {
@@ -36,8 +36,16 @@ __device__ __forceinline__ void adam_sweep(float* __restrict__ p, const float* _
     reinterpret_cast<f4*>(m)[i] = mm;
     reinterpret_cast<f4*>(v)[i] = vv;
     reinterpret_cast<f4*>(p)[i] = pp;
+    if (shadow != nullptr) {                  // fp16 copy of the updated parameters (the hash forward gathers from it)
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      h4 hh = {(_Float16)pp[0], (_Float16)pp[1], (_Float16)pp[2], (_Float16)pp[3]};
+      reinterpret_cast<h4*>(shadow)[i] = hh;
+    }
   }
-  for (int64_t i = 4 * n4 + tid; i < n; i += stride) adam_update(p[i], g[i] * gs, m[i], v[i], lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+  for (int64_t i = 4 * n4 + tid; i < n; i += stride) {
+    adam_update(p[i], g[i] * gs, m[i], v[i], lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+    if (shadow != nullptr) shadow[i] = (_Float16)p[i];
+  }
 }
 
 template <bool VEC>
@@ -136,13 +144,18 @@ template <bool VEC>
 __global__ void __launch_bounds__(256)
 adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                   int64_t n, float lr, float beta1, float beta2, float eps, float wd, float inv_bc1,
-                  float inv_sqrt_bc2, const float* __restrict__ normsq, float max_norm, float extra_scale) {
+                  float inv_sqrt_bc2, const float* __restrict__ normsq, float max_norm, float extra_scale,
+                  _Float16* __restrict__ shadow) {
   float gs = extra_scale;
   if (normsq != nullptr && max_norm > 0.0f) {
     const float coef = max_norm / (sqrtf(*normsq * extra_scale * extra_scale) + 1e-6f);   // torch clip_grad_norm_
     gs *= coef < 1.0f ? coef : 1.0f;
   }
-  adam_sweep<VEC>(p, g, m, v, n, gs, lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+  adam_sweep<VEC>(p, g, m, v, n, gs, lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2, shadow);
+}
+
+__global__ void __launch_bounds__(256) f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (_Float16)src[i];
 }
 
 }  // namespace nerf
@@ -166,9 +179,40 @@ extern "C" int nerf_tv_normsq(const float* params, float* grads, int64_t n, floa
   return nerf::check_launch("nerf_tv_normsq");
 }
 
+static int adamw_clip_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                           int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           const float* normsq_dev, float max_norm, float grad_scale, void* shadow_f16, nerf_stream_t stream);
+
 extern "C" int nerf_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                                     int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                                     const float* normsq_dev, float max_norm, float grad_scale, nerf_stream_t stream) {
+  return adamw_clip_impl(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, normsq_dev, max_norm,
+                         grad_scale, nullptr, stream);
+}
+
+extern "C" int nerf_adamw_clip_step_shadow(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                           int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                           const float* normsq_dev, float max_norm, float grad_scale, void* params_f16_out,
+                                           nerf_stream_t stream) {
+  NERF_REQUIRE(params_f16_out != nullptr && ((uintptr_t)params_f16_out & 7) == 0, "nerf_adamw_clip_step_shadow: params_f16_out NULL or unaligned");
+  return adamw_clip_impl(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, normsq_dev, max_norm,
+                         grad_scale, params_f16_out, stream);
+}
+
+extern "C" int nerf_f32_to_f16(const float* src, void* dst_f16, int64_t n, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0, "nerf_f32_to_f16: n=%lld", (long long)n);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(src && dst_f16, "nerf_f32_to_f16: NULL pointer");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nerf::f32_to_f16_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), src, static_cast<_Float16*>(dst_f16), n);
+  return nerf::check_launch("nerf_f32_to_f16");
+}
+
+static int adamw_clip_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                           int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           const float* normsq_dev, float max_norm, float grad_scale, void* shadow_f16, nerf_stream_t stream) {
+  _Float16* shadow = static_cast<_Float16*>(shadow_f16);
   NERF_REQUIRE(n >= 0 && step >= 1, "nerf_adamw_clip_step: n=%lld step=%d", (long long)n, step);
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq, "nerf_adamw_clip_step: NULL pointer");
@@ -178,10 +222,10 @@ extern "C" int nerf_adamw_clip_step(float* params, const float* grads, float* ex
   if (nerf::aligned16(params, grads, exp_avg, exp_avg_sq))
     hipLaunchKernelGGL(nerf::adamw_clip_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-                       (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale);
+                       (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale, shadow);
   else
     hipLaunchKernelGGL(nerf::adamw_clip_kernel<false>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
-                       (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale);
+                       (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale, shadow);
   return nerf::check_launch("nerf_adamw_clip_step");
 }

@@ -70,8 +70,18 @@ __device__ __forceinline__ Corner corners_of(const HashLevels& L, int lvl, float
 
 // out_f32 [n, 2L] row-major (optional), out_nat: bf16 natural-order operand blocks (optional):
 // [wave tile of 32 points][k-step ks = level/8][lane (c, h)][8] with feature 16ks + 8h + j
+// TableT = float2: the fp32 parameters themselves.  TableT = half2_t: an fp16 copy kept by the optimiser
+// (nerf_adamw_clip_step_shadow) -- half the bytes per gather and twice the entries per cache line; tinycudann
+// itself evaluates its grid from fp16 parameters next to an fp32 master copy.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 table_entry(const float2* t, unsigned i) { return t[i]; }
+__device__ __forceinline__ float2 table_entry(const half2_t* t, unsigned i) {
+  const half2_t h = t[i];
+  return make_float2((float)h[0], (float)h[1]);
+}
+template <class TableT>
 __global__ void __launch_bounds__(256)
-hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const float2* __restrict__ table, HashLevels L,
+hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const TableT* __restrict__ table, HashLevels L,
                 float* __restrict__ out_f32, __bf16* __restrict__ out_nat, unsigned* __restrict__ idx_out) {
   // the operand image is padded to whole 128-point tiles: pad rows repeat the last point so that
   // every stashed value is finite (their gradients are zero downstream)
@@ -87,7 +97,7 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const f
     float f0 = 0.0f, f1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float2 v = table[c.idx[k]];
+      const float2 v = table_entry(table, c.idx[k]);
       f0 += c.w[k] * v.x;
       f1 += c.w[k] * v.y;
       if (idx_out != nullptr && p < n) idx_out[g * 8 + k] = c.idx[k];
@@ -544,13 +554,35 @@ static int fill_levels(HashLevels& L, int n_levels, const float* scale, const un
 
 using namespace nerf;
 
+static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
+                         const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                         const unsigned* offset_host, const unsigned* dense_host, float bound,
+                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream);
+
 extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* table, int n_levels,
                                     const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                                     const unsigned* offset_host, const unsigned* dense_host, float bound,
                                     float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream) {
+  return hash_fwd_impl(pts, n, table, nullptr, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, out_f32,
+                       out_nat_bf16, idx_out, stream);
+}
+
+extern "C" int nerf_hash_encode_fwd_f16(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                        const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                        const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                        float* out_f32, void* out_nat_bf16, nerf_stream_t stream) {
+  NERF_REQUIRE(table_f16 != nullptr || n == 0, "nerf_hash_encode_fwd_f16: NULL table");
+  return hash_fwd_impl(pts, n, nullptr, table_f16, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, out_f32,
+                       out_nat_bf16, nullptr, stream);
+}
+
+static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
+                         const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                         const unsigned* offset_host, const unsigned* dense_host, float bound,
+                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_fwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
-  NERF_REQUIRE(pts && table && scale_host && res_host && size_host && offset_host && dense_host,
+  NERF_REQUIRE(pts && (table || table_f16) && scale_host && res_host && size_host && offset_host && dense_host,
                "nerf_hash_encode_fwd: NULL pointer");
   NERF_REQUIRE(out_f32 || out_nat_bf16, "nerf_hash_encode_fwd: no output requested");
   HashLevels L;
@@ -559,8 +591,12 @@ extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* ta
   const int64_t n_pad = (n + 127) / 128 * 128;
   int64_t blocks = (n_pad + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(hash_fwd_kernel, dim3((int)blocks, n_levels), dim3(256), 0, as_stream(stream), pts, n, n_pad,
-                     reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out);
+  if (table_f16 != nullptr)
+    hipLaunchKernelGGL(hash_fwd_kernel<half2_t>, dim3((int)blocks, n_levels), dim3(256), 0, as_stream(stream), pts, n, n_pad,
+                       static_cast<const half2_t*>(table_f16), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out);
+  else
+    hipLaunchKernelGGL(hash_fwd_kernel<float2>, dim3((int)blocks, n_levels), dim3(256), 0, as_stream(stream), pts, n, n_pad,
+                       reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out);
   return check_launch("nerf_hash_encode_fwd");
 }
 

@@ -245,6 +245,12 @@ class InstantNgpEngine:
         self.g_table = torch.zeros_like(self.table)
         self.g_net = torch.empty_like(self.net)
         self._hash_ws = None
+        # fp16 copy of the table for the forward gathers (tinycudann evaluates its grid from fp16 parameters next to
+        # the fp32 master copy too): written by the optimiser kernel, refreshed here whenever torch code has
+        # touched ``self.table`` in place (tensor version counter); cfg half_table: false keeps fp32 gathers
+        self.half_table = bool(cfg.get("half_table", True))
+        self.table_h = torch.empty(self.table.numel(), device=self.device, dtype=torch.float16) if self.half_table else None
+        self._table_version = None
         self.packed = ops.imlp_pack(self.net)
         self.near, self.far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
         self.lr0, self.eta_min = float(cfg.get("learning_rate", 1e-2)), float(cfg.get("eta_min", 1e-4))
@@ -263,11 +269,20 @@ class InstantNgpEngine:
         import math
         return self.eta_min + (self.lr0 - self.eta_min) * (1 + math.cos(math.pi * self.step_count / self.t_max)) / 2
 
+    def _gather_table(self) -> Tensor:
+        """the table the forward gathers from: the fp16 copy, brought up to date if torch code wrote the fp32 one"""
+        if not self.half_table:
+            return self.table.view(-1, 2)
+        if self._table_version != self.table._version:
+            ops.f32_to_f16(self.table, self.table_h)
+            self._table_version = self.table._version
+        return self.table_h.view(-1, 2)
+
     def _field(self, pts: Tensor, dirs: Tensor, train: bool):
         lib = ops._lib.load()
         n = pts.shape[0]
         ws = torch.empty(lib.nerf_imlp_workspace_bytes(n), device=self.device, dtype=torch.uint8)
-        ops.hash_encode_fwd(pts, self.table.view(-1, 2), self.levels, self.bound, want_f32=False, out_nat=ws)
+        ops.hash_encode_fwd(pts, self._gather_table(), self.levels, self.bound, want_f32=False, out_nat=ws)
         rgb, sigma = torch.empty(n, 3, device=self.device), torch.empty(n, device=self.device)
         ops._lib.check(lib.nerf_imlp_fwd(self.packed.data_ptr(), ws.data_ptr(), dirs.data_ptr(), n, rgb.data_ptr(),
                                          sigma.data_ptr(), 1 if train else 0, ops._stream()), "nerf_imlp_fwd")
@@ -373,7 +388,8 @@ class InstantNgpEngine:
         self.step_count += 1
         scale = 1.0 / self.world_size
         ops.tv_clip_adamw_step(self.table, self.g_table, *self.state["table"], self.step_count, lr, tv_weight=self.tv_weight,
-                               max_norm=1.0, weight_decay=self.wd, grad_scale=scale, scratch=self._scratch)
+                               max_norm=1.0, weight_decay=self.wd, grad_scale=scale, scratch=self._scratch,
+                               shadow_f16=self.table_h if self._table_version == self.table._version else None)
         ops.tv_clip_adamw_step(self.net, self.g_net, *self.state["net"], self.step_count, lr, max_norm=1.0,
                                weight_decay=self.wd, grad_scale=scale, scratch=self._scratch)
         ops.imlp_pack(self.net, self.packed)

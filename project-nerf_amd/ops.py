@@ -577,14 +577,33 @@ class HashLevelTable:
 
 def hash_encode_fwd(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: float,
                     want_f32: bool = True, out_nat: Optional[Tensor] = None, want_index: bool = False):
+    """``table``: fp32 [entries, 2] (the parameters) or an fp16 copy of them (torch.float16: half the bytes per
+    gather; see nerf_hash_encode_fwd_f16)."""
     lib = _lib.load()
-    pts, table = _dev(pts, "pts"), _dev(table, "table")
+    pts = _dev(pts, "pts")
     n = pts.shape[0]
     out = torch.empty(n, 2 * levels.n_levels, device=pts.device) if want_f32 else None
+    if table.dtype == torch.float16:
+        if want_index:
+            raise ValueError("hash_encode_fwd: corner indices come with the fp32 table only")
+        table = _dev(table, "table", torch.float16)
+        _lib.check(lib.nerf_hash_encode_fwd_f16(_p(pts), n, _p(table), levels.n_levels, *levels.host_args(), float(bound),
+                                                _p(out), _p(out_nat), _stream()), "nerf_hash_encode_fwd_f16")
+        return out, None
+    table = _dev(table, "table")
     idx = torch.empty(n, levels.n_levels, 8, device=pts.device, dtype=torch.int32) if want_index else None
     _lib.check(lib.nerf_hash_encode_fwd(_p(pts), n, _p(table), levels.n_levels, *levels.host_args(), float(bound),
                                         _p(out), _p(out_nat), _p(idx), _stream()), "nerf_hash_encode_fwd")
     return out, idx
+
+
+def f32_to_f16(src: Tensor, dst: Optional[Tensor] = None) -> Tensor:
+    """fp16 copy of a flat fp32 parameter vector (the shadow table of the hash forward)"""
+    src = _dev(src, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=torch.float16)
+    _lib.check(_lib.load().nerf_f32_to_f16(_p(src), _p(dst), src.numel(), _stream()), "nerf_f32_to_f16")
+    return dst
 
 
 def _hash_bwd_scratch(pts: Tensor, levels: "HashLevelTable") -> Tensor:
@@ -768,8 +787,9 @@ def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
 def tv_clip_adamw_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
                        tv_weight: float = 0.0, max_norm: float = 0.0, weight_decay: float = 0.0,
                        beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0,
-                       scratch: Optional[Tensor] = None) -> None:
+                       scratch: Optional[Tensor] = None, shadow_f16: Optional[Tensor] = None) -> None:
     """TV-L1 gradient (optional) + global-norm clip + AdamW on one flat group, two streaming passes.
+    ``shadow_f16``: a torch.float16 tensor of the same size that receives the updated parameters as well.
     ``grad_scale`` (1/world after a summing all-reduce) scales the data gradient BEFORE the TV term is
     added, so the regulariser keeps its weight on any number of ranks (reference run.py:611-629)."""
     lib = _lib.load()
@@ -779,6 +799,13 @@ def tv_clip_adamw_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_s
     normsq = scratch if scratch is not None else torch.empty(1, device=params.device)
     _lib.check(lib.nerf_tv_normsq(_p(params), _p(grads), params.numel(), tv_weight, grad_scale, _p(normsq), _stream()),
                "nerf_tv_normsq")
+    if shadow_f16 is not None:
+        if shadow_f16.dtype != torch.float16 or shadow_f16.numel() != params.numel() or not shadow_f16.is_contiguous():
+            raise ValueError("shadow_f16 must be a contiguous torch.float16 tensor of the parameters' size")
+        _lib.check(lib.nerf_adamw_clip_step_shadow(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), step, lr,
+                                                   beta1, beta2, eps, weight_decay, _p(normsq), max_norm, 1.0, _p(shadow_f16),
+                                                   _stream()), "nerf_adamw_clip_step_shadow")
+        return
     _lib.check(lib.nerf_adamw_clip_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), step, lr,
                                         beta1, beta2, eps, weight_decay, _p(normsq), max_norm, 1.0, _stream()),
                "nerf_adamw_clip_step")

@@ -489,3 +489,40 @@ def test_hash_backward_binned_form_large_tables(ops):
         ws = torch.empty(ops.hash_encode_bwd_workspace_bytes(20000, 8), dtype=torch.uint8, device="cuda")
         ops.hash_encode_bwd(pts, t, 1.5, d_feat, out, workspace=ws)
         assert float((out - ref).abs().max()) < 1e-5 * float(ref.abs().max()), log2_t
+
+
+def test_fp16_shadow_table_forward_and_bookkeeping(ops):
+    """The hash forward from an fp16 copy of the table (nerf_hash_encode_fwd_f16): features equal those of the
+    fp16-rounded table evaluated in fp32 (the oracle), i.e. within fp16 rounding of the fp32 result; the optimiser
+    kernel keeps the copy equal to fp16(params) (nerf_adamw_clip_step_shadow); the engine notices torch code
+    writing the fp32 table and refreshes the copy."""
+    import yaml
+    from conftest import ROOT
+    from project_nerf_amd.engine import InstantNgpEngine
+    lv = O.hash_grid_levels(16, 19, 16, 1.5)
+    t = ops.HashLevelTable(16, 19, 16, 1.5)
+    pts, _ = make_inputs(2000, 5)
+    table = (torch.rand(t.entries, 2, generator=torch.Generator().manual_seed(1)) * 2 - 1) * 0.5
+    half = ops.f32_to_f16(table.cuda().view(-1))
+    assert torch.equal(half.cpu(), table.view(-1).half())
+    feat_h, _ = ops.hash_encode_fwd(pts.cuda(), half.view(-1, 2), t, 1.5)
+    ref_h = O.hash_encode(lv, table.half().float(), O.hash_normalise(pts, 1.5))
+    np.testing.assert_allclose(feat_h.cpu().numpy(), ref_h.numpy(), rtol=1e-5, atol=1e-6)
+    ref = O.hash_encode(lv, table, O.hash_normalise(pts, 1.5))
+    assert float((feat_h.cpu() - ref).abs().max()) < 5e-4 * 0.5                  # fp16: 2^-11 relative on entries <= 0.5
+    # optimiser keeps the copy current
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    eng = InstantNgpEngine(cfg, seed=1)
+    assert eng.half_table and eng.table_h.dtype == torch.float16
+    o = torch.randn(256, 3)
+    o = (o / o.norm(dim=-1, keepdim=True) * 4.0).cuda()
+    d = torch.nn.functional.normalize(-o.cpu() + 0.2 * torch.randn(256, 3), dim=-1).cuda()
+    for _ in range(3):
+        eng.train_step(o, d, torch.rand(256, 3).cuda(), 64)
+    assert torch.equal(eng.table_h, eng.table.half())
+    eng.table.mul_(2.0)                                                          # torch writes the master copy ...
+    eng.render_rays(o, d, 64)
+    assert torch.equal(eng.table_h, eng.table.half())                            # ... the next forward refreshed the copy
+    fp32 = InstantNgpEngine(dict(cfg, half_table=False), seed=1)
+    assert fp32.table_h is None
+    fp32.train_step(o, d, torch.rand(256, 3).cuda(), 64)
