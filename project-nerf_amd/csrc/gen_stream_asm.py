@@ -42,7 +42,7 @@ from collections import deque
 
 D = int(os.environ.get("GEN_D", 4))                 # A-fragment prefetch depth (window registers)
 EPI_START = 3     # first gap (after MFMA k) that may carry epilogue work
-# timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,vmwait,oneimage
+# timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,stinst,vmwait,oneimage
 ABLATE = set(filter(None, os.environ.get("GEN_NO", "").split(",")))
 CHUNK = 64
 VA, SO, MO, T0 = 88, 89, 90, 95          # scratch VGPRs; v91..v94: mask words (4 rotating slots in dgrad, v91 forward)
@@ -280,6 +280,8 @@ def generate(mode):
     def emit_unit(u):
         for line in u:
             if isinstance(line, tuple) and line[0] == "store":
+                if "stinst" in ABLATE:            # keep the conversions and mask arithmetic, drop the store instructions
+                    continue
                 emit(line[1])
                 vm_q.append(("st",))
             elif isinstance(line, tuple) and line[0] == "load":
