@@ -35,11 +35,13 @@ class NeRFDecoder(BaseDecoder):
     def __init__(self, pos_dim, dir_dim, hidden_dim=256, num_layers=8, skip_layer=4, view_dim=128):
         super().__init__()
         ok_dims = lambda dim, max_l: dim in [3 + 6 * l for l in range(max_l + 1)]
-        if (hidden_dim, num_layers, skip_layer, view_dim) != (256, 8, 4, 128) or not ok_dims(pos_dim, 10) or not ok_dims(dir_dim, 4):
-            raise NotImplementedError(
-                "libnerf_hip is compiled for hidden 256 / 8 layers / skip 4 / view 128 and Fourier codes of up to "
-                f"L_embed 10 / L_embed_dir 4 bands (3 + 6 L columns); got pos {pos_dim}, dir {dir_dim}, hidden {hidden_dim}, "
-                f"layers {num_layers}, skip {skip_layer}, view {view_dim}")
+        # ``fused``: the shape the HIP chain kernels are compiled for.  Any other hidden_dim / num_layers /
+        # skip_layer / view_dim / code width from the YAML (reference src/core.py:36-55) still works: the same
+        # layers then run as library GEMMs on the GPU (torch -> hipBLASLt) around the HIP Fourier codes -- slower,
+        # same parameters and state-dict keys, fp32 like the reference.
+        self.fused = (hidden_dim, num_layers, skip_layer, view_dim) == (256, 8, 4, 128) and ok_dims(pos_dim, 10) and ok_dims(dir_dim, 4)
+        if not ok_dims(pos_dim, 16) or not ok_dims(dir_dim, 16) or not 0 < skip_layer < max(num_layers, 1) + 1 or num_layers < 1:
+            raise ValueError(f"NeRFDecoder: pos {pos_dim} / dir {dir_dim} columns (3 + 6 L expected), {num_layers} layers, skip {skip_layer}")
         self.pos_dim, self.dir_dim = pos_dim, dir_dim
         self.skip_layer = skip_layer
         layers = []
@@ -78,8 +80,26 @@ class NeRFDecoder(BaseDecoder):
             self._packed_version = version
         return self._packed
 
+    def _layers(self, x_enc, d_enc):
+        """the reference's forward (src/decoders.py:68-87) layer by layer: library GEMMs, fp32"""
+        h = x_enc
+        for i, layer in enumerate(self.pts_layers):
+            if i == self.skip_layer:
+                h = torch.cat([h, x_enc], dim=-1)
+            h = torch.relu(layer(h))
+        sigma = torch.relu(self.sigma_layer(h))
+        hv = torch.relu(self.view_layer(torch.cat([self.feature_layer(h), d_enc], dim=-1)))
+        return torch.sigmoid(self.rgb_layer(hv)), sigma
+
     def field(self, pts, dirs, z=None):
         """Fused encode + decode.  Point mode: pts/dirs [N,3]; ray mode: rays_o/rays_d [R,3] + z [R,S]."""
+        if not self.fused:
+            if z is not None:                                  # ray mode: sample points and per-sample directions
+                n_s = z.shape[1]
+                pts = (pts[:, None, :] + dirs[:, None, :] * z[..., None]).reshape(-1, 3)
+                dirs = dirs[:, None, :].expand(-1, n_s, -1).reshape(-1, 3)
+            code = lambda v, dim: ops.fourier_encode(v.contiguous(), (dim - 3) // 6) if dim > 3 else v
+            return self._layers(code(pts, self.pos_dim), code(dirs, self.dir_dim))
         rgb, sigma = ops.decoder(self.flat_parameters(), self.packed_weights(), pts, dirs, z)
         return rgb, sigma.unsqueeze(-1)
 
@@ -88,6 +108,10 @@ class NeRFDecoder(BaseDecoder):
         (NeuralField takes the fused path ``field`` -- the codes are then formed in registers.)"""
         if x_enc.shape[-1] != self.pos_dim or d_enc.shape[-1] != self.dir_dim:
             raise ValueError(f"expected x_enc [N,{self.pos_dim}] and d_enc [N,{self.dir_dim}]")
+        if not self.fused:
+            if x_enc.device.type != "cuda":
+                raise ops._lib.NerfHipError("NeRFDecoder runs on a HIP device only (no CPU fallback)")
+            return self._layers(x_enc, d_enc)
         pad = torch.nn.functional.pad
         rgb, sigma = ops.decoder_encoded(self.flat_parameters(), self.packed_weights(), pad(x_enc, (0, 63 - self.pos_dim)),
                                          pad(d_enc, (0, 27 - self.dir_dim)))

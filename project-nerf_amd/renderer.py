@@ -167,7 +167,7 @@ def render_image(model, rays_o, rays_d, near, far, n_samples, chunk, white_bkgd)
     """reference src/renderer.py:387-418."""
     h, w = rays_o.shape[:2]
     o, d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
-    if getattr(model, "mode", None) == "part2_nerf" and not torch.is_grad_enabled():
+    if getattr(model, "mode", None) == "part2_nerf" and not torch.is_grad_enabled() and getattr(model.decoder, "fused", True):
         # the whole image as one launch chain (nerf_render_rays_fwd): same kernels, one reused workspace
         bg = torch.ones(3, device=o.device) if white_bkgd else torch.zeros(3, device=o.device)
         return ops.render_rays_fwd(model.decoder.packed_weights(), o.contiguous(), d.contiguous(), n_samples, near, far, bg,

@@ -352,8 +352,52 @@ def test_narrower_fourier_codes_from_yaml(L, L_dir, use_dirs):
         cos = float((got * want).sum() / (got.norm() * want.norm() + 1e-20))
         assert cos > 0.97, (name, cos)
 
-    with pytest.raises(NotImplementedError):
-        NeuralField({**cfg, "hidden_dim": 128})
+    assert model.decoder.fused and not NeuralField({**cfg, "hidden_dim": 128}).decoder.fused     # library-GEMM path, next test
+
+
+def test_decoder_shapes_other_than_the_compiled_one_run_as_library_gemms(tmp_path):
+    """hidden_dim / num_layers / skip_layer / view_dim / L_embed from the YAML (reference src/core.py:36-55): any value
+    builds and trains.  Shapes the chain kernels are not compiled for run the same layers as library GEMMs on the
+    GPU around the HIP Fourier codes, against the oracle's fp32 restatement of src/decoders.py:68-87."""
+    from src.core import NeuralField
+    from src.renderer import render_image, render_rays
+    cfg = {"mode": "part2_nerf", "L_embed": 12, "L_embed_dir": 5, "hidden_dim": 64, "num_layers": 5, "skip_layer": 2, "view_dim": 32}
+    torch.manual_seed(3)
+    model = NeuralField(cfg).cuda()
+    assert not model.decoder.fused and NeuralField({"mode": "part2_nerf", "L_embed": 10}).decoder.fused
+    keys = set(model.state_dict())
+    assert {"decoder.pts_layers.2.weight", "decoder.sigma_layer.bias", "decoder.view_layer.weight", "decoder.rgb_layer.weight"} <= keys
+    assert model.state_dict()["decoder.pts_layers.2.weight"].shape == (64, 64 + 75)       # skip layer: [h | x_enc]
+    g = torch.Generator().manual_seed(1)
+    pts, dirs = (torch.rand(500, 3, generator=g) - 0.5) * 3, torch.nn.functional.normalize(torch.randn(500, 3, generator=g), dim=-1)
+    rgb, sigma = model(pts.cuda(), dirs.cuda())
+    assert rgb.shape == (500, 3) and sigma.shape == (500, 1)
+    sd = {k[len("decoder."):]: v.detach().cpu() for k, v in model.state_dict().items() if k.startswith("decoder.")}
+    x_enc, d_enc = O.fourier_encode(pts, 12), O.fourier_encode(dirs, 5)
+    h = x_enc
+    for i in range(5):
+        if i == 2:
+            h = torch.cat([h, x_enc], -1)
+        h = torch.relu(torch.nn.functional.linear(h, sd[f"pts_layers.{i}.weight"], sd[f"pts_layers.{i}.bias"]))
+    ref_sigma = torch.relu(torch.nn.functional.linear(h, sd["sigma_layer.weight"], sd["sigma_layer.bias"]))
+    feat = torch.nn.functional.linear(h, sd["feature_layer.weight"], sd["feature_layer.bias"])
+    hv = torch.relu(torch.nn.functional.linear(torch.cat([feat, d_enc], -1), sd["view_layer.weight"], sd["view_layer.bias"]))
+    ref_rgb = torch.sigmoid(torch.nn.functional.linear(hv, sd["rgb_layer.weight"], sd["rgb_layer.bias"]))
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), ref_rgb.numpy(), atol=2e-4)         # sin/cos of 2^11 x in fp32
+    np.testing.assert_allclose(sigma.detach().cpu().numpy(), ref_sigma.numpy(), atol=2e-4)
+    # the operators on their own, the ray-mode renderer, gradients to every layer, the image loop
+    rgb2, _ = model.decoder(model.representation(pts.cuda()), model.dir_representation(dirs.cuda()))
+    assert torch.allclose(rgb2, rgb)
+    gen = golden("g6_render")
+    o, d = T(gen["rays_o"]).cuda(), T(gen["rays_d"]).cuda()
+    c, _, _ = render_rays(model, o, d, 2.0, 6.0, 32, True)
+    c.square().mean().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    with torch.no_grad():
+        img = render_image(model, o.view(8, 12, 3), d.view(8, 12, 3), 2.0, 6.0, 32, 40, True)
+    assert img.shape == (8, 12, 3) and bool(torch.isfinite(img).all())
+    with pytest.raises(ValueError):
+        NeuralField({"mode": "part2_nerf", "L_embed": 10, "num_layers": 4, "skip_layer": 9})
 
 
 def test_render_rays_fwd_launch_chain_equals_chunked_kernels(field):
