@@ -3,7 +3,8 @@ import torch.nn as nn
 
 import torch
 
-from .decoders import HashDeformationDecoder, InstantNeRFDecoder, NeRFDecoder, StandardMLP, TimeModulationNetwork
+from .decoders import (DeformationNetwork, HashDeformationDecoder, InstantNeRFDecoder, NeRFDecoder, StandardMLP,
+                       TimeModulationNetwork)
 from .embeddings import FourierRepresentation, HashRepresentation
 
 
@@ -37,6 +38,34 @@ class NeuralField(nn.Module):
         elif self.mode == "part2_instant":
             from .instant import build_instant_field
             build_instant_field(self, config)
+        elif self.mode == "part3":
+            # MLP deformation field + canonical field (reference src/core.py:79-146): Fourier codes and the hash grid in
+            # HIP (the codes differentiable in their input: the loss reaches the deformation through x + delta_x), the
+            # deformation MLP and a canonical decoder of non-compiled width as library GEMMs
+            self.dir_representation = FourierRepresentation(input_dim=3, L=config.get("L_embed_dir", 4), use_encoding=True)
+            self.time_encoder = FourierRepresentation(input_dim=1, L=config.get("L_embed_time", 10), use_encoding=True)
+            self.pos_encoder_for_deform = FourierRepresentation(input_dim=3, L=config.get("L_embed", 10), use_encoding=True)
+            self.deform_net = DeformationNetwork(pos_dim=self.pos_encoder_for_deform.out_dim, time_dim=self.time_encoder.out_dim,
+                                                 hidden_dim=config.get("deform_hidden_dim", 128),
+                                                 num_layers=config.get("deform_num_layers", 4))
+            mlp_kw = dict(hidden_dim=config.get("hidden_dim", 256), num_layers=config.get("num_layers", 8),
+                          skip_layer=config.get("skip_layer", 4), view_dim=config.get("view_dim", 128))
+            if config.get("canonical_type", "nerf") == "instant":
+                self.canonical_repr = HashRepresentation(
+                    n_levels=config.get("n_levels", 16), n_features_per_level=config.get("n_features_per_level", 2),
+                    log2_hashmap_size=config.get("log2_hashmap_size", 19), base_resolution=config.get("base_resolution", 16),
+                    per_level_scale=config.get("per_level_scale", 1.5), bound=config.get("scene_bound", 1.0))
+                self.decoder = InstantNeRFDecoder(pos_dim=self.canonical_repr.out_dim + self.time_encoder.out_dim,
+                                                  dir_dim=self.dir_representation.out_dim, hidden_dim=config.get("hidden_dim", 64))
+            else:
+                self.canonical_repr = FourierRepresentation(input_dim=3, L=config.get("L_embed_canon", 10), use_encoding=True)
+                self.decoder = NeRFDecoder(pos_dim=self.canonical_repr.out_dim + self.time_encoder.out_dim,
+                                           dir_dim=self.dir_representation.out_dim, **mlp_kw)
+            self.direct_time_conditioning = config.get("direct_time_conditioning", False)
+            if self.direct_time_conditioning:
+                self.pos_encoder_direct = FourierRepresentation(input_dim=3, L=config.get("L_embed", 10), use_encoding=True)
+                self.decoder_direct = NeRFDecoder(pos_dim=self.pos_encoder_direct.out_dim + self.time_encoder.out_dim,
+                                                  dir_dim=self.dir_representation.out_dim, **mlp_kw)
         elif self.mode == "part4":
             # dual-hash dynamic field (reference src/core.py:148-225): three deformation hash grids anchored in
             # time, a shared displacement decoder gated by a time-modulation MLP, a canonical hash grid and a
@@ -66,9 +95,7 @@ class NeuralField(nn.Module):
             self.decoder = InstantNeRFDecoder(pos_dim=self.canonical_repr.out_dim + self.time_encoder.out_dim,
                                               dir_dim=self.dir_representation.out_dim, hidden_dim=config.get("hidden_dim", 64))
         else:
-            raise NotImplementedError(
-                f"mode {self.mode!r}: built are part1_fourier, part2_nerf, part2_instant and part4 (dual hash); "
-                "part3 (MLP deformation) is outside the built scope, see DESIGN.md")
+            raise NotImplementedError(f"mode {self.mode!r}: built are part1_fourier, part2_nerf, part2_instant, part3 and part4")
 
     def forward(self, x, d=None, t=None):
         if self.mode == "part1_fourier":
@@ -79,9 +106,34 @@ class NeuralField(nn.Module):
             if self.mode == "part2_nerf":
                 return self.decoder.field(x, d)
             return self._instant_forward(x, d)
+        if self.mode == "part3":
+            return self._part3_forward(x, d, t)
         if self.mode == "part4":
             return self._part4_forward(x, d, t)
         raise NotImplementedError(self.mode)
+
+    def _part3_forward(self, x, d, t):
+        """reference src/core.py:233-281: (rgb, sigma, delta_x); delta_x = 0 under direct time conditioning."""
+        if t is None:
+            raise ValueError("Part 3 requires time input 't'.")
+        if d is None:
+            raise ValueError("part3 requires view directions.")
+        x, d = x.contiguous(), d.contiguous()
+        if self.direct_time_conditioning:
+            h = torch.cat([self.pos_encoder_direct(x), self.time_encoder(t.contiguous())], dim=-1)
+            rgb, sigma = self.decoder_direct(h, self.dir_representation(d))
+            return rgb, sigma, torch.zeros_like(x)
+        x_deform, t_deform = x, t
+        if self.training and self.use_coord_noise:
+            if self.coord_noise_std > 0:
+                x_deform = x + torch.randn_like(x) * self.coord_noise_std
+            if self.time_noise_std > 0:
+                t_deform = torch.clamp(t + torch.randn_like(t) * self.time_noise_std, 0.0, 1.0)
+        feat_t = self.time_encoder(t_deform.contiguous())
+        delta_x = self.deform_net(self.pos_encoder_for_deform(x_deform.contiguous()), feat_t)
+        feat_can = self.canonical_repr((x + delta_x).contiguous())
+        rgb, sigma = self.decoder(torch.cat([feat_can, feat_t], dim=-1), self.dir_representation(d))
+        return rgb, sigma, delta_x
 
     def _part4_forward(self, x, d, t):
         """reference src/core.py:282-352: (rgb, sigma, delta_x).  The four hash encodings (table gradients AND

@@ -40,8 +40,8 @@ class NeRFDecoder(BaseDecoder):
         # layers then run as library GEMMs on the GPU (torch -> hipBLASLt) around the HIP Fourier codes -- slower,
         # same parameters and state-dict keys, fp32 like the reference.
         self.fused = (hidden_dim, num_layers, skip_layer, view_dim) == (256, 8, 4, 128) and ok_dims(pos_dim, 10) and ok_dims(dir_dim, 4)
-        if not ok_dims(pos_dim, 16) or not ok_dims(dir_dim, 16) or not 0 < skip_layer < max(num_layers, 1) + 1 or num_layers < 1:
-            raise ValueError(f"NeRFDecoder: pos {pos_dim} / dir {dir_dim} columns (3 + 6 L expected), {num_layers} layers, skip {skip_layer}")
+        if pos_dim < 1 or dir_dim < 1 or not 0 < skip_layer < max(num_layers, 1) + 1 or num_layers < 1:
+            raise ValueError(f"NeRFDecoder: pos {pos_dim} / dir {dir_dim} columns, {num_layers} layers, skip {skip_layer}")
         self.pos_dim, self.dir_dim = pos_dim, dir_dim
         self.skip_layer = skip_layer
         layers = []
@@ -98,6 +98,8 @@ class NeRFDecoder(BaseDecoder):
                 n_s = z.shape[1]
                 pts = (pts[:, None, :] + dirs[:, None, :] * z[..., None]).reshape(-1, 3)
                 dirs = dirs[:, None, :].expand(-1, n_s, -1).reshape(-1, 3)
+            if (self.pos_dim - 3) % 6 or (self.dir_dim - 3) % 6:
+                raise ValueError("NeRFDecoder.field: the code widths are not 3 + 6 L; encode first and call forward(x_enc, d_enc)")
             code = lambda v, dim: ops.fourier_encode(v.contiguous(), (dim - 3) // 6) if dim > 3 else v
             return self._layers(code(pts, self.pos_dim), code(dirs, self.dir_dim))
         rgb, sigma = ops.decoder(self.flat_parameters(), self.packed_weights(), pts, dirs, z)
@@ -247,11 +249,20 @@ class TimeModulationNetwork(BaseDecoder):
 
 
 class DeformationNetwork(BaseDecoder):
-    """reference src/decoders.py:165-195 (Part 3 MLP deformation field): not part of the built rows."""
+    """reference src/decoders.py:165-195 (Part 3): displacement delta_x [N,3] from the encoded position and time;
+    a plain nn.Linear / ReLU stack (library GEMMs), last layer initialised to near-zero output."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, pos_dim, time_dim, hidden_dim=128, num_layers=4):
         super().__init__()
-        raise NotImplementedError("Part 3 (MLP deformation field) is out of the built scope; Part 4 (dual hash) is built")
+        self.num_layers = num_layers
+        layers = [nn.Linear(pos_dim + time_dim, hidden_dim), nn.ReLU()]
+        for _ in range(num_layers - 2):
+            layers.extend([nn.Linear(hidden_dim, hidden_dim), nn.ReLU()])
+        out = nn.Linear(hidden_dim, 3)
+        nn.init.uniform_(out.weight, -1e-4, 1e-4)
+        nn.init.zeros_(out.bias)
+        layers.append(out)
+        self.net = nn.Sequential(*layers)
 
-    def forward(self, *args):
-        raise NotImplementedError
+    def forward(self, x_feat, t_feat):
+        return self.net(torch.cat([x_feat, t_feat], dim=-1))

@@ -1,4 +1,5 @@
-"""Part 4 training / evaluation loop (mode part4; reference run.py:1562-2331 run_part4): DynamicDataset,
+"""Part 3 / Part 4 training and evaluation loop (modes part3, part4; reference run.py:903-1559 run_part3 and
+run.py:1562-2331 run_part4): DynamicDataset,
 NeuralField('part4'), render_rays with per-ray times, AdamW + cosine LR, occupancy grid refreshed at the three
 time anchors, best-on-validation checkpoints, and the loss terms of the reference's loop
 (``part4_regularisers``: displacement magnitude, total variation on the deformation grids and on the canonical
@@ -70,13 +71,45 @@ def part4_regularisers(model, cfg, step, mean_delta_x, generator=None, probes=No
     return terms
 
 
+def part3_regularisers(model, cfg, step, mean_delta_x, generator=None, probes=None):
+    """The non-photometric loss terms of the reference's Part 3 loop (run.py:1107-1165): displacement magnitude,
+    total variation on a hash-grid canonical field, temporal smoothness (every 2nd step), unsupervised consistency
+    (every 4th step) -- same YAML keys, defaults and compensation factors."""
+    device = mean_delta_x.device
+    zero = torch.zeros((), device=device)
+    bound = float(cfg.get("scene_bound", 1.2))
+    warm = cfg.get("grid_warmup_iters", 256)
+    rand = lambda *shape: torch.rand(*shape, device=device, generator=generator)
+    terms = {"reg": torch.mean(mean_delta_x ** 2) * float(cfg.get("deformation_reg_weight", 1e-4)), "tv": zero, "temporal": zero,
+             "unsup": zero}
+    instant = cfg.get("canonical_type", "nerf") == "instant"
+    if cfg.get("use_tv_loss", True) and instant and hasattr(model, "canonical_repr") and hasattr(model.canonical_repr, "encoding"):
+        terms["tv"] = _total_variation(model.canonical_repr.encoding.params) * float(cfg.get("tv_loss_weight", 1e-6))
+    if getattr(model, "direct_time_conditioning", False):
+        return terms                                       # no deformation field to regularise
+    displacement = lambda x, t: model.deform_net(model.pos_encoder_for_deform(x), model.time_encoder(t))
+    if cfg.get("use_temporal_smooth", True) and step > warm and step % 2 == 0:
+        eps, n = float(cfg.get("temporal_epsilon", 0.02)), int(cfg.get("temporal_n_samples", 256))
+        x = probes["temporal_x"] if probes else (rand(n, 3) * 2 - 1) * bound
+        t = probes["temporal_t"] if probes else rand(n, 1) * (1.0 - eps)
+        feat = model.pos_encoder_for_deform(x)
+        d0, d1 = model.deform_net(feat, model.time_encoder(t)), model.deform_net(feat, model.time_encoder(t + eps))
+        terms["temporal"] = torch.mean((d0 - d1) ** 2) * float(cfg.get("temporal_smooth_weight", 1e-4)) * 2
+    if cfg.get("use_unsupervised_consistency", False) and step > warm and step % 4 == 0:
+        n = min(int(cfg.get("unsup_n_samples", 512)), 512)
+        t = probes["unsup_t"] if probes else rand(n, 1)
+        x = probes["unsup_x"] if probes else (rand(n, 3) * 2 - 1) * bound
+        terms["unsup"] = torch.mean(torch.abs(displacement(x, t).mean(dim=0))) * float(cfg.get("unsup_consistency_weight", 0.001)) * 4
+    return terms
+
+
 def run_dynamic(cfg, args):
     from .core import NeuralField
     from .dataset import DynamicDataset
     from .renderer import DensityGrid, render_rays
     from .utils import compute_psnr, compute_psnr_torch
     if not args.data_dir:
-        raise ValueError("Part 4 requires --data_dir pointing to a D-NeRF dataset root.")
+        raise ValueError("Part 3 / Part 4 require --data_dir pointing to a D-NeRF dataset root.")
     if not torch.cuda.is_available():
         raise RuntimeError("the NeRF hot path runs on a HIP device only (no CPU fallback)")
     device = torch.device("cuda")
@@ -87,7 +120,8 @@ def run_dynamic(cfg, args):
     batch, iters, lr = cfg.get("batch_size", 4096), cfg.get("train_iters", 5000), cfg.get("learning_rate", 0.01)
     chunk = args.render_chunk or cfg.get("chunk", 16384)
     log_every = cfg.get("log_every", 50)
-    log_dir = os.path.join(cfg.get("log_dir", "output/part4"), os.path.basename(args.data_dir.rstrip("/")))
+    part3 = cfg.get("mode") == "part3"
+    log_dir = os.path.join(cfg.get("log_dir", "output/part3" if part3 else "output/part4"), os.path.basename(args.data_dir.rstrip("/")))
     os.makedirs(log_dir, exist_ok=True)
     train_set = DynamicDataset(args.data_dir, "train", downscale, white_bkgd, cfg.get("scene_scale", 1.0)).to(device)
     split = "test" if os.path.exists(os.path.join(args.data_dir, "transforms_test.json")) else "train"
@@ -129,13 +163,22 @@ def run_dynamic(cfg, args):
             target = rgba[:, :3] * rgba[:, 3:4] + bg * (1 - rgba[:, 3:4])
             pred, _, _, extras = render_rays(model, o, d, near, far, n_samples, True, density_grid=grid, times=t, bg_color=bg)
             loss_rgb = torch.nn.functional.mse_loss(pred, target)
-            loss = loss_rgb + sum(part4_regularisers(model, cfg, step, extras["mean_delta_x"]).values())
+            regs = part3_regularisers if part3 else part4_regularisers
+            loss = loss_rgb + sum(regs(model, cfg, step, extras["mean_delta_x"]).values())
             opt.zero_grad()
             loss.backward()
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=float(cfg.get("max_grad_norm", 1.0)))
             opt.step()
             sched.step()
-            if grid is not None and step < iters * stop:
+            if grid is not None and part3:
+                # run.py:1191-1222: every 16 / 64 / 256 steps the union over 16 (later 8) times across the sequence, no decay
+                interval = 16 if step < iters * 0.1 else (64 if step < iters * 0.5 else 256)
+                if grid.should_update(step, interval, warm):
+                    model.eval()
+                    for t_val in torch.linspace(float(train_set.times.min()), float(train_set.times.max()), 16 if step < 1000 else 8):
+                        active = grid.update(model, device=device, time=t_val.view(1, 1), decay=1.0)
+                    model.train()
+            elif grid is not None and step < iters * stop:
                 interval = 32 if step < iters * 0.1 else (128 if step < iters * 0.5 else 512)
                 if grid.should_update(step, interval, warm):
                     model.eval()

@@ -23,13 +23,36 @@ class FourierRepresentation(BaseRepresentation):
     def forward(self, x):
         if not self.use_encoding or self.L == 0:
             return x
-        if x.requires_grad:
-            raise NotImplementedError("gradients w.r.t. encoded coordinates are not part of the static path")
+        if x.requires_grad and torch.is_grad_enabled():
+            # dynamic fields encode x + delta_x (reference src/core.py:268-271): the code is differentiable
+            return _FourierEncode.apply(x.contiguous(), self.L)
         return ops.fourier_encode(x, self.L)
 
     @property
     def out_dim(self):
         return self._out_dim
+
+
+class _FourierEncode(torch.autograd.Function):
+    """HIP Fourier code with its input gradient: d sin(a x) = a cos(a x) dx, d cos(a x) = -a sin(a x) dx with
+    a = 2^k pi, evaluated from the code itself (which already holds every sin and cos)."""
+
+    @staticmethod
+    def forward(ctx, x, n_freq):
+        out = ops.fourier_encode(x, n_freq)
+        ctx.save_for_backward(out)
+        ctx.n_freq = n_freq
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        dim, L = out.shape[1] // (1 + 2 * ctx.n_freq), ctx.n_freq
+        g, out = g.contiguous(), out
+        band = (2.0 ** torch.arange(L, device=g.device, dtype=g.dtype) * torch.pi).view(1, L, 1)
+        sc, gsc = out[:, dim:].view(-1, L, 2, dim), g[:, dim:].view(-1, L, 2, dim)       # [n, band, (sin, cos), coord]
+        dx = g[:, :dim] + ((gsc[:, :, 0] * sc[:, :, 1] - gsc[:, :, 1] * sc[:, :, 0]) * band).sum(dim=1)
+        return dx, None
 
 
 class ParamHolder(nn.Module):

@@ -25,8 +25,8 @@ class DensityGrid(nn.Module):
         static fields overwrite, dynamic ones keep max(grid*decay, current) (renderer.py:35-132)."""
         res = self.resolution
         mode = getattr(model, "mode", "unknown")
-        if mode == "part3":
-            raise NotImplementedError("Part 3 (MLP deformation field) is outside the built scope")
+        if mode == "part3" and time is None:
+            raise ValueError("Part 3 density grid update requires a time parameter")
         pts = ops.grid_lattice(self.bound, res, self.grid.device)
         batch = 2 ** 18
 
@@ -45,6 +45,11 @@ class DensityGrid(nn.Module):
             # density at the three time anchors 0, 0.5, 1 (`time` is ignored), element-wise maximum, then the
             # running maximum against the decayed history (reference src/renderer.py:65-86, 122-125)
             sig = torch.stack([query(a) for a in (0.0, 0.5, 1.0)], 0).max(dim=0)[0]
+            self.binary_grid, ratio = ops.grid_threshold(sig.view(res, res, res).contiguous(), self.threshold, prev=self.grid, decay=decay)
+            return ratio
+        if mode == "part3":
+            # density at the given time, running maximum against the decayed history (src/renderer.py:87-101, 122-125)
+            sig = query(float(torch.as_tensor(time).reshape(-1)[0]))
             self.binary_grid, ratio = ops.grid_threshold(sig.view(res, res, res).contiguous(), self.threshold, prev=self.grid, decay=decay)
             return ratio
         self.grid = query().view(res, res, res)
@@ -73,14 +78,12 @@ def volume_render(rgb, sigma, z_vals, rays_d, bg_color=None):
 
 def render_rays(model, rays_o, rays_d, near, far, n_samples, perturb, density_grid=None, times=None,
                 white_bkgd=True, bg_color=None):
-    """reference src/renderer.py:240-384: 3-tuple (rgb, depth, acc) for static fields; for the dynamic (part4)
-    field a 4-tuple with ``extras['mean_delta_x']`` = sum_s w_s delta_x_s (missing ``times`` mean t = 0)."""
+    """reference src/renderer.py:240-384: 3-tuple (rgb, depth, acc) for static fields; for the dynamic (part3 / part4)
+    fields a 4-tuple with ``extras['mean_delta_x']`` = sum_s w_s delta_x_s (missing ``times`` mean t = 0)."""
     device = rays_o.device
     n_rays = rays_o.shape[0]
     mode = getattr(model, "mode", "unknown")
-    if mode == "part3":
-        raise NotImplementedError("Part 3 (MLP deformation field) is outside the built scope")
-    if mode == "part4":
+    if mode in ("part3", "part4"):
         return _render_rays_dynamic(model, rays_o, rays_d, near, far, n_samples, perturb, density_grid, times, white_bkgd, bg_color)
     if bg_color is None:
         bg_color = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)

@@ -175,10 +175,10 @@ def main():
         run_part2(cfg, args)
     elif mode == "part2_instant":
         run_part2_instant(cfg, args)
-    elif mode == "part4":
-        run_part4(cfg, args)
+    elif mode in ("part3", "part4"):
+        run_part4(cfg, args)           # one loop for both dynamic modes (project-nerf_amd/dynamic.py)
     else:
-        raise ValueError(f"mode {mode!r} is not built (part1_fourier, part2_nerf, part2_instant, part4 are); see DESIGN.md")
+        raise ValueError(f"mode {mode!r} is not built (part1_fourier, part2_nerf, part2_instant, part3, part4 are); see DESIGN.md")
 
 
 if __name__ == "__main__":

@@ -427,6 +427,84 @@ def g14_part4():
     del sys.modules["tinycudann"]
 
 
+PART3_CFGS = {
+    "nerf": {"mode": "part3", "canonical_type": "nerf", "L_embed": 6, "L_embed_canon": 8, "L_embed_dir": 4, "L_embed_time": 6,
+             "hidden_dim": 64, "num_layers": 5, "skip_layer": 3, "view_dim": 32, "deform_hidden_dim": 48, "deform_num_layers": 3},
+    "dtc": {"mode": "part3", "canonical_type": "nerf", "direct_time_conditioning": True, "L_embed": 6, "L_embed_canon": 8,
+            "L_embed_dir": 4, "L_embed_time": 6, "hidden_dim": 64, "num_layers": 5, "skip_layer": 3, "view_dim": 32,
+            "deform_hidden_dim": 48, "deform_num_layers": 3},
+    "instant": {"mode": "part3", "canonical_type": "instant", "L_embed": 6, "L_embed_dir": 4, "L_embed_time": 10, "hidden_dim": 64,
+                "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 11, "base_resolution": 16, "per_level_scale": 1.5,
+                "scene_bound": 1.5, "deform_hidden_dim": 48, "deform_num_layers": 3},
+}
+
+
+def g15_part3():
+    """The reference's Part 3 field (src/core.py:79-146, 233-281): MLP deformation + canonical NeRF MLP, direct time
+    conditioning, and the hash-grid canonical variant around the stand-in tinycudann -- forward (rgb, sigma, delta_x),
+    gradients of a weighted sum (the deformation MLP is reached only through d code / d x of the canonical encoding),
+    render_rays with times and DensityGrid.update(time=...) with the running maximum."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tinycudann", os.path.join(HERE, "tinycudann_shim.py"))
+    shim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shim)
+    sys.modules["tinycudann"] = shim
+    out = {}
+    gen = torch.Generator().manual_seed(53)
+    n = 300
+    pts = (torch.rand(n, 3, generator=gen) - 0.5) * 2.6
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    times = torch.rand(n, 1, generator=gen)
+    w_rgb, w_dx = torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen)
+    o, d = synth_rays(64, gen)
+    ray_t = torch.rand(64, 1, generator=gen)
+    out.update(pts=pts, dirs=dirs, times=times, w_rgb=w_rgb, w_dx=w_dx, rays_o=o, rays_d=d, ray_t=ray_t)
+    for tag, cfg in PART3_CFGS.items():
+        torch.manual_seed(15)
+        model = NeuralField(dict(cfg))
+        with torch.no_grad():
+            model.deform_net.net[-1].weight.mul_(3000.0)                  # visible displacements (init is 1e-4)
+            model.deform_net.net[-1].bias.add_(0.02)
+            if tag == "instant":
+                t = model.canonical_repr.encoding.params
+                t.copy_(part4_table(t.numel(), 0.5))
+                model.decoder.sigma_net.params[:64 * 64].mul_(1.5)
+                model.decoder.sigma_net.params[64 * 64:64 * 64 + 64].mul_(24.0)
+            else:
+                dec = model.decoder_direct if tag == "dtc" else model.decoder
+                dec.sigma_layer.bias.add_(0.3)
+                dec.sigma_layer.weight.mul_(4.0)
+        model.eval()
+        sd = {k: v.clone() for k, v in model.state_dict().items() if "encoding.params" not in k and "freq_bands" not in k}
+        rgb, sigma, delta = model(pts, dirs, t=times)
+        model.zero_grad()
+        ((rgb * w_rgb).sum() + sigma.sum() + (delta * w_dx).sum()).backward()
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            if "encoding.params" in k:
+                out[f"{tag}:gn:{k}"] = p.grad.norm()
+            else:
+                out[f"{tag}:g:{k}"] = p.grad.clone()
+        grid = DensityGrid(resolution=64, bound=1.5, threshold=0.01)
+        ax = torch.linspace(-1.5, 1.5, 64)
+        gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+        grid.binary_grid = (gx ** 2 + gy ** 2 + gz ** 2) < 1.1 ** 2
+        with torch.no_grad():
+            c, dep, acc, extras = render_rays(model, o, d, 2.0, 6.0, 40, False, density_grid=grid, times=ray_t,
+                                              bg_color=torch.tensor([0.2, 0.4, 0.6]))
+            dg = DensityGrid(resolution=20, bound=1.5, threshold=0.05)
+            r1 = dg.update(model, device="cpu", time=torch.tensor([[0.25]]), decay=0.9)
+            r2 = dg.update(model, device="cpu", time=torch.tensor([[0.75]]), decay=0.9)
+        out.update({f"{tag}:rgb": rgb, f"{tag}:sigma": sigma, f"{tag}:delta": delta, f"{tag}:r_rgb": c, f"{tag}:r_depth": dep,
+                    f"{tag}:r_acc": acc, f"{tag}:r_mean_delta": extras["mean_delta_x"], f"{tag}:grid": dg.grid,
+                    f"{tag}:binary": dg.binary_grid, f"{tag}:ratios": np.array([r1, r2]),
+                    f"{tag}:n_params": np.int64(sum(p.numel() for p in model.parameters()))})
+        out.update({f"{tag}:w:{k}": v for k, v in sd.items()})
+    save("g15_part3", **out)
+    del sys.modules["tinycudann"]
+
+
 def g11_psnr():
     mse = np.array([1e-4, 3.3e-3, 0.02, 0.25])
     save("g11_psnr", mse=mse, psnr=np.array([compute_psnr(m) for m in mse]))
@@ -454,3 +532,4 @@ if __name__ == "__main__":
     g12_part1()
     g13_instant_glue()
     g14_part4()
+    g15_part3()

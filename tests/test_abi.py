@@ -107,8 +107,7 @@ def test_reference_import_lines_resolve_against_this_package():
     from src.abstract import BaseDecoder, BaseRepresentation
     assert issubclass(HashRepresentation, BaseRepresentation) and issubclass(InstantNeRFDecoder, BaseDecoder)
     assert issubclass(HashDeformationDecoder, BaseDecoder) and issubclass(TimeModulationNetwork, BaseDecoder)
-    with pytest.raises(NotImplementedError):
-        DeformationNetwork(63, 21)              # Part 3's MLP deformation field: named, not built
+    assert issubclass(DeformationNetwork, BaseDecoder) and DeformationNetwork(63, 21).net[-1].out_features == 3   # Part 3
 
 
 def comm_declared_functions():
