@@ -237,18 +237,18 @@ hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0
 //   1 count   : corners per (level, slice), LDS histogram per workgroup, one global add per bin and workgroup
 //   2 plan    : exclusive scan -> bin starts / write cursors; work items = (bin, <= kChunk records); a bin cut
 //               into several items (dense coarse levels: thousands of samples per cell) flushes with atomics
-//   3 scatter : records {slot in slice, w g0, w g1} (12 B) to cursor positions, ranges reserved per workgroup
+//   3 scatter : records {slot in slice, w g0, w g1} packed into 8 B to cursor positions, ranges reserved per workgroup
 //   4 reduce  : one workgroup per item sums its records into the LDS slice, flush of the non-zero entries
 // The LDS sums are 64-bit FIXED POINT (ds_add_u64): ds_add_f32 retires one lane every three clocks whatever the
 // addresses (tools/probe/lds_atomic_rate.hip: 0.33 lanes/clk/CU against 4.7 for ds_add_u64, 7.8 for ds_add_u32).
 // The scale is a power of two taken from the largest |d_feat| of the call (found by the count pass), so that a
-// term keeps 38 bits below that maximum -- finer than the fp32 sum it replaces -- and 2^25 terms cannot overflow;
+// term keeps 25 bits below that maximum (the packed record's width) and 2^37 terms cannot overflow;
 // integer sums also make the result independent of the order of the records.
 constexpr unsigned kSliceLog2 = 12, kSlice = 1u << kSliceLog2;   // 4096 entries x 2 features x 8 B = 64 KiB of LDS
 constexpr unsigned kChunk = 32768;             // records per work item
 constexpr unsigned kMaxSlices = 4096;          // per level (LDS histogram); larger tables use the atomic form
 constexpr int kMaxBins = 65536;
-constexpr int kFixedBits = 38;
+constexpr int kFixedBits = 25;                 // magnitude bits of a term (26-bit signed field of the packed record)
 
 struct BinPlan {
   int first, count;                            // levels [first, first + count)
@@ -261,10 +261,20 @@ struct BinHeader {                             // start of the workspace
 struct BinItem {
   unsigned entry0, begin, end, atomic;         // first table entry of the slice, record range, flush mode
 };
-struct BinRecord {
-  unsigned slot;
-  float g0, g1;
-};
+// one corner contribution, 8 bytes: bits [0,12) slot in the slice, [12,38) and [38,64) the two feature gradients as
+// 26-bit signed fixed point at the call's scale (fixed_shift: the largest |d_feat| of the call keeps 25 bits, i.e. a
+// resolution of 3e-8 of it -- finer than one fp32 ulp of that largest term; tinycudann accumulates these in fp16)
+typedef unsigned long long BinRecord;
+__device__ __forceinline__ BinRecord pack_record(unsigned slot, float g0, float g1, float scale) {
+  const long long lim = (1ll << kFixedBits) - 1;
+  long long a = __float2ll_rn(g0 * scale), b = __float2ll_rn(g1 * scale);
+  a = a > lim ? lim : (a < -lim ? -lim : a);
+  b = b > lim ? lim : (b < -lim ? -lim : b);
+  return (BinRecord)slot | (((BinRecord)a & 0x3ffffffull) << 12) | ((BinRecord)b << 38);
+}
+__device__ __forceinline__ unsigned record_slot(BinRecord r) { return (unsigned)r & (kSlice - 1); }
+__device__ __forceinline__ long long record_g0(BinRecord r) { return (long long)(r << 26) >> 38; }   // sign-extended bits [12,38)
+__device__ __forceinline__ long long record_g1(BinRecord r) { return (long long)r >> 38; }
 
 struct BinWorkspace {
   BinHeader* header;
@@ -393,7 +403,7 @@ constexpr unsigned kStagedBins = 256;
 template <bool STAGED>
 __global__ void __launch_bounds__(512)
 hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
-                        unsigned* __restrict__ cursor, BinRecord* __restrict__ records) {
+                        unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header) {
   constexpr unsigned kBins = STAGED ? kStagedBins : kMaxSlices;
   __shared__ unsigned cnt[kBins], base[kBins];
   __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
@@ -402,6 +412,7 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
   const int lvl = plan.first + blockIdx.y;
   const unsigned bins = plan.bin0[blockIdx.y + 1] - plan.bin0[blockIdx.y], offset = L.offset[lvl];
   if (STAGED != (bins <= kStagedBins)) return;                 // the other instantiation owns this level
+  const float scale = __uint_as_float((unsigned)(127 + fixed_shift(header->amax_bits)) << 23);
   for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) cnt[i] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -445,11 +456,7 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const unsigned local = c.idx[k] - offset, b = local >> kSliceLog2, pos = start[b] + slot[k];
-          BinRecord r;
-          r.slot = local & (kSlice - 1);
-          r.g0 = c.w[k] * g0;
-          r.g1 = c.w[k] * g1;
-          stage[pos] = r;
+          stage[pos] = pack_record(local & (kSlice - 1), c.w[k] * g0, c.w[k] * g1, scale);
           dest[pos] = base[b] + slot[k];
         }
       }
@@ -468,11 +475,7 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const unsigned local = c.idx[k] - offset;
-          BinRecord r;
-          r.slot = local & (kSlice - 1);
-          r.g0 = c.w[k] * g0;
-          r.g1 = c.w[k] * g1;
-          records[base[local >> kSliceLog2] + slot[k]] = r;
+          records[base[local >> kSliceLog2] + slot[k]] = pack_record(local & (kSlice - 1), c.w[k] * g0, c.w[k] * g1, scale);
         }
       }
       __syncthreads();                          // base[] is rewritten by the next round
@@ -485,7 +488,7 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
                        float* __restrict__ d_table, unsigned table_entries) {
   __shared__ unsigned long long acc[2 * kSlice];            // 64 KiB of 64-bit fixed-point sums
   const int shift = fixed_shift(header->amax_bits);
-  const float scale = __uint_as_float((unsigned)(127 + shift) << 23), inv_scale = __uint_as_float((unsigned)(127 - shift) << 23);
+  const float inv_scale = __uint_as_float((unsigned)(127 - shift) << 23);
   for (unsigned item_id = blockIdx.x; item_id < header->n_items; item_id += gridDim.x) {
     const BinItem item = items[item_id];
     for (unsigned i = threadIdx.x; i < 2 * kSlice; i += blockDim.x) acc[i] = 0ull;
@@ -502,8 +505,8 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         if (r0 + u * blockDim.x < item.end) {
-          atomicAdd(&acc[2 * rec[u].slot + 0], (unsigned long long)__float2ll_rn(rec[u].g0 * scale));
-          atomicAdd(&acc[2 * rec[u].slot + 1], (unsigned long long)__float2ll_rn(rec[u].g1 * scale));
+          atomicAdd(&acc[2 * record_slot(rec[u]) + 0], (unsigned long long)record_g0(rec[u]));
+          atomicAdd(&acc[2 * record_slot(rec[u]) + 1], (unsigned long long)record_g1(rec[u]));
         }
       }
     }
@@ -649,10 +652,10 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
       for (int i = 0; i < plan.count; ++i) (plan.bin0[i + 1] - plan.bin0[i] <= kStagedBins ? any_staged : any_direct) = true;
       if (any_staged)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records);
+                           plan, d_feat, w.cursor, w.records, w.header);
       if (any_direct)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records);
+                           plan, d_feat, w.cursor, w.records, w.header);
       size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
       if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
       hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,
