@@ -281,6 +281,7 @@ struct BinWorkspace {
   unsigned* count;                             // [bins]
   unsigned* cursor;                            // [bins]
   BinItem* items;                              // [max_items]
+  float2* grad_lm;                             // [levels][n] level-major copy of d_feat (the count pass writes it)
   BinRecord* records;
 };
 
@@ -293,13 +294,14 @@ static BinWorkspace carve(void* base, int64_t n, int n_levels) {
   w.count = reinterpret_cast<unsigned*>(p);                   p += sizeof(unsigned) * kMaxBins;
   w.cursor = reinterpret_cast<unsigned*>(p);                  p += sizeof(unsigned) * kMaxBins;
   w.items = reinterpret_cast<BinItem*>(p);                    p += (sizeof(BinItem) * bin_max_items(n, n_levels) + 255) / 256 * 256;
+  w.grad_lm = reinterpret_cast<float2*>(p);                   p += (sizeof(float2) * (size_t)n * (size_t)n_levels + 255) / 256 * 256;
   w.records = reinterpret_cast<BinRecord*>(p);
   return w;
 }
 
 static size_t bin_workspace_bytes(int64_t n, int n_levels) {
   return 256 + 2 * sizeof(unsigned) * kMaxBins + (sizeof(BinItem) * bin_max_items(n, n_levels) + 255) / 256 * 256 +
-         sizeof(BinRecord) * (size_t)n * 8 * (size_t)n_levels;
+         (sizeof(float2) * (size_t)n * (size_t)n_levels + 255) / 256 * 256 + sizeof(BinRecord) * (size_t)n * 8 * (size_t)n_levels;
 }
 
 __device__ __forceinline__ bool point_gradient(const float* __restrict__ d_feat, int64_t p, int n_levels, int lvl, float& g0, float& g1) {
@@ -336,6 +338,45 @@ hash_bin_count_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, Bi
     atomicMax(&header->amax_bits, wg_amax);
   for (unsigned i = threadIdx.x; i < bins; i += blockDim.x)
     if (hist[i] != 0) atomicAdd(count + plan.bin0[blockIdx.y] + i, hist[i]);
+}
+
+// The same count with the POINT on the lane: a lane reads its point and its whole 8 L-byte row of d_feat once
+// (the level-major form reads 8 bytes of every 128-byte row per level: a quarter of each sector fetched is used),
+// walks the levels, and leaves a level-major copy of the gradients for the scatter pass.  Needs the histograms of
+// all levels in LDS at once: used when the call has at most kPmBins bins (2048 for L16 / T2^19).
+constexpr unsigned kPmBins = 8192;
+__global__ void __launch_bounds__(256)
+hash_bin_count_pm_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
+                         unsigned* __restrict__ count, BinHeader* __restrict__ header, float2* __restrict__ grad_lm) {
+  __shared__ unsigned hist[kPmBins];
+  __shared__ unsigned wg_amax;
+  const unsigned n_bins = plan.bin0[plan.count];
+  for (unsigned i = threadIdx.x; i < n_bins; i += blockDim.x) hist[i] = 0;
+  if (threadIdx.x == 0) wg_amax = 0;
+  __syncthreads();
+  float amax = 0.0f;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const float px = pts[p * 3 + 0], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+    const float2* row = reinterpret_cast<const float2*>(d_feat + p * (2 * L.n_levels)) + plan.first;
+    for (int li = 0; li < plan.count; ++li) {
+      const float2 g = row[li];
+      grad_lm[(int64_t)li * n + p] = g;
+      if (g.x == 0.0f && g.y == 0.0f) continue;
+      amax = fmaxf(amax, fmaxf(fabsf(g.x), fabsf(g.y)));
+      const int lvl = plan.first + li;
+      const Corner c = corners_of(L, lvl, px, py, pz);
+      const unsigned offset = L.offset[lvl], b0 = plan.bin0[li];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(&hist[b0 + ((c.idx[k] - offset) >> kSliceLog2)], 1u);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if ((threadIdx.x & 63) == 0 && amax > 0.0f && amax <= 3.0e38f) atomicMax(&wg_amax, __float_as_uint(amax));
+  __syncthreads();
+  if (threadIdx.x == 0 && wg_amax > __hip_atomic_load(&header->amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(&header->amax_bits, wg_amax);
+  for (unsigned i = threadIdx.x; i < n_bins; i += blockDim.x)
+    if (hist[i] != 0) atomicAdd(count + i, hist[i]);
 }
 
 // 2^s with |v| 2^s < 2^kFixedBits for every |v| <= amax; s clamped so that both 2^s and 2^-s are normal fp32
@@ -403,7 +444,8 @@ constexpr unsigned kStagedBins = 256;
 template <bool STAGED>
 __global__ void __launch_bounds__(512)
 hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
-                        unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header) {
+                        unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header,
+                        const float2* __restrict__ grad_lm) {
   constexpr unsigned kBins = STAGED ? kStagedBins : kMaxSlices;
   __shared__ unsigned cnt[kBins], base[kBins];
   __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
@@ -419,7 +461,15 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
   for (int64_t p0 = blockIdx.x * (int64_t)blockDim.x; p0 < n; p0 += stride) {     // uniform trip count: barriers inside
     const int64_t p = p0 + threadIdx.x;
     float g0 = 0.0f, g1 = 0.0f;
-    const bool live = p < n && point_gradient(d_feat, p, L.n_levels, lvl, g0, g1);
+    bool live = false;
+    if (p < n) {
+      if (grad_lm != nullptr) {                 // coalesced: the count pass left the gradients level-major
+        const float2 g = grad_lm[(int64_t)blockIdx.y * n + p];
+        g0 = g.x;
+        g1 = g.y;
+        live = g0 != 0.0f || g1 != 0.0f;
+      } else live = point_gradient(d_feat, p, L.n_levels, lvl, g0, g1);
+    }
     Corner c;
     unsigned slot[8];
     if (live) {
@@ -645,17 +695,25 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
         return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws: memset failed");
       int64_t bx = (n + 511) / 512;
       const int64_t bx_count = bx > 256 ? 256 : bx, bx_scatter = bx > 128 ? 128 : bx;
-      hipLaunchKernelGGL(hash_bin_count_kernel, dim3((int)bx_count, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan, d_feat,
-                         w.count, w.header);
+      const bool point_major = n_bins <= kPmBins;
+      if (point_major) {
+        int64_t bpm = (n + 255) / 256;
+        if (bpm > 1024) bpm = 1024;
+        hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm), dim3(256), 0, as_stream(stream), pts, n, L, plan, d_feat, w.count,
+                           w.header, w.grad_lm);
+      } else
+        hipLaunchKernelGGL(hash_bin_count_kernel, dim3((int)bx_count, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan, d_feat,
+                           w.count, w.header);
+      const float2* grad_lm = point_major ? w.grad_lm : nullptr;
       hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header);
       bool any_staged = false, any_direct = false;
       for (int i = 0; i < plan.count; ++i) (plan.bin0[i + 1] - plan.bin0[i] <= kStagedBins ? any_staged : any_direct) = true;
       if (any_staged)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm);
       if (any_direct)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm);
       size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
       if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
       hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,
