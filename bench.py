@@ -190,7 +190,7 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
                      "note": "table gathers from the fp16 copy of the table (mostly L2 / Infinity Cache hits: 26 MB re-read by every batch)"},
         "hash_bwd": {"bound": "hbm", "kernel": "hash_bin_count + _plan + _scatter + _reduce kernels",
                      "achieved": (n * L * 8 * 8 + n * (12 + 2 * L * 4)) / k["hash_bwd"] * 1e-6,
-                     "note": "binned scatter: 12-byte corner records written once and read once (24 B per corner against the 8 B "
+                     "note": "binned scatter: 8-byte corner records written once and read once (16 B per corner against the 8 B "
                              "counted here), slice sums in LDS (64-bit fixed point), plain read-modify-write of the table"},
         "tv_clip_adamw(table)": {"bound": "hbm", "kernel": "tv_normsq_kernel + adamw_clip_kernel",
                                  "achieved": n_tab * 4 * 9 / k["tv_clip_adamw(table)"] * 1e-6},

@@ -291,7 +291,7 @@ int nerf_hash_encode_bwd_levels(const float* pts, int64_t n, int n_levels, const
                          nerf_stream_t stream);
 /* the same with a workspace (nerf_hash_encode_bwd_workspace_bytes(n, n_levels), 256-B aligned; NULL = the
  * atomic form above): the levels whose table exceeds the LDS pass are scattered as a partial SORT --
- * contributions binned by 8192-entry table slice (12-byte records in the workspace), each slice summed in LDS
+ * contributions binned by 4096-entry table slice (8-byte records in the workspace), each slice summed in LDS
  * by the workgroup that owns it and added to d_table with plain coalesced read-modify-writes.  No global
  * float atomics on the hashed levels (they retire per line request, ~20 G/s, wherever they land).  d_table
  * must not be updated by another stream during the call.  Same sums as the atomic form up to fp32 order. */

@@ -372,8 +372,8 @@ class InstantNgpEngine:
         return loss
 
     def _hash_bwd_workspace(self, n: int) -> Tensor:
-        """Workspace of the binned hash-gradient scatter, grown to the largest point count seen (12 B per corner
-        record: 0.3 GB for the steady-state 200 k points, 3 GB for an unpruned 16384 x 128 batch)."""
+        """Workspace of the binned hash-gradient scatter, grown to the largest point count seen (8 B per corner
+        record + 8 B per point and level: 0.23 GB for the steady-state 200 k points, 2.3 GB for an unpruned 16384 x 128 batch)."""
         need = ops.hash_encode_bwd_workspace_bytes(n, self.levels.n_levels)
         if self._hash_ws is None or self._hash_ws.numel() < need:
             self._hash_ws = None                                  # release before growing
