@@ -23,6 +23,9 @@ KEEP = {"pack_kernel", "pack16_kernel", "sample_rays_kernel", "sample_pdf_kernel
 
 
 def short(name):
+    m = re.search(r"nerf::(\w+)", name)
+    if m and m.group(1) == "hash_fwd_kernel":          # template argument is a vector type: nested brackets
+        return "hash_fwd_kernel<fp16 table>" if "_Float16" in name else "hash_fwd_kernel<fp32 table>"
     m = re.search(r"nerf::(\w+(?:<[^>]*>)?)", name)
     return m.group(1) if m else name.split("(")[0]
 
