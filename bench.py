@@ -446,7 +446,7 @@ def main():
         out["kernels_in_step"] = {p: {"ms": v} for p, v in in_step.items()}
         out["kernels_in_step_note"] = ("HIP events on the launch stream between the phases of the timed step; "
                                        "fwd = mlp_fwd_stream_kernel<true>, loss = composite_mse_bwd_kernel, dgrad = mlp_bwd_stream_kernel, "
-                                       "wgrad = memset + mlp_wgrad_kernel, batch_sampling = train_batch_kernel (pixel draws, rays, targets, jittered depths)")
+                                       "wgrad = memset + mlp_wgrad_kernel + wgrad_reduce_kernel, batch_sampling = train_batch_kernel (pixel draws, rays, targets, jittered depths)")
         # ---- the same kernels launched back to back on their own (warm caches) ----
         o, d, target = ds.sample_batch(R, eng.bg)
         u = torch.rand(R, S, device=device)
