@@ -526,3 +526,19 @@ def test_fp16_shadow_table_forward_and_bookkeeping(ops):
     fp32 = InstantNgpEngine(dict(cfg, half_table=False), seed=1)
     assert fp32.table_h is None
     fp32.train_step(o, d, torch.rand(256, 3).cuda(), 64)
+
+
+@pytest.mark.parametrize("n,n_levels,log2_t", [(1, 1, 10), (7, 3, 12), (513, 2, 19), (4097, 16, 10)])
+def test_hash_backward_binned_form_small_and_odd_shapes(ops, n, n_levels, log2_t):
+    """Edge shapes of the workspace form: one point, one level, tables smaller than one slice, a batch that is not a
+    multiple of any block size; against the atomic form."""
+    t = ops.HashLevelTable(n_levels, log2_t, 16, 1.5)
+    gen = torch.Generator().manual_seed(n)
+    pts = ((torch.rand(n, 3, generator=gen) - 0.5) * 3.1).cuda()
+    d_feat = torch.randn(n, 2 * n_levels, generator=gen).cuda()
+    ref = torch.zeros(t.entries, 2, device="cuda")
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, ref)
+    out = torch.zeros_like(ref)
+    ws = torch.empty(ops.hash_encode_bwd_workspace_bytes(n, n_levels), dtype=torch.uint8, device="cuda")
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, out, workspace=ws)
+    assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12
