@@ -544,7 +544,8 @@ def test_hash_backward_binned_form_small_and_odd_shapes(ops, n, n_levels, log2_t
     assert float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-12
 
 
-def test_run_py_cli_part2_instant_trains_and_evaluates(tmp_path):
+@pytest.mark.parametrize("engine", [True, False])
+def test_run_py_cli_part2_instant_trains_and_evaluates(tmp_path, engine):
     """`python run.py --config part2_instant.yaml --data_dir <blender scene>`: the reference's entry point for the
     hash-grid field through NeuralField + torch.optim (the drop-in path: autograd Functions, binned hash backward with a
     scratch workspace, occupancy grid updates, checkpoint with the reference's keys)."""
@@ -554,7 +555,7 @@ def test_run_py_cli_part2_instant_trains_and_evaluates(tmp_path):
     root = write_synthetic_scene(str(tmp_path / "scene"), n_train=6, n_test=1, size=32)
     cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
     cfg.update(train_iters=40, batch_size=1024, log_every=10, save_every=0, val_every=40, downscale=1, n_samples=48, render_n_samples=48,
-               grid_resolution=32, grid_warmup_iters=16, log2_hashmap_size=14, log_dir=str(tmp_path / "out"))
+               grid_resolution=32, grid_warmup_iters=16, log2_hashmap_size=14, log_dir=str(tmp_path / "out"), engine=engine)
     cfg_path = tmp_path / "part2_instant.yaml"
     cfg_path.write_text(yaml.safe_dump(cfg))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "run.py"), "--config", str(cfg_path), "--data_dir", root, "--render_n", "1"],
@@ -563,5 +564,8 @@ def test_run_py_cli_part2_instant_trains_and_evaluates(tmp_path):
     assert "Test PSNR" in r.stdout
     saved = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path / "out") for f in fs if f.endswith(".pth")]
     assert saved, "no checkpoint written"
-    sd = torch.load(saved[0], map_location="cpu")["model_state_dict"]
+    ckpt = torch.load(saved[0], map_location="cpu")
+    sd = ckpt["model_state_dict"]
     assert {"representation.encoding.params", "decoder.sigma_net.params", "decoder.color_net.params"} <= set(sd)
+    assert float(sd["representation.encoding.params"].abs().max()) > 1.5e-4       # trained away from the +-1e-4 initialisation
+    assert "density_grid" in ckpt and ckpt["density_grid"]["binary_grid"].shape == (32, 32, 32)

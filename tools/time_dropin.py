@@ -29,3 +29,38 @@ for _ in range(20): estep()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(200): estep()
 torch.cuda.synchronize(); print(f"engine (flat parameters, fused Adam + repack):   {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step")
+
+# ---- Instant-NGP: module path (NeuralField + DensityGrid + torch.optim.AdamW + torch TV / clipping) against the engine
+import yaml
+from src.renderer import DensityGrid
+from project_nerf_amd.engine import InstantNgpEngine
+cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "configs", "part2_instant.yaml.example")))
+model = NeuralField(cfg).cuda()
+grid = DensityGrid(128, 1.5, 0.12).cuda()
+ax = torch.linspace(-1.5, 1.5, 128)
+gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+grid.binary_grid = ((gx ** 2 + gy ** 2 + gz ** 2) < 0.75 ** 2).cuda()          # ~13 % of the volume active
+opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=1e-5)
+def istep():
+    o, d, rgba = ds.sample_random_rays(16384, "cuda")
+    target = rgba[:, :3] * rgba[:, 3:4] + bg * (1 - rgba[:, 3:4])
+    pred, _, _ = render_rays(model, o, d, 2.0, 6.0, 128, True, density_grid=grid, bg_color=bg)
+    p = model.representation.encoding.params
+    loss = torch.nn.functional.mse_loss(pred, target) + torch.mean(torch.abs(p[1:] - p[:-1])) * 1e-6
+    opt.zero_grad(); loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.representation.parameters(), max_norm=1.0)
+    torch.nn.utils.clip_grad_norm_(model.decoder.parameters(), max_norm=1.0)
+    opt.step()
+for _ in range(10): istep()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50): istep()
+torch.cuda.synchronize(); print(f"Instant, module path (NeuralField + torch.optim.AdamW): {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms/step")
+eng = InstantNgpEngine(cfg, seed=0)
+eng.binary_grid.copy_(grid.binary_grid)
+def iestep():
+    o, d, target = ds.sample_batch(16384, eng.bg)
+    eng.train_step(o, d, target, 128)
+for _ in range(10): iestep()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50): iestep()
+torch.cuda.synchronize(); print(f"Instant, engine:                                        {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms/step")
