@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const 
 using namespace nerf;
 
 int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work, const BwdLayout& bl,
-                      int64_t n, float* grads, int part, hipStream_t stream);   // mlp_wgrad.hip
+                      int64_t n, float* grads, int part, hipStream_t stream, size_t zero_lo, size_t zero_hi);   // mlp_wgrad.hip
 
 extern "C" size_t nerf_mlp_bwd_workspace_bytes(int64_t n) { return n > 0 ? bwd_layout(n).total : 0; }
 
@@ -271,12 +271,15 @@ static int launch_wgrad(const void* stash, const void* workspace, int64_t n, flo
   NERF_REQUIRE(grads_f32 != nullptr, "nerf_mlp_bwd: grads_f32 is NULL");
   NERF_REQUIRE(part >= 0 && part <= 2, "nerf_mlp_bwd_wgrad_part: part=%d (0 all, 1 late layers, 2 early layers)", part);
   const size_t lo = part == 1 ? (size_t)plan::kW4 : 0, hi = part == 2 ? (size_t)plan::kW4 : (size_t)plan::kParamCount;
-  if (hipMemsetAsync(grads_f32 + lo, 0, sizeof(float) * (hi - lo), as_stream(stream)) != hipSuccess)
-    return fail(NERF_ELAUNCH, "nerf_mlp_bwd: memset failed");
-  if (n == 0) return NERF_OK;
+  if (n == 0) {
+    if (hipMemsetAsync(grads_f32 + lo, 0, sizeof(float) * (hi - lo), as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_mlp_bwd: memset failed");
+    return NERF_OK;
+  }
   NERF_REQUIRE(stash && workspace, "nerf_mlp_bwd: NULL pointer");
+  // the range is zeroed inside only if the launch flushes with atomics (the partial-tile form overwrites it)
   return nerf_launch_wgrad(static_cast<const char*>(stash), stash_layout(n), static_cast<const char*>(workspace),
-                           bwd_layout(n), n, grads_f32, part, as_stream(stream));
+                           bwd_layout(n), n, grads_f32, part, as_stream(stream), lo, hi);
 }
 
 extern "C" int nerf_mlp_bwd_dgrad(const void* packed, const void* stash, const float* rgb, const float* sigma,

@@ -53,7 +53,9 @@ struct WgradArgs {
 // fills cost0 / total_cost / wave_tiles / grads and launches; jobs[0..n_jobs) must be set
 // slab: partial-tile memory of slab_bytes (mlp_stash.h::kSlabBytes) or null for the atomic flush; in slab mode
 // every parameter of the launched jobs is OVERWRITTEN (no memset needed), in atomic mode accumulated
+// zero_lo / zero_hi: the parameter range [zero_lo, zero_hi) of grads is zeroed here when (and only when) the launch
+// flushes with atomics -- the slab form overwrites every parameter of its jobs, so it needs no memset
 int wgrad_launch(WgradArgs& args, int64_t n_samples, float* grads, hipStream_t stream, float* slab = nullptr,
-                 size_t slab_bytes = 0);
+                 size_t slab_bytes = 0, size_t zero_lo = 0, size_t zero_hi = 0);
 
 }  // namespace nerf

@@ -536,7 +536,7 @@ using namespace nerf;
 // pts_layers.0 .. 3 (parameters [0, kW4)).  Parts 1 and 2 let a data-parallel caller all-reduce the
 // first range while the second is still being computed.
 int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work, const BwdLayout& bl,
-                      int64_t n, float* grads, int part, hipStream_t stream) {
+                      int64_t n, float* grads, int part, hipStream_t stream, size_t zero_lo, size_t zero_hi) {
   WgradArgs args{};
   const size_t np = (size_t)sl.n_pad, eb = sl.fp8 ? 1 : 2;
   if (sl.fp8 != bl.fp8) return fail(NERF_EINVAL, "nerf_mlp_bwd: stash and workspace disagree on the image width");
@@ -610,10 +610,11 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
   }
   args.n_jobs = nj;
   float* slab = bl.slab_bytes ? reinterpret_cast<float*>(const_cast<char*>(work) + bl.slab) : nullptr;
-  return wgrad_launch(args, n, grads, stream, slab, bl.slab_bytes);
+  return wgrad_launch(args, n, grads, stream, slab, bl.slab_bytes, zero_lo, zero_hi);
 }
 
-int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t stream, float* slab, size_t slab_bytes) {
+int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t stream, float* slab, size_t slab_bytes,
+                       size_t zero_lo, size_t zero_hi) {
   int nj = args.n_jobs;
   // span cost of one wave tile = its bytes + a fixed per-iteration share (barrier, counted waits,
   // DMA issue, LDS reads + MFMAs of the stage).  Measured on MI355X: the iteration time is nearly
@@ -690,6 +691,9 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
     }
     if (ok && (size_t)off * sizeof(float) <= slab_bytes) args.slab = slab;
   }
+  if (args.slab == nullptr && zero_hi > zero_lo &&
+      hipMemsetAsync(grads + zero_lo, 0, sizeof(float) * (zero_hi - zero_lo), stream) != hipSuccess)
+    return fail(NERF_ELAUNCH, "nerf_mlp_bwd: memset failed");
   bool small = args.amax == nullptr && args.slab == nullptr && !options().wgrad_big_only;
   for (int j = 0; j < args.n_jobs; ++j) {
     const WgradJob& jb = args.jobs[j];
