@@ -385,7 +385,9 @@ def main():
 
     def step(mark=None):
         # the data side of the step (run.py:314-322 + the jitter of render_rays): one kernel
-        o, d, target, z = ds.train_batch(R, S, eng.near, eng.far, eng.bg, seed=100 + rank, counter=counter[0])
+        # every rank draws ITS shard of one global batch of world x R rays (same seed and counter, first_ray = rank x R):
+        # the union over the ranks is the batch one GPU would draw with the global size
+        o, d, target, z = ds.train_batch(R, S, eng.near, eng.far, eng.bg, seed=100, counter=counter[0], first_ray=rank * R)
         counter[0] += 1
         if mark is not None:
             mark("batch_sampling")

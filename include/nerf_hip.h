@@ -91,6 +91,14 @@ int nerf_train_batch(const float* images, const float* poses, int n_images, int 
                      int n_samples, float near_plane, float far_plane, int perturb, float* rays_o, float* rays_d,
                      float* rgba, float* target, float* z_out, nerf_stream_t stream);
 
+/* the same for rays [first_ray, first_ray + batch) of a larger batch: ranks that pass the same seed and counter and
+ * their shard of a global batch draw, between them, exactly the batch one rank draws with the global size (SURVEY 8(e):
+ * "each rank draws its own shard from the same seeded index stream so the union equals the 1-GPU batch") */
+int nerf_train_batch_shard(const float* images, const float* poses, int n_images, int H, int W, float focal,
+                     float scene_scale, const float* bg, uint64_t seed, uint64_t counter, int64_t first_ray, int64_t batch,
+                     int n_samples, float near_plane, float far_plane, int perturb, float* rays_o, float* rays_d,
+                     float* rgba, float* target, float* z_out, nerf_stream_t stream);
+
 /* ---- a3: occupancy lookup ---------------------------------------------------
  * replaces DensityGrid.get_active_mask (src/renderer.py:134-166).
  *   pts [N,3]; binary_grid [res,res,res] bytes (torch.bool storage);

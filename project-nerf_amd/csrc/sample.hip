@@ -171,19 +171,22 @@ __device__ __forceinline__ uint32_t squares32(uint64_t ctr, uint64_t key) {
 // one uniform draw -> jittered stratified depth.  Thread per (ray, sample); sample 0 also forms the ray.
 __global__ void __launch_bounds__(256)
 train_batch_kernel(const GatherArgs a, uint64_t n_pixels, uint64_t key, uint64_t counter, int64_t batch, int n_samples,
-                   float near_p, float far_p, float step, int perturb, float* __restrict__ z_out) {
+                   float near_p, float far_p, float step, int perturb, float* __restrict__ z_out, int64_t first_ray) {
+  // first_ray: this call forms rays [first_ray, first_ray + batch) of a larger (global) batch -- the draws are indexed by
+  // the GLOBAL ray / sample number, the outputs by the local one
   const int64_t total = batch * (int64_t)n_samples;
   for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = g / n_samples;
     const int s = (int)(g - r * n_samples);
     if (perturb) {
-      const float u = (float)(squares32((counter << 40) + (uint64_t)g, key) >> 8) * 5.9604644775390625e-08f;   // [0, 1), 24 bits
+      const uint64_t gg = (uint64_t)(g + first_ray * n_samples);
+      const float u = (float)(squares32((counter << 40) + gg, key) >> 8) * 5.9604644775390625e-08f;   // [0, 1), 24 bits
       z_out[g] = jitter_depth(s, n_samples, step, near_p, far_p, u);
     } else {
       z_out[g] = plain_depth(s, n_samples, step, near_p, far_p);
     }
     if (s == 0) {
-      const uint64_t c0 = (counter << 40) + ((uint64_t)1 << 39) + 2 * (uint64_t)r;
+      const uint64_t c0 = (counter << 40) + ((uint64_t)1 << 39) + 2 * (uint64_t)(r + first_ray);
       const uint64_t r64 = ((uint64_t)squares32(c0, key) << 32) | squares32(c0 + 1, key);
       const uint64_t idx = __umul64hi(r64, n_pixels);            // uniform over [0, n_pixels)
       const int64_t px = (int64_t)(idx % (uint64_t)a.W), py = (int64_t)((idx / (uint64_t)a.W) % (uint64_t)a.H);
@@ -257,12 +260,35 @@ extern "C" int nerf_gather_batch(const float* images, const float* poses, const 
   return check_launch("nerf_gather_batch");
 }
 
+static int train_batch_impl(const float* images, const float* poses, int n_images, int H, int W, float focal,
+                            float scene_scale, const float* bg, uint64_t seed, uint64_t counter, int64_t first_ray, int64_t batch,
+                            int n_samples, float near_plane, float far_plane, int perturb, float* rays_o, float* rays_d,
+                            float* rgba, float* target, float* z_out, nerf_stream_t stream);
+
 extern "C" int nerf_train_batch(const float* images, const float* poses, int n_images, int H, int W, float focal,
                                 float scene_scale, const float* bg, uint64_t seed, uint64_t counter, int64_t batch,
                                 int n_samples, float near_plane, float far_plane, int perturb, float* rays_o, float* rays_d,
                                 float* rgba, float* target, float* z_out, nerf_stream_t stream) {
+  return train_batch_impl(images, poses, n_images, H, W, focal, scene_scale, bg, seed, counter, 0, batch, n_samples, near_plane,
+                          far_plane, perturb, rays_o, rays_d, rgba, target, z_out, stream);
+}
+
+extern "C" int nerf_train_batch_shard(const float* images, const float* poses, int n_images, int H, int W, float focal,
+                                      float scene_scale, const float* bg, uint64_t seed, uint64_t counter, int64_t first_ray,
+                                      int64_t batch, int n_samples, float near_plane, float far_plane, int perturb, float* rays_o,
+                                      float* rays_d, float* rgba, float* target, float* z_out, nerf_stream_t stream) {
+  NERF_REQUIRE(first_ray >= 0, "nerf_train_batch_shard: first_ray=%lld", (long long)first_ray);
+  return train_batch_impl(images, poses, n_images, H, W, focal, scene_scale, bg, seed, counter, first_ray, batch, n_samples,
+                          near_plane, far_plane, perturb, rays_o, rays_d, rgba, target, z_out, stream);
+}
+
+static int train_batch_impl(const float* images, const float* poses, int n_images, int H, int W, float focal,
+                            float scene_scale, const float* bg, uint64_t seed, uint64_t counter, int64_t first_ray, int64_t batch,
+                            int n_samples, float near_plane, float far_plane, int perturb, float* rays_o, float* rays_d,
+                            float* rgba, float* target, float* z_out, nerf_stream_t stream) {
   NERF_REQUIRE(batch >= 0 && n_images > 0 && H > 0 && W > 0 && focal > 0.0f && n_samples >= 2, "nerf_train_batch: bad sizes");
-  NERF_REQUIRE(counter < ((uint64_t)1 << 24) && batch * (int64_t)n_samples < ((int64_t)1 << 39), "nerf_train_batch: counter / batch out of range");
+  NERF_REQUIRE(counter < ((uint64_t)1 << 24) && (first_ray + batch) * (int64_t)n_samples < ((int64_t)1 << 39),
+               "nerf_train_batch: counter / batch out of range");
   if (batch == 0) return NERF_OK;
   NERF_REQUIRE(images && poses && rays_o && rays_d && z_out && (rgba || target), "nerf_train_batch: NULL pointer");
   NERF_REQUIRE((target == nullptr) == (bg == nullptr), "nerf_train_batch: target and bg go together");
@@ -274,6 +300,6 @@ extern "C" int nerf_train_batch(const float* images, const float* poses, int n_i
   const GatherArgs a{images, poses, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, bg, rays_o, rays_d, rgba, target};
   const float step = 1.0f / (float)(n_samples - 1);
   hipLaunchKernelGGL(train_batch_kernel, dim3(grid_for(batch * (int64_t)n_samples, 256)), dim3(256), 0, as_stream(stream), a,
-                     (uint64_t)n_images * H * W, key, counter, batch, n_samples, near_plane, far_plane, step, perturb, z_out);
+                     (uint64_t)n_images * H * W, key, counter, batch, n_samples, near_plane, far_plane, step, perturb, z_out, first_ray);
   return check_launch("nerf_train_batch");
 }

@@ -76,12 +76,13 @@ class BlenderDataset:
         o, d, target, _ = ops.gather_batch(self.images, self.poses, idx, self.focal, self.scene_scale, bg=bg)
         return o, d, target
 
-    def train_batch(self, batch_size, n_samples, near, far, bg, seed, counter, perturb=True):
+    def train_batch(self, batch_size, n_samples, near, far, bg, seed, counter, perturb=True, first_ray=0):
         """(rays_o, rays_d, target, z) of one training step from one kernel (ops.train_batch): pixel draws,
-        rays, composited targets and jittered stratified depths."""
+        rays, composited targets and jittered stratified depths.  ``first_ray`` = rank * batch_size with the same seed and
+        counter on every rank: the ranks' batches are then the shards of ONE global batch of world * batch_size rays."""
         from . import ops
         return ops.train_batch(self.images, self.poses, self.focal, batch_size, n_samples, near, far, seed, counter, bg=bg,
-                               scene_scale=self.scene_scale, perturb=perturb)
+                               scene_scale=self.scene_scale, perturb=perturb, first_ray=first_ray)
 
     @classmethod
     def from_tensors(cls, images, poses, camera_angle_x, white_bkgd=True, scene_scale=1.0):

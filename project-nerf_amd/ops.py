@@ -105,9 +105,10 @@ def gather_batch(images: Tensor, poses: Tensor, flat_idx: Tensor, focal: float, 
 
 def train_batch(images: Tensor, poses: Tensor, focal: float, batch: int, n_samples: int, near: float, far: float,
                 seed: int, counter: int, bg: Optional[Tensor] = None, scene_scale: float = 1.0, perturb: bool = True,
-                want_rgba: bool = False):
+                want_rgba: bool = False, first_ray: int = 0):
     """The data side of a training step as ONE kernel: (rays_o, rays_d, target or rgba, z).  Pixels and
-    stratified jitter come from a counter-based generator keyed by (seed, counter)."""
+    stratified jitter come from a counter-based generator keyed by (seed, counter).  ``first_ray``: this call forms
+    rays [first_ray, first_ray + batch) of a larger batch (data-parallel shards of one global batch)."""
     lib = _lib.load()
     images, poses = _dev(images, "images"), _dev(poses, "poses")
     n_img, H, W, _ = images.shape
@@ -116,10 +117,10 @@ def train_batch(images: Tensor, poses: Tensor, focal: float, batch: int, n_sampl
     z = torch.empty(batch, n_samples, device=dev)
     rgba = torch.empty(batch, 4, device=dev) if (want_rgba or bg is None) else None
     target = torch.empty(batch, 3, device=dev) if bg is not None else None
-    _lib.check(lib.nerf_train_batch(_p(images), _p(poses), n_img, H, W, float(focal), float(scene_scale),
-                                    _p(None if bg is None else _dev(bg, "bg")), int(seed), int(counter), batch, n_samples,
-                                    float(near), float(far), 1 if perturb else 0, _p(o), _p(d), _p(rgba), _p(target), _p(z),
-                                    _stream()), "nerf_train_batch")
+    _lib.check(lib.nerf_train_batch_shard(_p(images), _p(poses), n_img, H, W, float(focal), float(scene_scale),
+                                          _p(None if bg is None else _dev(bg, "bg")), int(seed), int(counter), int(first_ray), batch,
+                                          n_samples, float(near), float(far), 1 if perturb else 0, _p(o), _p(d), _p(rgba), _p(target),
+                                          _p(z), _stream()), "nerf_train_batch")
     return o, d, (target if bg is not None else rgba), z
 
 

@@ -273,6 +273,11 @@ def test_train_batch_kernel_statistics_and_formulas(tmp_path):
     assert torch.equal(o, o2) and torch.equal(z, z2)                       # counter-based: reproducible
     o3, _, _, z3 = ds.train_batch(B, S, 2.0, 6.0, bg, seed=7, counter=1)
     assert not torch.equal(z, z3) and not torch.equal(o, o3)               # a new counter is a new batch
+    # data-parallel shards: three ranks with the same seed / counter and first_ray = their offset draw, between them,
+    # exactly the batch one rank draws with the global size
+    parts = [ds.train_batch(n, S, 2.0, 6.0, bg, seed=7, counter=0, first_ray=f) for f, n in ((0, 25000), (25000, 20000), (45000, 15000))]
+    for k, whole in enumerate((o, d, target, z)):
+        assert torch.equal(torch.cat([p[k] for p in parts], 0), whole), k
     # depths: inside their stratum, and u = (z - lower) / (upper - lower) is uniform
     plain = O.stratified_depths(2.0, 6.0, S, 1, False)[0]
     mids = 0.5 * (plain[1:] + plain[:-1])
