@@ -41,7 +41,7 @@ import sys
 from collections import deque
 
 D = int(os.environ.get("GEN_D", 4))                 # A-fragment prefetch depth (window registers)
-EPI_START = 3     # first gap (after MFMA k) that may carry epilogue work
+EPI_START = int(os.environ.get("GEN_EPI", 3))     # first gap (after MFMA k) that may carry epilogue work
 # timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,stinst,vmwait,oneimage
 ABLATE = set(filter(None, os.environ.get("GEN_NO", "").split(",")))
 CHUNK = 64
@@ -484,7 +484,7 @@ def emit_function(mode, p):
 def main():
     p = print
     p("// GENERATED by gen_stream_asm.py -- do not edit.  See that file for the design.")
-    p(f"// GEN_CONFIG D={D} NO={','.join(sorted(ABLATE))}")
+    p(f"// GEN_CONFIG D={D} NO={','.join(sorted(ABLATE))}" + (f" EPI={EPI_START}" if EPI_START != 3 else ""))
     p("#pragma once\n")
     p("namespace nerf {\n")
     p(f"static_assert(plan::kChunkFrags == {CHUNK}, \"stream plan\");")
