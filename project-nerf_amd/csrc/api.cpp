@@ -33,6 +33,7 @@ static const OptionSlot kSlots[] = {
     {"wgrad_big_only", "NERF_WGRAD_BIG_ONLY", &Options::wgrad_big_only},
     {"infer_shape32", "NERF_INFER_SHAPE32", &Options::infer_shape32},
     {"stash_bf16", "NERF_STASH_BF16", &Options::stash_bf16},
+    {"chain_grid", "NERF_CHAIN_GRID", &Options::chain_grid},
 };
 
 Options& options() {

@@ -37,6 +37,7 @@ struct Options {
   int hash_bwd_atomic = 0;       // 1: the atomic form of the hash scatter even when a workspace is given (A/B)
   int infer_shape32 = 0;         // inference on the 32x32x16 MFMA stream instead of the 16x16x32 one (A/B)
   int stash_bf16 = 0;            // training images in bf16 (round-1 format) instead of fp8
+  int chain_grid = 0;            // > 0: cap the chain kernels' workgroup count (timing below the power limit)
 };
 Options& options();
 

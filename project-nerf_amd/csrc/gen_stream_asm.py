@@ -42,7 +42,7 @@ from collections import deque
 
 D = int(os.environ.get("GEN_D", 4))                 # A-fragment prefetch depth (window registers)
 EPI_START = int(os.environ.get("GEN_EPI", 3))     # first gap (after MFMA k) that may carry epilogue work
-# timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,stinst,vmwait,oneimage
+# timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,stinst,vmwait,maskwait,oneimage
 ABLATE = set(filter(None, os.environ.get("GEN_NO", "").split(",")))
 CHUNK = 64
 VA, SO, MO, T0 = 88, 89, 90, 95          # scratch VGPRs; v91..v94: mask words (4 rotating slots in dgrad, v91 forward)
@@ -137,6 +137,7 @@ def generate(mode):
     assert all(c["count"] > D + 12 for c in chunks[1:-1]), [c["count"] for c in chunks]
 
     out, lds_q, vm_q = [], [], []      # emitted lines; LDS / vector-memory operations in issue order
+    vm_done = []                       # vector-memory operations of this pass that a wait has already retired
     emit = out.append
 
     def frag_addr(j):
@@ -165,15 +166,17 @@ def generate(mode):
         """all queued vector-memory ops matching pred have completed (in-order return)"""
         hits = [i for i, t in enumerate(vm_q) if pred(t)]
         if not hits:
-            if unknown_ok:
+            if unknown_ok or any(pred(t) for t in vm_done):         # an earlier wait of this pass already covered it
                 return
             emit("s_waitcnt vmcnt(0)")                              # issued before this pass: count unknown
+            vm_done.extend(vm_q)
             del vm_q[:]
             return
         last = max(hits)
         n = len(vm_q) - 1 - last
         assert n <= 63
         emit(f"s_waitcnt vmcnt({n})")
+        vm_done.extend(vm_q[:last + 1])
         del vm_q[:last + 1]
 
     def dma_piece(cc, p):
@@ -288,6 +291,8 @@ def generate(mode):
                 emit(line[1])
                 vm_q.append(line[2])
             elif isinstance(line, tuple) and line[0] == "waitmask":
+                if "maskwait" in ABLATE:          # do not wait for the mask word (in-order vmcnt: the wait also covers older stores)
+                    continue
                 wait_vm(lambda t, gi=line[1]: t == ("ml", gi), unknown_ok=False)
             else:
                 emit(line)

@@ -252,6 +252,7 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
   if (int rc = ensure_dynamic_lds(stream_family ? (const void*)mlp_bwd_stream_kernel : (const void*)mlp_bwd_kernel, kChainLds,
                                   "nerf_mlp_bwd"); rc != NERF_OK) return rc;
   const int64_t tiles = bl.n_pad / kTileSamples;
+  if (options().chain_grid > 0 && options().chain_grid < n_cu) n_cu = options().chain_grid;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
   if (bl.fp8 && amax_dev == nullptr) {
     if (hipMemsetAsync(a.amax, 0, sizeof(float), as_stream(stream)) != hipSuccess)

@@ -427,6 +427,7 @@ static int mlp_fwd_impl(const void* packed, const float* rays_o, const float* ra
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
   const int64_t tiles = (n + kTileSamples - 1) / kTileSamples;
+  if (options().chain_grid > 0 && options().chain_grid < n_cu) n_cu = options().chain_grid;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
   const bool legacy = !chain_use_stream(n, stash != nullptr);
   // inference: the 16x16x32-shape stream unless option infer_shape32 asks for the 32x32x16 one (A/B)
