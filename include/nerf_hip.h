@@ -215,7 +215,7 @@ int nerf_mlp_pack_streams(const float* params_f32, void* packed, int which, nerf
  * Outputs rgb [n,3], sigma [n] fp32.
  * stash: NULL for inference; for training a workspace of nerf_mlp_stash_bytes(n)
  * that nerf_mlp_bwd consumes: an image of every layer input + relu bitmasks.  The default (asm-stream)
- * kernels write 8-bit images (e4m3, 2.5 KB + 0.6 KB of mask words per sample); the compiler-scheduled
+ * kernels write 8-bit images (e4m3, 2.5 KB + 0.3 KB of mask words per sample); the compiler-scheduled
  * family (option chain_legacy, launches above 2^22 samples) writes bf16.  Forward and backward of one
  * step must run under the same option. */
 size_t nerf_mlp_stash_bytes(int64_t n);

@@ -23,8 +23,8 @@ leave a counted `s_waitcnt` alone.  Inside a single statement every wait state a
     chunk c+1 (every wave's reads of chunk c have returned), then the DMA of chunk c+2 into the
     freed slot, one 1-KiB piece per MFMA gap.
   * training: ReLU mask word of tile m = sum_q min(bf16 pair q, 1) << q  (bit q: row 2q active,
-    bit 16+q: row 2q+1), one dword per lane and tile; dgrad expands it with shift / and 0x10001 /
-    v_pk_mul_lo_u16.
+    bit 16+q: row 2q+1); its two used bytes go to memory as one 16-bit word per lane and tile (v_perm_b32
+    packs / unpacks); dgrad expands it with shift / and 0x10001 / v_pk_mul_lo_u16.
   * training images are 8-bit: the bf16 pair the chain keeps for the next layer is converted once
     more (v_cvt_scalef32_pk_fp8_bf16: e4m3 activations; ..._bf8_bf16: e5m2 pre-activation gradients,
     divided by the power-of-two scale in s95) into the accumulator tile the epilogue has just drained
@@ -50,8 +50,8 @@ X, Y, P, Q = 96, 112, 128, 192
 FIRST_LITERAL_VGPR = 88
 # literal SGPRs s84..s99: [84:85] h / dh base, [86:87] feat / dfeat, [88:89] hv / dhv, [90:91] current
 # image, [92:93] mask base, [94] 0x00010001, [95] image scale (divisor), [96:97] layer stride in bytes,
-# [98:99] scratch
-SGPR_LITERALS = range(84, 100)
+# [98:99] scratch, [100] v_perm_b32 selector that packs (forward) / unpacks (dgrad) a mask word
+SGPR_LITERALS = range(84, 101)
 
 
 def vr(a, n=1):
@@ -221,8 +221,8 @@ def generate(mode):
         ml = g["epi"].get("mask_layer")
         if ml is None or "store" in ABLATE:
             return []
-        return [f"v_add_u32 {vr(MO)}, {hex((ml * 8 + g['m']) * 2048)}, %[{src}]",
-                ("load", f"global_load_dword {vr(mask_slot(gi))}, {vr(MO)}, s[92:93]", ("ml", gi))]
+        return [f"v_add_u32 {vr(MO)}, {hex((ml * 8 + g['m']) * 1024)}, %[{src}]",
+                ("load", f"global_load_ushort {vr(mask_slot(gi))}, {vr(MO)}, s[92:93]", ("ml", gi))]
 
     def epi_units(gi):
         """gap-sized units of group gi's epilogue (its accumulators are tile T)"""
@@ -261,7 +261,8 @@ def generate(mode):
                 else:
                     u += [f"v_pk_min_u16 {vr(T0)}, {vr(r0 + j)}, s94", f"v_lshl_or_b32 {vr(w)}, {vr(T0)}, {j}, {vr(w)}"]
             if bwd and masked and "store" not in ABLATE:
-                u += [("waitmask", gi)] if j == 0 else []
+                if j == 0:                                           # bytes (even rows, odd rows) -> the halves of a dword
+                    u += [("waitmask", gi), f"v_perm_b32 {vr(mask_slot(gi))}, {vr(mask_slot(gi))}, {vr(mask_slot(gi))}, s100"]
                 u += [f"v_lshrrev_b32 {vr(T0)}, {j}, {vr(mask_slot(gi))}", f"v_and_b32 {vr(T0)}, s94, {vr(T0)}",
                       f"v_pk_mul_lo_u16 {vr(r0 + j)}, {vr(r0 + j)}, {vr(T0)}"]
             if stash and "store" not in ABLATE:
@@ -274,8 +275,9 @@ def generate(mode):
             units.append(set_image(e["image"]) + [f"v_add_u32 {vr(SO)}, {hex(e['m'] * 1024)}, %[{so_base}]",
                                                    ("store", f"global_store_dwordx4 {vr(SO)}, {vr(T, 4)}, s[90:91] nt")])
             if train and masked:
-                units.append([f"v_add_u32 {vr(MO)}, {hex((e['mask_layer'] * 8 + e['m']) * 2048)}, %[mo0]",
-                              ("store", f"global_store_dword {vr(MO)}, {vr(mask_slot(gi))}, s[92:93]")])
+                units.append([f"v_perm_b32 {vr(mask_slot(gi))}, {vr(mask_slot(gi))}, {vr(mask_slot(gi))}, s100",
+                              f"v_add_u32 {vr(MO)}, {hex((e['mask_layer'] * 8 + e['m']) * 1024)}, %[mo0]",
+                              ("store", f"global_store_short {vr(MO)}, {vr(mask_slot(gi))}, s[92:93]")])
             if bwd and gi + 4 < n_groups:
                 units.append(mask_load(gi + 4))                      # slot gi % 4 is free again
         return units
@@ -312,6 +314,9 @@ def generate(mode):
         for sreg, off in zip((84, 86, 88, 92, 96), ka):
             emit(f"s_load_dwordx2 s[{sreg}:{sreg + 1}], %[karg], {hex(off)}")
         emit("s_mov_b32 s94, 0x10001")
+        # mask word in registers: bit q = row 2q, bit 16+q = row 2q+1 (q < 8); in memory: 16 bits, byte 0 = even rows,
+        # byte 1 = odd rows.  v_perm_b32 selector bytes: 0..3 pick a byte of the source, 0x0c writes zero
+        emit("s_mov_b32 s100, " + ("0x0c010c00" if bwd else "0x0c0c0200"))
         emit("s_mov_b32 s95, %[scale]")                              # divisor of the 8-bit images
         emit("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")      # MODE.FP16_OVFL: 8-bit conversions saturate
         emit("s_waitcnt lgkmcnt(0)")
@@ -495,7 +500,7 @@ def main():
     p(f"static_assert(plan::kChunkFrags == {CHUNK}, \"stream plan\");")
     p("// ab0/ab1: LDS byte address of ring slot 0/1 + lane*16; bb: LDS address of the bias table + 16*half;")
     p("// voff = wave*1024 + lane*16; ldsw = ring base + wave*1024 (wave-uniform); src = fragment stream;")
-    p("// so8/so4 = wave_tile*MT*1024 + block8_lane_offset(col, half) for MT = 8/4; mo0 = (tile*72*512 + tid)*4;")
+    p("// so8/so4 = wave_tile*MT*1024 + block8_lane_offset(col, half) for MT = 8/4; mo0 = (tile*72*512 + tid)*2;")
     p("// karg = kernarg segment.\n")
     for mode in os.environ.get("GEN_MODES", "infer,infer16,train,bwd").split(","):
         emit_function(mode, p)

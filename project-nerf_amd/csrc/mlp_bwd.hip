@@ -207,9 +207,9 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const 
 
     const unsigned lane32 = block8_lane_offset(col, half);
     const unsigned so8 = (unsigned)wave_tile * (8u * 1024u) + lane32, so4 = (unsigned)wave_tile * (4u * 1024u) + lane32;
-    const unsigned mo0 = (unsigned)tile * (72u * 512u * 4u) + 4u * tid;
+    const unsigned mo0 = (unsigned)tile * (72u * 512u * 2u) + 2u * tid;
     const bool more = tile + gridDim.x < n_tiles;
-    const unsigned mo0n = more ? (unsigned)(tile + gridDim.x) * (72u * 512u * 4u) + 4u * tid : mo0;
+    const unsigned mo0n = more ? (unsigned)(tile + gridDim.x) * (72u * 512u * 2u) + 2u * tid : mo0;
     const unsigned first = __builtin_amdgcn_readfirstlane(tile == (int64_t)blockIdx.x ? 1u : 0u);
     bwd_stream_pass(ab0, ab1, in_rgb, in_sigma, src, voff, ldsw, so8, so4, mo0, mo0n, first, karg, gscale);
   }

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
       for (int ks = 0; ks < 2; ++ks) stash_nat8<false>(reinterpret_cast<char*>(a.st_denc), wave_tile, 2, ks, col, half, denc[ks], kActScale);
       const unsigned lane32 = block8_lane_offset(col, half);
       const unsigned so8 = (unsigned)wave_tile * (8u * 1024u) + lane32, so4 = (unsigned)wave_tile * (4u * 1024u) + lane32;
-      const unsigned mo0 = (unsigned)tile * (72u * 512u * 4u) + 4u * tid;
+      const unsigned mo0 = (unsigned)tile * (72u * 512u * 2u) + 2u * tid;
       fwd_train_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, so8, so4, mo0, karg, kActScale, sg, cr, cg, cb);
     } else {
       fwd_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, sg, cr, cg, cb);

@@ -19,7 +19,7 @@ namespace nerf {
 //   option chain_legacy (env NERF_CHAIN_LEGACY=1, or nerf_set_option) selects the compiler-scheduled
 //   family everywhere (development aid, tests).
 // Forward and backward of one step must decide alike: the ReLU
-// mask words differ between the families (stream: one dword per lane and m-tile, bit q / 16+q =
+// mask words differ between the families (stream: 16 bits per lane and m-tile, bit q / 8+q =
 // rows 2q / 2q+1; compiler-scheduled: 16 bits per m-tile, bit r = accumulator register r).
 inline bool chain_use_stream(int64_t n, bool training) {
   if (options().chain_legacy) return false;
@@ -52,7 +52,7 @@ inline StashLayout stash_layout(int64_t n) {
   s.feat = o; o += np * 256 * eb;
   s.hv = o;   o += np * 128 * eb;
   s.denc = o; o += np * 32 * eb;
-  s.mask = o; o += (np / 256) * 9 * 512 * 32;
+  s.mask = o; o += (np / 256) * 9 * 512 * 16;   // both families: 16 mask bits per lane and m-tile
   s.total = o;
   return s;
 }

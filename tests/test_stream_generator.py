@@ -32,6 +32,6 @@ def test_vector_memory_waits_are_counted(mode, max_full_drains):
 def test_dgrad_waits_once_per_masked_tile():
     text = _generate("bwd")
     # 68 of the 76 tiles carry a ReLU mask word (B_VIEW's 8 do not); the first three words are loaded by the previous pass
-    n_mask_loads = len(re.findall(r"global_load_dword v9[1-4], v90, s\[92:93\]", text))
+    n_mask_loads = len(re.findall(r"global_load_ushort v9[1-4], v90, s\[92:93\]", text))
     assert n_mask_loads >= 68, n_mask_loads
     assert "GEN_CONFIG D=4 NO=\n" in text            # default configuration: no timing ablation leaked into the build
