@@ -115,7 +115,7 @@ int nerf_active_mask(const float* pts, int64_t n, const uint8_t* binary_grid, in
  *   z_out [R,S]; slot_of_sample [R*S] int32: row of the sample in the compact arrays, -1 = skipped;
  *   pts_compact / dirs_compact [capacity >= R*S rows, 3] (only the first *active_count rows are
  *   written; dirs are unit view directions); active_count: device u32.
- * z and the voxel test are bit-exact w.r.t. nerf_sample_rays + nerf_active_mask. */
+ * z and the voxel test are bit-exact w.r.t. nerf_sample_rays + nerf_active_mask.  resolution <= 32768. */
 int nerf_sample_compact(const float* rays_o, const float* rays_d, const float* u, int64_t n_rays,
                         int n_samples, float near_plane, float far_plane, const uint8_t* binary_grid,
                         int resolution, float bound, float* z_out, int* slot_of_sample, float* pts_compact,
