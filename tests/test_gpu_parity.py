@@ -499,9 +499,10 @@ def test_adam_and_adamw_vs_reference_golden(ops):
 
 
 # ------------------------------------------------------------------ a1-a4 fused
-@pytest.mark.parametrize("perturb", [False, True])
-def test_sample_compact_matches_separate_kernels(ops, perturb):
-    R, S = 77, 64
+@pytest.mark.parametrize("perturb,R,S", [(False, 77, 64), (True, 77, 64), (True, 3, 5), (True, 33001, 128)])
+def test_sample_compact_matches_separate_kernels(ops, perturb, R, S):
+    """77 x 64: one ragged pass of a workgroup (4096 samples per pass); 3 x 5: less than a wave; 33001 x 128 = 4.2 M
+    samples: more than the 1024 workgroups cover in one pass (grid-stride loop, ragged last pass)."""
     o, d = synth_rays(R, 23)
     gen = torch.Generator().manual_seed(3)
     bits = torch.rand(128, 128, 128, generator=gen) < 0.2
