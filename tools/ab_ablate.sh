@@ -4,9 +4,12 @@
 cd $GRAFT_REPO_ROOT
 CMD=$1; shift
 build() { timeout 900 python3 project-nerf_amd/build.py -q > /dev/null || exit 1; }
+APPLIED=""
+restore() { if [ -n "$APPLIED" ]; then patch -p1 -s -R < $APPLIED; APPLIED=""; build; fi; }   # never leave an ablated tree or library behind
+trap restore EXIT
 echo "== as is"; timeout -k 10 300 $CMD 2>&1 | grep -v amdgpu.ids | tail -2
 for P in "$@"; do
-  patch -p1 -s < $P || exit 1; build
+  patch -p1 -s < $P || exit 1; APPLIED=$P; build
   echo "== $P"; timeout -k 10 300 $CMD 2>&1 | grep -v amdgpu.ids | tail -2
-  patch -p1 -s -R < $P || exit 1; build
+  restore
 done
