@@ -34,6 +34,7 @@ static const OptionSlot kSlots[] = {
     {"infer_shape32", "NERF_INFER_SHAPE32", &Options::infer_shape32},
     {"stash_bf16", "NERF_STASH_BF16", &Options::stash_bf16},
     {"chain_grid", "NERF_CHAIN_GRID", &Options::chain_grid},
+    {"hash_fwd_lds_kb", "NERF_HASH_FWD_LDS_KB", &Options::hash_fwd_lds_kb},
 };
 
 Options& options() {
