@@ -120,6 +120,14 @@ int nerf_sample_compact(const float* rays_o, const float* rays_d, const float* u
                         int n_samples, float near_plane, float far_plane, const uint8_t* binary_grid,
                         int resolution, float bound, float* z_out, int* slot_of_sample, float* pts_compact,
                         float* dirs_compact, unsigned* active_count, nerf_stream_t stream);
+/* the same with the jitter drawn in the kernel (one uniform per sample from the counter-based generator of
+ * nerf_train_batch, keyed by (seed, counter); counter < 2^24): what `perturb=True` costs the reference a
+ * torch.rand([R,S]) for (src/renderer.py:198).  Same distribution, not the same stream. */
+int nerf_sample_compact_jitter(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,
+                               int64_t n_rays, int n_samples, float near_plane, float far_plane,
+                               const uint8_t* binary_grid, int resolution, float bound, float* z_out,
+                               int* slot_of_sample, float* pts_compact, float* dirs_compact,
+                               unsigned* active_count, nerf_stream_t stream);
 
 /* ---- hierarchical (inverse-CDF) fine sampling, opt-in extension --------------------
  * No reference counterpart (the reference has one stratified pass only); follows Mildenhall et al.

@@ -51,6 +51,30 @@ int ensure_dynamic_lds(const void* kernel, int bytes, const char* what);
     if (!(cond)) return ::nerf::fail(NERF_EINVAL, __VA_ARGS__); \
   } while (0)
 
+// Counter-based generator ("squares", Widynski 2020: four rounds of squaring a 64-bit counter x key): every
+// (step, element) pair owns its draw, so one kernel can draw the batch's pixels AND the stratified jitter
+// without any state -- the reference draws them with torch.randint / torch.rand (dataset.py:147-150,
+// renderer.py:198); the distributions are the same, the streams are not.
+__device__ __forceinline__ uint32_t squares32(uint64_t ctr, uint64_t key) {
+  uint64_t x = ctr * key, y = x, z = y + key;
+  x = x * x + y; x = (x >> 32) | (x << 32);
+  x = x * x + z; x = (x >> 32) | (x << 32);
+  x = x * x + y; x = (x >> 32) | (x << 32);
+  return (uint32_t)((x * x + z) >> 32);
+}
+
+// key of the generator from a user seed: splitmix64 of the seed, forced odd
+inline uint64_t squares_key(uint64_t seed) {
+  uint64_t key = seed + 0x9E3779B97F4A7C15ull;
+  key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull;
+  key = (key ^ (key >> 27)) * 0x94D049BB133111EBull;
+  return (key ^ (key >> 31)) | 1ull;
+}
+// uniform in [0, 1) with 24 bits: draw `index` of step `counter` (< 2^24; index < 2^40)
+__device__ __forceinline__ float squares_uniform(uint64_t counter, uint64_t index, uint64_t key) {
+  return (float)(squares32((counter << 40) + index, key) >> 8) * 5.9604644775390625e-08f;
+}
+
 // ---- individually rounded fp32 ops: never contracted into FMAs (hipcc defaults to
 // -ffp-contract=fast; the reference's eager ops round after every multiply and add) ----
 __device__ __forceinline__ float mul_rn(float a, float b) {

@@ -154,18 +154,6 @@ gather_rays_kernel(const GatherArgs a, const int64_t* __restrict__ img_idx, cons
   }
 }
 
-// Counter-based generator ("squares", Widynski 2020: four rounds of squaring a 64-bit counter x key): every
-// (step, element) pair owns its draw, so one kernel can draw the batch's pixels AND the stratified jitter
-// without any state -- the reference draws them with torch.randint / torch.rand (dataset.py:147-150,
-// renderer.py:198); the distributions are the same, the streams are not.
-__device__ __forceinline__ uint32_t squares32(uint64_t ctr, uint64_t key) {
-  uint64_t x = ctr * key, y = x, z = y + key;
-  x = x * x + y; x = (x >> 32) | (x << 32);
-  x = x * x + z; x = (x >> 32) | (x << 32);
-  x = x * x + y; x = (x >> 32) | (x << 32);
-  return (uint32_t)((x * x + z) >> 32);
-}
-
 // One kernel for the data side of a training step (reference run.py:314-322 + renderer.py:186-201):
 // per ray one uniform draw over all pixels of all frames -> origin, direction, composited target; per sample
 // one uniform draw -> jittered stratified depth.  Thread per (ray, sample); sample 0 also forms the ray.
@@ -293,10 +281,7 @@ static int train_batch_impl(const float* images, const float* poses, int n_image
   NERF_REQUIRE(images && poses && rays_o && rays_d && z_out && (rgba || target), "nerf_train_batch: NULL pointer");
   NERF_REQUIRE((target == nullptr) == (bg == nullptr), "nerf_train_batch: target and bg go together");
   NERF_REQUIRE((((uintptr_t)images | (uintptr_t)rgba) & 15) == 0, "nerf_train_batch: images / rgba must be 16-byte aligned");
-  uint64_t key = seed + 0x9E3779B97F4A7C15ull;                   // splitmix64 of the seed, forced odd
-  key = (key ^ (key >> 30)) * 0xBF58476D1CE4E5B9ull;
-  key = (key ^ (key >> 27)) * 0x94D049BB133111EBull;
-  key = (key ^ (key >> 31)) | 1ull;
+  const uint64_t key = squares_key(seed);
   const GatherArgs a{images, poses, H, W, (float)(W * 0.5), (float)(H * 0.5), focal, scene_scale, bg, rays_o, rays_d, rgba, target};
   const float step = 1.0f / (float)(n_samples - 1);
   hipLaunchKernelGGL(train_batch_kernel, dim3(grid_for(batch * (int64_t)n_samples, 256)), dim3(256), 0, as_stream(stream), a,

@@ -224,6 +224,7 @@ class InstantNgpEngine:
     def __init__(self, cfg: Optional[dict] = None, device: str = "cuda", seed: int = 0, world_size: int = 1):
         cfg = dict(cfg or {})
         self.device = torch.device(device)
+        self.seed = int(seed)
         self.bound = float(cfg.get("scene_bound", 1.5))
         if cfg.get("n_levels", 16) != 16 or cfg.get("n_features_per_level", 2) != 2 or cfg.get("hidden_dim", 64) != 64:
             raise NotImplementedError("libnerf_hip's tiny-MLP kernels are compiled for 16 levels x 2 features (32 hash "
@@ -305,9 +306,12 @@ class InstantNgpEngine:
         runs step i never stalls on the count: it arrives while step i computes (the reference, and
         ``compute_gradients`` without ``prepared``, wait at this point of every step).  The batch is compacted
         against the occupancy grid as it is now; prepare again after ``update_grid`` to use the new one."""
-        if u is None:
-            u = torch.rand(rays_o.shape[0], n_samples, device=self.device)
-        return ops.sample_compact_async(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid, self.bound, u=u)
+        jitter = None
+        if u is None:                 # the jitter is drawn in the compaction kernel: no [R, S] tensor of uniforms
+            self._jitter_counter = getattr(self, "_jitter_counter", -1) + 1
+            jitter = (self.seed, self._jitter_counter)
+        return ops.sample_compact_async(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid, self.bound, u=u,
+                                        jitter=jitter)
 
     def compute_gradients(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
                           u: Optional[Tensor] = None, sync_grads_async=None, reduce_dtype=None, prepared=None) -> Tensor:

@@ -165,8 +165,11 @@ class CompactedSamples:
 
 
 def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_samples: int,
-                         binary_grid: Tensor, bound: float, u: Optional[Tensor] = None) -> CompactedSamples:
-    """``sample_compact`` without the host wait: same kernel, same outputs; the count comes back asynchronously."""
+                         binary_grid: Tensor, bound: float, u: Optional[Tensor] = None,
+                         jitter: Optional[Tuple[int, int]] = None) -> CompactedSamples:
+    """``sample_compact`` without the host wait: same kernel, same outputs; the count comes back asynchronously.
+    ``jitter=(seed, counter)`` (with ``u`` None): the stratified jitter is drawn inside the kernel (nerf_sample_compact_jitter)
+    instead of being read from a [R, S] tensor of uniforms."""
     lib = _lib.load()
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
     grid = _dev(binary_grid, "binary_grid", torch.bool)
@@ -179,9 +182,14 @@ def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float
     slots = torch.empty(n, device=dev, dtype=torch.int32)
     pts, dirs = torch.empty(max(n, 1), 3, device=dev), torch.empty(max(n, 1), 3, device=dev)
     count = torch.zeros(1, device=dev, dtype=torch.int32)
-    _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
-                                       float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),
-               "nerf_sample_compact")
+    if u is None and jitter is not None:
+        _lib.check(lib.nerf_sample_compact_jitter(_p(rays_o), _p(rays_d), int(jitter[0]), int(jitter[1]) & 0xFFFFFF, R, n_samples,
+                                                  near, far, _p(grid), grid.shape[0], float(bound), _p(z), _p(slots), _p(pts),
+                                                  _p(dirs), _p(count), _stream()), "nerf_sample_compact_jitter")
+    else:
+        _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
+                                           float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),
+                   "nerf_sample_compact")
     count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     count_host.copy_(count, non_blocking=True)
     event = torch.cuda.Event()

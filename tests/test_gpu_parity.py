@@ -521,6 +521,36 @@ def test_sample_compact_matches_separate_kernels(ops, perturb, R, S):
     np.testing.assert_allclose(dirs_c[act].cpu().numpy(), dirs[mask].cpu().numpy(), rtol=2e-7)
 
 
+def test_sample_compact_jitter_draws_in_the_kernel(ops):
+    """nerf_sample_compact_jitter: same kernel, the uniforms come from the counter-based generator instead of a tensor.
+    The depths stay inside their strata, feeding the recovered uniforms back through the tensor entry reproduces them,
+    the draws are uniform, repeat for the same (seed, counter) and change with either."""
+    R, S = 513, 128
+    o, d = synth_rays(R, 5)
+    gen = torch.Generator().manual_seed(4)
+    bits = dev(torch.rand(128, 128, 128, generator=gen) < 0.2)
+    o, d = dev(o), dev(d)
+    run = lambda seed, counter: ops.sample_compact_async(o, d, 2.0, 6.0, S, bits, 1.5, jitter=(seed, counter)).get()
+    z, slots, pts_c, dirs_c = run(7, 3)
+    plain = dev(O.stratified_depths(2.0, 6.0, S, R, False).contiguous())
+    mids = 0.5 * (plain[:, 1:] + plain[:, :-1])
+    lo, hi = torch.cat([plain[:, :1], mids], -1), torch.cat([mids, plain[:, -1:]], -1)
+    assert bool((z >= lo).all()) and bool((z <= hi).all())
+    u = ((z - lo) / (hi - lo)).clamp(0, 1)
+    assert abs(float(u.mean()) - 0.5) < 5e-3 and abs(float(u.var()) - 1 / 12) < 2e-3
+    hist = torch.histc(u, bins=16, min=0, max=1) / u.numel()
+    assert float((hist - 1 / 16).abs().max()) < 3e-3
+    # same voxel test and compaction as the tensor entry on these depths
+    z2, slots2, pts2, _ = ops.sample_compact(o, d, 2.0, 6.0, S, bits, 1.5, u=u)
+    assert float((z2 - z).abs().max()) < 2e-6
+    same = (z2 == z).view(-1)
+    assert torch.equal((slots >= 0)[same], (slots2 >= 0)[same]) and float(same.float().mean()) > 0.5
+    assert pts_c.shape[0] == int((slots >= 0).sum()) > 0
+    z_again = run(7, 3)[0]
+    assert torch.equal(z, z_again)
+    assert not torch.equal(z, run(7, 4)[0]) and not torch.equal(z, run(8, 3)[0])
+
+
 def test_composite_indexed_equals_zero_filled_scatter(ops):
     """reference renderer.py:328-343: scatter into zeros then volume_render == compositing through the slot map."""
     R, S = 41, 64
