@@ -6,7 +6,7 @@ Same scene, batch and optimiser as tools/convergence_ab.py (synthetic scene, 409
 after STEPS steps, mean over the two test views, a few seeds; runs in the dead-density plateau are left out.
 Schemes: see tools/quant_wgrad_study.py (fp32 = exact gradient, cur = today's images, mx6 / mx4 = 6 / 4-bit block-scaled).
 
-usage: python tools/quant_convergence_study.py [STEPS=2000] [SEEDS=3]"""
+usage: [SEED0=0] [SCHEMES=fp32,cur,mx6,mx4] python tools/quant_convergence_study.py [STEPS=2000] [SEEDS=3]"""
 import os
 import sys
 import tempfile
@@ -131,7 +131,7 @@ def run(seed, scheme):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        if step == 150 and float(loss) > 0.1:
+        if step == 150 and float(loss.detach()) > 0.1:
             return None
         if step % 500 == 0:
             print(f"    seed {seed} step {step} loss {float(loss):.5f} ({time.time() - t0:.0f} s)", flush=True)
@@ -144,9 +144,12 @@ def run(seed, scheme):
     return float(np.mean(ps))
 
 
-print(f"test PSNR after {STEPS} steps (dB), seeds 0..{SEEDS - 1}", flush=True)
-for name, scheme in SCHEMES.items():
-    res = [run(seed, scheme) for seed in range(SEEDS)]
+SEED0 = int(os.environ.get("SEED0", 0))
+ONLY = [k for k in os.environ.get("SCHEMES", ",".join(SCHEMES)).split(",") if k]
+print(f"test PSNR after {STEPS} steps (dB), seeds {SEED0}..{SEED0 + SEEDS - 1}", flush=True)
+for name in ONLY:
+    scheme = SCHEMES[name]
+    res = [run(seed, scheme) for seed in range(SEED0, SEED0 + SEEDS)]
     ok = [r for r in res if r is not None]
     mean = f"{np.mean(ok):.2f}" if ok else "-"
     print(f"{name:5s}: " + " ".join("dead " if r is None else f"{r:.2f}" for r in res) + f"  -> mean {mean} dB over {len(ok)} runs", flush=True)
