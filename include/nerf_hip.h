@@ -33,7 +33,10 @@ extern "C" {
 #define NERF_ELAUNCH (-5)  /* HIP launch / runtime failure          */
 #define NERF_ENOSYS (-38)  /* configuration not compiled in         */
 
-#define NERF_ABI_VERSION 1
+/* 2 (round 2 -> 3): nerf_tv_normsq gained `grad_scale`, the training images of the decoder changed format (see
+ * nerf_mlp_fwd).  A host built against another version must refuse to run: compare nerf_abi_version() with the
+ * NERF_ABI_VERSION it was compiled against (project-nerf_amd/_lib.py does; INTEGRATION.md shows the check). */
+#define NERF_ABI_VERSION 2
 
 typedef void* nerf_stream_t;
 
@@ -42,9 +45,9 @@ int nerf_abi_version(void);
 
 /* Development options (kernel-family selection, timing skeletons).  Defaults are read from the
  * environment ONCE per process (NERF_CHAIN_LEGACY, NERF_FWD_CYCLES, NERF_WGRAD_OVH,
- * NERF_WGRAD_DEBUG, NERF_WGRAD_ONLY, NERF_HASH_BWD_ONLY_LEVEL, NERF_STASH_BF16); afterwards they
+ * NERF_WGRAD_DEBUG, NERF_WGRAD_ONLY, NERF_HASH_BWD_ONLY_LEVEL, NERF_STASH_FP8); afterwards they
  * change only through nerf_set_option.  Names: "chain_legacy", "fwd_cycles", "wgrad_overhead",
- * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "wgrad_atomic", "wgrad_k16", "wgrad_big_only", "stash_bf16", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed", "chain_grid", "hash_fwd_lds_kb".  No hot-path launch reads the
+ * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "wgrad_atomic", "wgrad_k16", "wgrad_big_only", "stash_fp8", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed", "chain_grid", "hash_fwd_lds_kb".  No hot-path launch reads the
  * environment. */
 int nerf_set_option(const char* name, int value);
 int nerf_get_option(const char* name, int* value_out);
@@ -222,10 +225,11 @@ int nerf_mlp_pack_streams(const float* params_f32, void* packed, int which, nerf
  *                dirs are used as given (NeuralField.forward takes unit view dirs).
  * Outputs rgb [n,3], sigma [n] fp32.
  * stash: NULL for inference; for training a workspace of nerf_mlp_stash_bytes(n)
- * that nerf_mlp_bwd consumes: an image of every layer input + relu bitmasks.  The default (asm-stream)
- * kernels write 8-bit images (e4m3, 2.5 KB + 0.3 KB of mask words per sample); the compiler-scheduled
- * family (option chain_legacy, launches above 2^22 samples) writes bf16.  Forward and backward of one
- * step must run under the same option. */
+ * that nerf_mlp_bwd consumes: an image of every layer input + relu bitmasks.  Images are bf16 (5.1 KB + 0.3 KB
+ * of mask words per sample): every MFMA of a training step contracts bf16 operands.  Option stash_fp8 = 1 makes
+ * the asm-stream kernels write 8-bit images instead (e4m3, 2.5 KB per sample; weight gradients then come from
+ * e4m3 x e5m2 operands -- narrower than the reference's precision, opt-in).  Forward and backward of one
+ * step must run under the same options. */
 size_t nerf_mlp_stash_bytes(int64_t n);
 int nerf_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* z,
                  int64_t n, int n_samples, float* rgb, float* sigma, void* stash,
@@ -241,9 +245,9 @@ int nerf_mlp_fwd_encoded(const void* packed, const float* x_enc, const float* d_
  * run.py:337 for the decoder).  rgb/sigma are the forward outputs, d_rgb [n,3] / d_sigma [n]
  * the upstream gradients; grads_f32 [595844] (same layout as the parameter vector) is
  * OVERWRITTEN.  Two kernels: a dgrad chain (transposed weight stream; pre-activation gradients kept
- * in `workspace` as e5m2 images divided by a power of two derived from the launch's largest
- * output-layer derivative -- bf16 in the compiler-scheduled family) and a split-K weight-gradient
- * pass over the stash (v_mfma_f32_32x32x16_bf8_fp8 / _bf16).
+ * in `workspace` as bf16 images -- with option stash_fp8 as e5m2 images divided by a power of two derived
+ * from the launch's largest output-layer derivative) and a split-K weight-gradient
+ * pass over the stash (v_mfma_f32_32x32x16_bf16; stash_fp8: v_mfma_scale_f32_32x32x64_f8f6f4).
  * workspace: nerf_mlp_bwd_workspace_bytes(n), 256-byte aligned. */
 size_t nerf_mlp_bwd_workspace_bytes(int64_t n);
 int nerf_mlp_bwd(const void* packed, const void* stash, const float* rgb, const float* sigma,

@@ -83,6 +83,8 @@ PROTOTYPES = {
     "nerf_adamw_clip_step_shadow": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, c_ptr]),
 }
 
+ABI_VERSION = 2      # the NERF_ABI_VERSION of include/nerf_hip.h this table was written against
+
 _lib = None
 
 
@@ -105,8 +107,9 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.nerf_abi_version() != 1:
-        raise NerfHipError(f"ABI version mismatch: library reports {lib.nerf_abi_version()}, binding expects 1")
+    if lib.nerf_abi_version() != ABI_VERSION:
+        raise NerfHipError(f"ABI version mismatch: {LIB_PATH} reports {lib.nerf_abi_version()}, this binding was written against "
+                           f"{ABI_VERSION} (rebuild with `python project-nerf_amd/build.py`)")
     _lib = lib
     return lib
 

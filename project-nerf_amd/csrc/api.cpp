@@ -32,7 +32,7 @@ static const OptionSlot kSlots[] = {
     {"wgrad_k16", "NERF_WGRAD_K16", &Options::wgrad_k16},
     {"wgrad_big_only", "NERF_WGRAD_BIG_ONLY", &Options::wgrad_big_only},
     {"infer_shape32", "NERF_INFER_SHAPE32", &Options::infer_shape32},
-    {"stash_bf16", "NERF_STASH_BF16", &Options::stash_bf16},
+    {"stash_fp8", "NERF_STASH_FP8", &Options::stash_fp8},
     {"chain_grid", "NERF_CHAIN_GRID", &Options::chain_grid},
     {"hash_fwd_lds_kb", "NERF_HASH_FWD_LDS_KB", &Options::hash_fwd_lds_kb},
 };

@@ -126,7 +126,8 @@ def chunk_groups(groups):
 
 # ---------------------------------------------------------------- stream
 def generate(mode):
-    bwd, train, s16 = mode == "bwd", mode == "train", mode == "infer16"
+    img16 = mode in ("train16", "bwd16")          # bf16 training images (two 16-byte stores per lane and m-tile)
+    bwd, train, s16 = mode in ("bwd", "bwd16"), mode in ("train", "train16"), mode == "infer16"
     stash = bwd or train
     groups = bwd_groups() if bwd else fwd_groups(s16)
     chunks = chunk_groups(groups)
@@ -265,15 +266,22 @@ def generate(mode):
                     u += [("waitmask", gi), f"v_perm_b32 {vr(mask_slot(gi))}, {vr(mask_slot(gi))}, {vr(mask_slot(gi))}, s100"]
                 u += [f"v_lshrrev_b32 {vr(T0)}, {j}, {vr(mask_slot(gi))}", f"v_and_b32 {vr(T0)}, s94, {vr(T0)}",
                       f"v_pk_mul_lo_u16 {vr(r0 + j)}, {vr(r0 + j)}, {vr(T0)}"]
-            if stash and "store" not in ABLATE:
+            if stash and not img16 and "store" not in ABLATE:
                 # 8-bit image: bytes 2j, 2j+1 of the lane's 16-byte record, staged in the drained tile
                 cvt8 = "v_cvt_scalef32_pk_bf8_bf16" if bwd else "v_cvt_scalef32_pk_fp8_bf16"
                 u.append(f"{cvt8} {vr(T + (j >> 1))}, {vr(r0 + j)}, s95" + (" op_sel:[0,0,1]" if j & 1 else ""))
             units.append(u)
         if stash and "store" not in ABLATE:
             so_base = "so8" if e["mt"] == 8 else "so4"
-            units.append(set_image(e["image"]) + [f"v_add_u32 {vr(SO)}, {hex(e['m'] * 1024)}, %[{so_base}]",
-                                                   ("store", f"global_store_dwordx4 {vr(SO)}, {vr(T, 4)}, s[90:91] nt")])
+            if img16:
+                # bf16 image: the operand registers themselves, 2-KiB block per (wave tile, m-tile), lane (c, h) at
+                # block_lane_offset(c, h) and + 128 (mlp_chain.h::stash_block)
+                units.append(set_image(e["image"]) + [f"v_add_u32 {vr(SO)}, {hex(e['m'] * 2048)}, %[{so_base}]",
+                                                       ("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0, 4)}, s[90:91] nt")])
+                units.append([("store", f"global_store_dwordx4 {vr(SO)}, {vr(r0 + 4, 4)}, s[90:91] offset:128 nt")])
+            else:
+                units.append(set_image(e["image"]) + [f"v_add_u32 {vr(SO)}, {hex(e['m'] * 1024)}, %[{so_base}]",
+                                                       ("store", f"global_store_dwordx4 {vr(SO)}, {vr(T, 4)}, s[90:91] nt")])
             if train and masked:
                 units.append([f"v_perm_b32 {vr(mask_slot(gi))}, {vr(mask_slot(gi))}, {vr(mask_slot(gi))}, s100",
                               f"v_add_u32 {vr(MO)}, {hex((e['mask_layer'] * 8 + e['m']) * 1024)}, %[mo0]",
@@ -310,17 +318,18 @@ def generate(mode):
     # ---- pass prologue ----
     emit("s_mov_b32 %[m0s], m0")
     if stash:
-        ka = dict(train=(80, 88, 96, 112, 64), bwd=(88, 80, 72, 56, 48))[mode]   # h, feat, hv, mask, n_pad
+        ka = (80, 88, 96, 112, 64) if train else (88, 80, 72, 56, 48)          # h, feat, hv, mask, n_pad
         for sreg, off in zip((84, 86, 88, 92, 96), ka):
             emit(f"s_load_dwordx2 s[{sreg}:{sreg + 1}], %[karg], {hex(off)}")
         emit("s_mov_b32 s94, 0x10001")
         # mask word in registers: bit q = row 2q, bit 16+q = row 2q+1 (q < 8); in memory: 16 bits, byte 0 = even rows,
         # byte 1 = odd rows.  v_perm_b32 selector bytes: 0..3 pick a byte of the source, 0x0c writes zero
         emit("s_mov_b32 s100, " + ("0x0c010c00" if bwd else "0x0c0c0200"))
-        emit("s_mov_b32 s95, %[scale]")                              # divisor of the 8-bit images
-        emit("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")      # MODE.FP16_OVFL: 8-bit conversions saturate
+        if not img16:
+            emit("s_mov_b32 s95, %[scale]")                          # divisor of the 8-bit images
+            emit("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")  # MODE.FP16_OVFL: 8-bit conversions saturate
         emit("s_waitcnt lgkmcnt(0)")
-        emit("s_lshl_b64 s[96:97], s[96:97], 8")                     # layer stride = n_pad * 256 bytes
+        emit(f"s_lshl_b64 s[96:97], s[96:97], {9 if img16 else 8}")  # layer stride = n_pad * 256 elements
     if bwd and "store" not in ABLATE:
         emit("s_cmp_eq_u32 %[first], 0")
         emit("s_cbranch_scc1 .Lwarm%=")
@@ -443,6 +452,13 @@ SIGS = {
               "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
               "    unsigned voff, unsigned ldsw, unsigned so8, unsigned so4, unsigned mo0, const void* karg, float scale,\n"
               "    float& sg, float& cr, float& cg, float& cb"),
+    "train16": ("fwd_train16_stream_pass",
+                "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
+                "    unsigned voff, unsigned ldsw, unsigned so8, unsigned so4, unsigned mo0, const void* karg, float scale,\n"
+                "    float& sg, float& cr, float& cg, float& cb"),
+    "bwd16": ("bwd16_stream_pass",
+              "unsigned ab0, unsigned ab1, const bf16x8& g0, const bf16x8& gs, const char* src, unsigned voff, unsigned ldsw,\n"
+              "    unsigned so8, unsigned so4, unsigned mo0, unsigned mo0n, unsigned first, const void* karg, float scale"),
     "bwd": ("bwd_stream_pass",
             "unsigned ab0, unsigned ab1, const bf16x8& g0, const bf16x8& gs, const char* src, unsigned voff, unsigned ldsw,\n"
             "    unsigned so8, unsigned so4, unsigned mo0, unsigned mo0n, unsigned first, const void* karg, float scale"),
@@ -455,7 +471,7 @@ def emit_function(mode, p):
         lines = [l for l in lines if l != "s_barrier"]
     name, sig = SIGS[mode]
     tab = "kBwdChunks" if mode == "bwd" else "kFwdChunks"
-    if mode not in ("train", "infer16"):
+    if mode in ("infer", "bwd"):
         p(f"static_assert(plan::{tab}.n_chunks == {len(chunks)} && plan::{tab}.n_groups == {len(groups)}, \"stream plan\");")
         for i, c in enumerate(chunks):
             p(f"static_assert(plan::{tab}.chunk_frag0[{i}] == {c['frag0']} && plan::{tab}.chunk_count[{i}] == {c['count']}, \"stream plan\");")
@@ -470,7 +486,7 @@ def emit_function(mode, p):
             p(f'      "{ln}\\n\\t"')
     outs = [f'[w{i}] "=&v"(w{i})' for i in range(D)] + ['[m0s] "=&s"(m0s)']
     ins = ['[ab0] "v"(ab0)', '[ab1] "v"(ab1)', '[src] "s"(src)', '[voff] "v"(voff)', '[ldsw] "s"(ldsw)']
-    if mode == "bwd":
+    if mode in ("bwd", "bwd16"):
         ins += ['[g0] "v"(g0)', '[gs] "v"(gs)', '[mo0n] "v"(mo0n)', '[first] "s"(first)']
     elif mode == "infer16":
         outs += ['[sg0] "=&v"(sg[0])', '[sg1] "=&v"(sg[1])'] + [f'[c{i}] "=&v"(c[{i}])' for i in range(6)]
@@ -500,9 +516,10 @@ def main():
     p(f"static_assert(plan::kChunkFrags == {CHUNK}, \"stream plan\");")
     p("// ab0/ab1: LDS byte address of ring slot 0/1 + lane*16; bb: LDS address of the bias table + 16*half;")
     p("// voff = wave*1024 + lane*16; ldsw = ring base + wave*1024 (wave-uniform); src = fragment stream;")
-    p("// so8/so4 = wave_tile*MT*1024 + block8_lane_offset(col, half) for MT = 8/4; mo0 = (tile*72*512 + tid)*2;")
+    p("// so8/so4 = wave_tile*MT*1024 + block8_lane_offset(col, half) for MT = 8/4 (8-bit images; bf16 images:")
+    p("// wave_tile*MT*2048 + block_lane_offset(col, half)); mo0 = (tile*72*512 + tid)*2;")
     p("// karg = kernarg segment.\n")
-    for mode in os.environ.get("GEN_MODES", "infer,infer16,train,bwd").split(","):
+    for mode in os.environ.get("GEN_MODES", "infer,infer16,train,bwd,train16,bwd16").split(","):
         emit_function(mode, p)
     p("}  // namespace nerf")
 

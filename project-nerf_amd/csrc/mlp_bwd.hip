@@ -162,6 +162,8 @@ static_assert(offsetof(BwdArgs, n_pad) == 48 && offsetof(BwdArgs, st_mask) == 56
 
 // dgrad chain as one hand-scheduled asm statement per wave and tile (gen_stream_asm.py): this kernel
 // forms the output-layer derivatives and hands the pass its two natural-order operands.
+// IMG16: bf16 gradient images (stash_block / stash_nat) instead of the e5m2 ones (option stash_fp8).
+template <bool IMG16>
 __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -183,10 +185,13 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const 
 
   // e5m2 gradient images, divided by a power of two that puts the launch's largest output-layer
   // derivative in [64, 128) (the chain itself runs on unscaled bf16; wgrad multiplies the scale back)
-  set_fp8_saturate();
-  const float amax_in = *a.amax_src;
-  if (a.amax_src != a.amax && blockIdx.x == 0 && tid == 0) *a.amax = amax_in;   // the wgrad pass reads the workspace slot
-  const float gscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, grad_image_scale(amax_in))));
+  float gscale = 1.0f;
+  if constexpr (!IMG16) {
+    set_fp8_saturate();
+    const float amax_in = *a.amax_src;
+    if (a.amax_src != a.amax && blockIdx.x == 0 && tid == 0) *a.amax = amax_in;   // the wgrad pass reads the workspace slot
+    gscale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, grad_image_scale(amax_in))));
+  }
   const int64_t n_tiles = a.n_pad / kTileSamples;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t wave_tile = tile * 8 + wave;
@@ -201,17 +206,20 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_bwd_stream_kernel(const 
       small[0] = (__bf16)g0; small[1] = (__bf16)g1; small[2] = (__bf16)g2; small[3] = (__bf16)gs;
       in_sigma[0] = (__bf16)gs;
     }
-    stash_nat8<true>(reinterpret_cast<char*>(a.dsmall), wave_tile, 1, 0, col, half, small, gscale);
+    if constexpr (IMG16) stash_nat(a.dsmall, wave_tile, 1, 0, col, half, small);
+    else stash_nat8<true>(reinterpret_cast<char*>(a.dsmall), wave_tile, 1, 0, col, half, small, gscale);
     in_rgb = small;
     in_rgb[3] = (__bf16)0.0f;   // column 3 carries d(sigma_pre), not an rgb row
 
-    const unsigned lane32 = block8_lane_offset(col, half);
-    const unsigned so8 = (unsigned)wave_tile * (8u * 1024u) + lane32, so4 = (unsigned)wave_tile * (4u * 1024u) + lane32;
+    const unsigned lane32 = IMG16 ? block_lane_offset(col, half) : block8_lane_offset(col, half);
+    const unsigned blk = IMG16 ? 2048u : 1024u;
+    const unsigned so8 = (unsigned)wave_tile * (8u * blk) + lane32, so4 = (unsigned)wave_tile * (4u * blk) + lane32;
     const unsigned mo0 = (unsigned)tile * (72u * 512u * 2u) + 2u * tid;
     const bool more = tile + gridDim.x < n_tiles;
     const unsigned mo0n = more ? (unsigned)(tile + gridDim.x) * (72u * 512u * 2u) + 2u * tid : mo0;
     const unsigned first = __builtin_amdgcn_readfirstlane(tile == (int64_t)blockIdx.x ? 1u : 0u);
-    bwd_stream_pass(ab0, ab1, in_rgb, in_sigma, src, voff, ldsw, so8, so4, mo0, mo0n, first, karg, gscale);
+    if constexpr (IMG16) bwd16_stream_pass(ab0, ab1, in_rgb, in_sigma, src, voff, ldsw, so8, so4, mo0, mo0n, first, karg, gscale);
+    else bwd_stream_pass(ab0, ab1, in_rgb, in_sigma, src, voff, ldsw, so8, so4, mo0, mo0n, first, karg, gscale);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -249,8 +257,9 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
   const bool stream_family = chain_use_stream(n, true);
-  if (int rc = ensure_dynamic_lds(stream_family ? (const void*)mlp_bwd_stream_kernel : (const void*)mlp_bwd_kernel, kChainLds,
-                                  "nerf_mlp_bwd"); rc != NERF_OK) return rc;
+  const void* kernel = stream_family ? (bl.fp8 ? (const void*)mlp_bwd_stream_kernel<false> : (const void*)mlp_bwd_stream_kernel<true>)
+                                     : (const void*)mlp_bwd_kernel;
+  if (int rc = ensure_dynamic_lds(kernel, kChainLds, "nerf_mlp_bwd"); rc != NERF_OK) return rc;
   const int64_t tiles = bl.n_pad / kTileSamples;
   if (options().chain_grid > 0 && options().chain_grid < n_cu) n_cu = options().chain_grid;
   const int grid = (int)(tiles < n_cu ? tiles : n_cu);
@@ -260,8 +269,10 @@ static int launch_dgrad(const void* packed, const void* stash, const float* rgb,
     const int64_t want = (n + 1023) / 1024;
     hipLaunchKernelGGL(bwd_amax_kernel, dim3((int)(want < 1024 ? want : 1024)), dim3(256), 0, as_stream(stream), a);
   }
-  if (stream_family)
-    hipLaunchKernelGGL(mlp_bwd_stream_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  if (stream_family && bl.fp8)
+    hipLaunchKernelGGL(mlp_bwd_stream_kernel<false>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  else if (stream_family)
+    hipLaunchKernelGGL(mlp_bwd_stream_kernel<true>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   return check_launch("nerf_mlp_bwd (dgrad chain)");

@@ -200,7 +200,9 @@ static_assert(offsetof(FwdArgs, n_pad) == 64 && offsetof(FwdArgs, st_h) == 80 &&
 // (gen_stream_asm.py); this kernel supplies the sample geometry and Fourier codes, the cold start
 // of the ring, and the sigma / rgb heads' activations.  TRAIN: the statement also writes the
 // blocked stash images and one ReLU mask word per lane and m-tile.
-template <bool TRAIN>
+// IMG16: bf16 training images (stash_block / stash_nat, the default: the precision BASELINE configs[1] names) instead
+// of the 8-bit ones (option stash_fp8).
+template <bool TRAIN, bool IMG16 = false>
 __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = reinterpret_cast<float*>(smem);
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
   const char* src = a.packed + kPackFwdOff;
   const void* karg = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
 
-  if constexpr (TRAIN) set_fp8_saturate();
+  if constexpr (TRAIN && !IMG16) set_fp8_saturate();
   const int64_t n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   unsigned passes = 0;
@@ -237,7 +239,17 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream_kernel(const 
     sample_operands(a, nc, half, xenc, denc);
 
     float sg, cr, cg, cb;
-    if constexpr (TRAIN) {
+    if constexpr (TRAIN && IMG16) {
+      const int64_t wave_tile = tile * 8 + wave;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) stash_nat(a.st_xenc, wave_tile, 4, ks, col, half, xenc[ks]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) stash_nat(a.st_denc, wave_tile, 2, ks, col, half, denc[ks]);
+      const unsigned lane_off = block_lane_offset(col, half);
+      const unsigned so8 = (unsigned)wave_tile * (8u * 2048u) + lane_off, so4 = (unsigned)wave_tile * (4u * 2048u) + lane_off;
+      const unsigned mo0 = (unsigned)tile * (72u * 512u * 2u) + 2u * tid;
+      fwd_train16_stream_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, so8, so4, mo0, karg, 1.0f, sg, cr, cg, cb);
+    } else if constexpr (TRAIN) {
       // 8-bit (e4m3) images of every layer input; kActScale divides before the conversion (1: values
       // above 448 saturate in the image only -- the chain itself stays bf16)
       const int64_t wave_tile = tile * 8 + wave;
@@ -432,8 +444,9 @@ static int mlp_fwd_impl(const void* packed, const float* rays_o, const float* ra
   const bool legacy = !chain_use_stream(n, stash != nullptr);
   // inference: the 16x16x32-shape stream unless option infer_shape32 asks for the 32x32x16 one (A/B)
   const bool shape16 = !legacy && stash == nullptr && !options().infer_shape32;
+  const bool img16 = stash != nullptr && !stash_fp8(n);
   const void* kernel = legacy ? (stash != nullptr ? (const void*)mlp_fwd_kernel<true> : (const void*)mlp_fwd_kernel<false>)
-                              : (stash != nullptr ? (const void*)mlp_fwd_stream_kernel<true>
+                              : (stash != nullptr ? (img16 ? (const void*)mlp_fwd_stream_kernel<true, true> : (const void*)mlp_fwd_stream_kernel<true>)
                                                   : (shape16 ? (const void*)mlp_fwd_stream16_kernel : (const void*)mlp_fwd_stream_kernel<false>));
   if (int rc = ensure_dynamic_lds(kernel, kChainLds, "nerf_mlp_fwd"); rc != NERF_OK) return rc;
   static unsigned long long* dbg = nullptr;
@@ -446,6 +459,8 @@ static int mlp_fwd_impl(const void* packed, const float* rays_o, const float* ra
     hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else if (legacy)
     hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  else if (stash != nullptr && img16)
+    hipLaunchKernelGGL((mlp_fwd_stream_kernel<true, true>), dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else if (stash != nullptr)
     hipLaunchKernelGGL(mlp_fwd_stream_kernel<true>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else if (shape16)

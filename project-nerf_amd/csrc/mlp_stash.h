@@ -30,7 +30,10 @@ inline bool chain_use_stream(int64_t n, bool training) {
 // activations (forward) and e5m2 pre-activation gradients (dgrad), both consumed by
 // v_mfma_f32_32x32x16_bf8_fp8 in the wgrad kernel -- half the bytes of every image crosses HBM
 // (step traffic 5.8 -> 3.0 GB at 4096 x 64 samples).  The compiler-scheduled family keeps bf16.
-inline bool stash_fp8(int64_t n) { return chain_use_stream(n, true); }
+// DEFAULT: bf16 images -- every MFMA of the training step then contracts bf16 operands, the precision BASELINE.json
+// configs[1] names.  Option stash_fp8 (NERF_STASH_FP8=1) selects the 8-bit images (narrower than the config's
+// precision: reported as a labelled secondary figure by bench.py, never as the headline).
+inline bool stash_fp8(int64_t n) { return options().stash_fp8 != 0 && chain_use_stream(n, true); }
 // divisor of the activation images before the e4m3 conversion (a power of two).  1: the image
 // saturates at 448 and flushes below 2^-10; the chain's own bf16 values are unaffected.
 constexpr float kActScale = 1.0f;

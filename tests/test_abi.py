@@ -53,17 +53,22 @@ def test_ctypes_table_matches_header(lib):
 
 def test_load_and_size_queries(lib):
     h = lib.load()
-    assert h.nerf_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "nerf_hip.h")).read()
+    declared = int(re.search(r"#define NERF_ABI_VERSION (\d+)", header).group(1))
+    assert h.nerf_abi_version() == declared == lib.ABI_VERSION      # header, library and binding move together
     assert h.nerf_mlp_packed_bytes() % 256 == 0 and h.nerf_mlp_packed_bytes() > 2 * 1024 * 1024
     assert h.nerf_mlp_stash_bytes(0) == 0
     per_sample = h.nerf_mlp_stash_bytes(262144) / 262144
-    assert 2700 < per_sample < 3000          # 2.5 KB of e4m3 layer inputs + 0.3 KB of relu bits per sample
-    h.nerf_set_option(b"chain_legacy", 1)
+    assert 5000 < per_sample < 6000          # default: bf16 images of every layer input + 0.3 KB of relu bits per sample
+    h.nerf_set_option(b"stash_fp8", 1)
     try:
         per_sample = h.nerf_mlp_stash_bytes(262144) / 262144
-        assert 5000 < per_sample < 6000      # compiler-scheduled family: bf16 images
+        assert 2700 < per_sample < 3000      # opt-in: 2.5 KB of e4m3 layer inputs + 0.3 KB of relu bits
+        h.nerf_set_option(b"chain_legacy", 1)
+        assert 5000 < h.nerf_mlp_stash_bytes(262144) / 262144 < 6000      # the compiler-scheduled family always writes bf16
     finally:
         h.nerf_set_option(b"chain_legacy", 0)
+        h.nerf_set_option(b"stash_fp8", 0)
 
 
 def test_ops_refuse_cpu_tensors(lib):

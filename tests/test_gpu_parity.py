@@ -229,13 +229,23 @@ def test_decoder_point_mode_vs_reference_golden(ops):
     np.testing.assert_allclose(sigma.cpu().numpy(), sb[:, 0].numpy(), atol=3e-3 * max(1.0, float(sb.max())))
 
 
+FAMILIES = ["asm-stream", "asm-stream-fp8", "compiler-scheduled"]
+
+
+def select_family(name):
+    """chain-kernel family and training-image width (library options chain_legacy / stash_fp8, include/nerf_hip.h):
+    asm-stream = the default (hand-scheduled streams, bf16 training images), asm-stream-fp8 = the opt-in 8-bit
+    images, compiler-scheduled = the hipcc-scheduled kernels (bf16 images)."""
+    from project_nerf_amd import _lib
+    _lib.set_option("chain_legacy", 1 if name == "compiler-scheduled" else 0)
+    _lib.set_option("stash_fp8", 1 if name == "asm-stream-fp8" else 0)
+
+
 @pytest.fixture
 def chain_family(request):
-    """selects the chain-kernel family (library option chain_legacy, see include/nerf_hip.h)"""
-    from project_nerf_amd import _lib
-    _lib.set_option("chain_legacy", 1 if request.param == "compiler-scheduled" else 0)
+    select_family(request.param)
     yield request.param
-    _lib.set_option("chain_legacy", 0)
+    select_family("asm-stream")
 
 
 @pytest.mark.parametrize("chain_family", ["asm-stream", "compiler-scheduled"], indirect=True)
@@ -395,7 +405,8 @@ def test_decoder_backward_in_two_parts_equals_one_launch(ops):
 
 def test_decoder_training_families_agree_over_multiple_passes(ops, monkeypatch):
     """1101 x 64 samples = 276 tiles > 256 CUs: the second pass of a workgroup (stash offsets, mask
-    words, look-ahead DMA) in both families of training kernels; they differ only in summation order."""
+    words, look-ahead DMA) in all three families of training kernels.  The two bf16-image families differ only in
+    summation order; the 8-bit images add their quantisation."""
     params = O.nerf_init_params(seed=11)
     R, S = 1101, 64
     o, d = synth_rays(R, 3)
@@ -405,30 +416,42 @@ def test_decoder_training_families_agree_over_multiple_passes(ops, monkeypatch):
     d_rgb, d_sigma = dev(torch.randn(n, 3, generator=gen)), dev(torch.randn(n, generator=gen))
     packed = ops.mlp_pack(dev(flat_params(params)))
     out = {}
-    for fam in ("compiler-scheduled", "asm-stream"):
-        ops._lib.set_option("chain_legacy", 1 if fam == "compiler-scheduled" else 0)
-        stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
-        rgb, sigma = ops.mlp_fwd(packed, dev(o), dev(d), dev(z), stash)
-        out[fam] = (rgb.cpu(), sigma.cpu(), ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb, d_sigma).cpu())
-    a, b = out["compiler-scheduled"], out["asm-stream"]
-    assert float((a[0] - b[0]).abs().max()) < 2e-2 and float((a[1] - b[1]).abs().max()) < 2e-2 * max(1.0, float(a[1].max()))
-    off = 0
-    for name, shape in O.nerf_param_shapes():
-        cnt = int(np.prod(shape))
-        ga, gb = a[2][off:off + cnt], b[2][off:off + cnt]
-        off += cnt
-        assert float((ga - gb).norm() / (ga.norm() + 1e-12)) < 0.12, name   # 8-bit vs bf16 training images, random upstream gradients
+    try:
+        for fam in FAMILIES:
+            select_family(fam)
+            stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
+            rgb, sigma = ops.mlp_fwd(packed, dev(o), dev(d), dev(z), stash)
+            out[fam] = (rgb.cpu(), sigma.cpu(), ops.mlp_bwd(packed, stash, rgb, sigma, d_rgb, d_sigma).cpu())
+    finally:
+        select_family("asm-stream")
+    a = out["compiler-scheduled"]
+    for fam, bound in (("asm-stream", 2e-2), ("asm-stream-fp8", 0.12)):
+        b = out[fam]
+        assert float((a[0] - b[0]).abs().max()) < 2e-2 and float((a[1] - b[1]).abs().max()) < 2e-2 * max(1.0, float(a[1].max()))
+        off = 0
+        for name, shape in O.nerf_param_shapes():
+            cnt = int(np.prod(shape))
+            ga, gb = a[2][off:off + cnt], b[2][off:off + cnt]
+            off += cnt
+            # bf16 images in both: the same operands, another summation order (and the ReLU flips of the forward's);
+            # 8-bit against bf16 training images on random upstream gradients: 0.12
+            assert float((ga - gb).norm() / (ga.norm() + 1e-12)) < bound, (fam, name)
 
 
-@pytest.mark.parametrize("chain_family", ["asm-stream", "compiler-scheduled"], indirect=True)
+# per-tensor bound against the fp32 oracle's gradients, stated from measurement (profiles/r03_measurements.md: bf16
+# images rel <= 0.107 / cos >= 0.9943, 8-bit images rel <= 0.130 / cos >= 0.9916 on these inputs)
+FP32_GRAD_BOUND = {"asm-stream": (0.13, 0.992), "compiler-scheduled": (0.13, 0.992), "asm-stream-fp8": (0.2, 0.98)}
+
+
+@pytest.mark.parametrize("chain_family", FAMILIES, indirect=True)
 @pytest.mark.parametrize("R,S", [(2, 64), (40, 64), (9, 128)])
 def test_decoder_backward_vs_oracle_autograd(ops, R, S, chain_family):
-    """dgrad chain + wgrad vs autograd of the oracle, for both families of chain kernels.
+    """dgrad chain + wgrad vs autograd of the oracle, for every family of chain kernels.
     * against the oracle evaluated with the SAME rounding points (bf16 operands, fp32 accumulate; for the
-      asm-stream family also the 8-bit training images): per-tensor relative L2 error <= 2e-2 -- this is
-      the correctness bar;
+      opt-in 8-bit training images also their e4m3 / e5m2 rounding): per-tensor relative L2 error <= 2e-2;
     * against the pure fp32 oracle: bf16 rounding and the ReLU masks it flips accumulate over the
-      10 chained layers, stated tolerance: cosine >= 0.98 and relative L2 error <= 0.2 per tensor."""
+      10 chained layers -- bound per family in FP32_GRAD_BOUND (bf16 images: relative L2 <= 0.13, cosine >= 0.992;
+      the looser 0.2 / 0.98 only for the 8-bit opt-in)."""
     params = O.nerf_init_params(seed=3)
     o, d = synth_rays(R, 17)
     u = torch.rand(R, S, generator=torch.Generator().manual_seed(2))
@@ -444,8 +467,9 @@ def test_decoder_backward_vs_oracle_autograd(ops, R, S, chain_family):
     grads = ops.mlp_bwd(packed, stash, rgb, sigma, dev(d_rgb), dev(d_sigma)).cpu()
     pts, dirs = O.ray_points(o, d, z)
     ref32 = oracle_param_grads(params, pts, dirs, d_rgb, d_sigma)
-    # the asm-stream family contracts the weight gradients from 8-bit images, the compiler-scheduled one from bf16
-    ref16 = bf16_param_grads(params, pts, dirs, d_rgb, d_sigma, fp8_images=chain_family == "asm-stream")
+    ref16 = bf16_param_grads(params, pts, dirs, d_rgb, d_sigma, fp8_images=chain_family == "asm-stream-fp8")
+    max_rel, min_cos = FP32_GRAD_BOUND[chain_family]
+    worst = [0.0, 1.0]
     off = 0
     for name, shape in O.nerf_param_shapes():
         cnt = int(np.prod(shape))
@@ -455,12 +479,16 @@ def test_decoder_backward_vs_oracle_autograd(ops, R, S, chain_family):
         rel32 = float((g - ref32[name]).norm() / (ref32[name].norm() + 1e-12))
         cos32 = float((g * ref32[name]).sum() / (g.norm() * ref32[name].norm() + 1e-20))
         assert rel16 < 2e-2, (name, "bf16-matched", rel16)
-        assert rel32 < 0.2 and cos32 > 0.98, (name, "fp32", rel32, cos32)
+        assert rel32 < max_rel and cos32 > min_cos, (name, "fp32", rel32, cos32)
+        worst = [max(worst[0], rel32), min(worst[1], cos32)]
     assert off == grads.numel()
+    print(f"[grad parity vs fp32 oracle] {chain_family} R={R} S={S}: worst rel {worst[0]:.4f} cos {worst[1]:.5f}")
 
 
-def test_decoder_autograd_function_end_to_end(ops):
-    """decoder -> composite -> MSE through torch.autograd, against the reference's own gradients (g6)."""
+@pytest.mark.parametrize("chain_family", FAMILIES, indirect=True)
+def test_decoder_autograd_function_end_to_end(ops, chain_family):
+    """decoder -> composite -> MSE through torch.autograd, against the reference's own gradients (g6), with the
+    per-family bound of FP32_GRAD_BOUND (bf16 images: the tight one)."""
     params, _ = golden_params()
     g = golden("g6_render")
     flat = dev(flat_params(params)).requires_grad_(True)
@@ -474,15 +502,18 @@ def test_decoder_autograd_function_end_to_end(ops):
     assert abs(loss.item() - float(g["loss"])) < 2e-3
     loss.backward()
     grads = flat.grad.cpu()
-    off = 0
+    off, worst = 0, (0.0, 1.0)
     for name, shape in O.nerf_param_shapes():
         cnt = int(np.prod(shape))
         ref = T(g["dw:" + name])
         g_ = grads[off:off + cnt].reshape(shape)
         rel = float((g_ - ref).norm() / (ref.norm() + 1e-12))
         cos = float((g_ * ref).sum() / (g_.norm() * ref.norm() + 1e-20))
-        assert rel < 0.2 and cos > 0.98, (name, rel, cos)     # bf16 chain vs the reference's fp32 autograd
+        max_rel, min_cos = FP32_GRAD_BOUND[chain_family]
+        assert rel < max_rel and cos > min_cos, (name, rel, cos)     # bf16 chain vs the reference's fp32 autograd
+        worst = (max(worst[0], rel), min(worst[1], cos))
         off += cnt
+    print(f"[grad parity vs reference g6] {chain_family}: worst rel {worst[0]:.4f} cos {worst[1]:.5f}")
 
 
 # ------------------------------------------------------------------ a14
