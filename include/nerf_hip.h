@@ -131,6 +131,14 @@ int nerf_sample_compact_jitter(const float* rays_o, const float* rays_d, uint64_
                                const uint8_t* binary_grid, int resolution, float bound, float* z_out,
                                int* slot_of_sample, float* pts_compact, float* dirs_compact,
                                unsigned* active_count, nerf_stream_t stream);
+/* rays [first_ray, first_ray + n_rays) of a larger batch: sample g of this call draws uniform (first_ray * n_samples + g)
+ * of step `counter`, so data-parallel ranks that compact the shards of ONE global batch (same seed and counter, first_ray =
+ * the shard's first ray) jitter exactly as one GPU would with the whole batch. */
+int nerf_sample_compact_jitter_shard(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,
+                                     int64_t first_ray, int64_t n_rays, int n_samples, float near_plane, float far_plane,
+                                     const uint8_t* binary_grid, int resolution, float bound, float* z_out,
+                                     int* slot_of_sample, float* pts_compact, float* dirs_compact,
+                                     unsigned* active_count, nerf_stream_t stream);
 
 /* ---- hierarchical (inverse-CDF) fine sampling, opt-in extension --------------------
  * No reference counterpart (the reference has one stratified pass only); follows Mildenhall et al.

@@ -90,11 +90,20 @@ class NativeComm:
     def gather_row_bands(self, band: torch.Tensor, rows_total: int, dst: int = 0):
         """row bands of an image (parallel.shard_range split of ``rows_total``) -> the whole image on ``dst``"""
         from .parallel import shard_range
+        if band.device.type != "cuda":
+            raise NerfCommError("gather_row_bands: the band must live on the HIP device")
+        if band.dtype != torch.float32:                    # the wire format is fp32: a narrower band would be read past its end
+            raise TypeError(f"gather_row_bands: fp32 bands only, got {band.dtype}")
         band = band.contiguous()
-        per_row = band[0].numel() if band.shape[0] else 0
+        # the row shape comes from the tensor's trailing dimensions, so a rank whose band is EMPTY (rows_total < world)
+        # still joins the grouped send/recv with count 0 instead of raising on its own while its peers wait
+        per_row = 1
+        for d in band.shape[1:]:
+            per_row *= int(d)
         rows = [shard_range(rows_total, r, self.world) for r in range(self.world)]
-        if per_row == 0:                                   # an empty band carries no row shape: take it from a peer's
-            raise NerfCommError("gather_row_bands: empty band")
+        if band.shape[0] != rows[self.rank][1] - rows[self.rank][0]:
+            raise ValueError(f"gather_row_bands: rank {self.rank} holds {band.shape[0]} rows, its shard of {rows_total} has "
+                             f"{rows[self.rank][1] - rows[self.rank][0]}")
         counts = (i64 * self.world)(*[(b - a) * per_row for a, b in rows])
         out = torch.empty((rows_total,) + tuple(band.shape[1:]), device=band.device, dtype=torch.float32) if self.rank == dst else None
         _check(load().nerf_comm_gather_tiles(self._h, band.data_ptr(), counts, None if out is None else out.data_ptr(), dst,

@@ -35,6 +35,8 @@ PROTOTYPES = {
     "nerf_sample_compact": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, i32, f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_sample_compact_jitter": (i32, [c_ptr, c_ptr, ctypes.c_uint64, ctypes.c_uint64, i64, i32, f32, f32, c_ptr, i32, f32,
                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_sample_compact_jitter_shard": (i32, [c_ptr, c_ptr, ctypes.c_uint64, ctypes.c_uint64, i64, i64, i32, f32, f32, c_ptr, i32, f32,
+                                               c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_composite_fwd_indexed": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_composite_bwd_indexed": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, i64, i32, c_ptr, c_ptr, c_ptr]),
     "nerf_sample_pdf": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr, c_ptr]),

@@ -33,7 +33,7 @@ sample_compact_kernel(const float* __restrict__ rays_o, const float* __restrict_
                       const uint8_t* __restrict__ grid, int res, float bound, float scale,
                       float* __restrict__ z_out, int* __restrict__ slot_of_sample,
                       float* __restrict__ pts_c, float* __restrict__ dirs_c, unsigned* __restrict__ count,
-                      uint64_t key, uint64_t counter, int draw) {
+                      uint64_t key, uint64_t counter, int draw, uint64_t first_sample) {
   const int64_t total = n_rays * (int64_t)S;
   const int64_t span = (int64_t)kCompactThreads * kCompactPer;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -54,7 +54,7 @@ sample_compact_kernel(const float* __restrict__ rays_o, const float* __restrict_
         float z = depth_plain(s, S, step, near_p, far_p);
         if (u != nullptr || draw) {
           // draw: the jitter comes from the counter-based generator (common.h) instead of a [R,S] tensor of uniforms
-          const float uu = u != nullptr ? u[g] : squares_uniform(counter, (uint64_t)g, key);
+          const float uu = u != nullptr ? u[g] : squares_uniform(counter, first_sample + (uint64_t)g, key);
           float lo = z, hi = z;
           if (s > 0) lo = mul_rn(0.5f, add_rn(z, depth_plain(s - 1, S, step, near_p, far_p)));
           if (s < S - 1) hi = mul_rn(0.5f, add_rn(depth_plain(s + 1, S, step, near_p, far_p), z));
@@ -116,7 +116,7 @@ static int sample_compact_impl(const float* rays_o, const float* rays_d, const f
                                int n_samples, float near_plane, float far_plane, const uint8_t* binary_grid,
                                int resolution, float bound, float* z_out, int* slot_of_sample, float* pts_compact,
                                float* dirs_compact, unsigned* active_count, nerf_stream_t stream,
-                               uint64_t key, uint64_t counter, int draw) {
+                               uint64_t key, uint64_t counter, int draw, uint64_t first_sample = 0) {
   NERF_REQUIRE(n_rays >= 0 && n_samples >= 2 && resolution > 0 && resolution <= 32768 && bound > 0.0f, "nerf_sample_compact: bad sizes");
   NERF_REQUIRE(active_count != nullptr, "nerf_sample_compact: active_count is NULL");
   if (hipMemsetAsync(active_count, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
@@ -131,7 +131,7 @@ static int sample_compact_impl(const float* rays_o, const float* rays_d, const f
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(sample_compact_kernel, dim3((int)blocks), dim3(kCompactThreads), 0, as_stream(stream), rays_o, rays_d, u, n_rays,
                      n_samples, near_plane, far_plane, step, binary_grid, resolution, bound, scale, z_out, slot_of_sample,
-                     pts_compact, dirs_compact, active_count, key, counter, draw);
+                     pts_compact, dirs_compact, active_count, key, counter, draw, first_sample);
   return check_launch("nerf_sample_compact");
 }
 
@@ -143,13 +143,23 @@ extern "C" int nerf_sample_compact(const float* rays_o, const float* rays_d, con
                              slot_of_sample, pts_compact, dirs_compact, active_count, stream, 0, 0, 0);
 }
 
+extern "C" int nerf_sample_compact_jitter_shard(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,
+                                                int64_t first_ray, int64_t n_rays, int n_samples, float near_plane, float far_plane,
+                                                const uint8_t* binary_grid, int resolution, float bound, float* z_out,
+                                                int* slot_of_sample, float* pts_compact, float* dirs_compact,
+                                                unsigned* active_count, nerf_stream_t stream) {
+  NERF_REQUIRE(first_ray >= 0 && counter < ((uint64_t)1 << 24) && (first_ray + n_rays) * (int64_t)n_samples < ((int64_t)1 << 40),
+               "nerf_sample_compact_jitter: counter / batch out of range");
+  return sample_compact_impl(rays_o, rays_d, nullptr, n_rays, n_samples, near_plane, far_plane, binary_grid, resolution, bound,
+                             z_out, slot_of_sample, pts_compact, dirs_compact, active_count, stream, squares_key(seed), counter, 1,
+                             (uint64_t)first_ray * (uint64_t)n_samples);
+}
+
 extern "C" int nerf_sample_compact_jitter(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,
                                           int64_t n_rays, int n_samples, float near_plane, float far_plane,
                                           const uint8_t* binary_grid, int resolution, float bound, float* z_out,
                                           int* slot_of_sample, float* pts_compact, float* dirs_compact,
                                           unsigned* active_count, nerf_stream_t stream) {
-  NERF_REQUIRE(counter < ((uint64_t)1 << 24) && n_rays * (int64_t)n_samples < ((int64_t)1 << 40),
-               "nerf_sample_compact_jitter: counter / batch out of range");
-  return sample_compact_impl(rays_o, rays_d, nullptr, n_rays, n_samples, near_plane, far_plane, binary_grid, resolution, bound,
-                             z_out, slot_of_sample, pts_compact, dirs_compact, active_count, stream, squares_key(seed), counter, 1);
+  return nerf_sample_compact_jitter_shard(rays_o, rays_d, seed, counter, 0, n_rays, n_samples, near_plane, far_plane, binary_grid,
+                                          resolution, bound, z_out, slot_of_sample, pts_compact, dirs_compact, active_count, stream);
 }

@@ -97,15 +97,24 @@ extern "C" int nerf_comm_gather_tiles(nerf_comm_t comm, const float* tile, const
   if (comm->rank == root && !out) return fail(kInval, "nerf_comm_gather_tiles: NULL out on the root");
   hipStream_t s = static_cast<hipStream_t>(stream);
   COMM_CHECK(ncclGroupStart(), "ncclGroupStart");
-  if (mine > 0) COMM_CHECK(ncclSend(tile, (size_t)mine, ncclFloat32, root, comm->comm, s), "ncclSend");
+  // inside the group an error must not return before ncclGroupEnd(): an open group would swallow every later call
+  // of this thread.  The first failure is remembered, the remaining operations are skipped, the group is closed.
+  ncclResult_t first = ncclSuccess;
+  const char* what = "";
+  auto in_group = [&](ncclResult_t r, const char* op) {
+    if (first == ncclSuccess && r != ncclSuccess) { first = r; what = op; }
+  };
+  if (mine > 0) in_group(ncclSend(tile, (size_t)mine, ncclFloat32, root, comm->comm, s), "ncclSend");
   if (comm->rank == root) {
     int64_t off = 0;
-    for (int r = 0; r < comm->world; ++r) {
-      if (counts_host[r] > 0) COMM_CHECK(ncclRecv(out + off, (size_t)counts_host[r], ncclFloat32, r, comm->comm, s), "ncclRecv");
+    for (int r = 0; r < comm->world && first == ncclSuccess; ++r) {
+      if (counts_host[r] > 0) in_group(ncclRecv(out + off, (size_t)counts_host[r], ncclFloat32, r, comm->comm, s), "ncclRecv");
       off += counts_host[r];
     }
   }
-  COMM_CHECK(ncclGroupEnd(), "ncclGroupEnd");
+  const ncclResult_t end = ncclGroupEnd();
+  if (first != ncclSuccess) return fail(kComm, "%s: %s", what, ncclGetErrorString(first));
+  if (end != ncclSuccess) return fail(kComm, "ncclGroupEnd: %s", ncclGetErrorString(end));
   return 0;
 }
 

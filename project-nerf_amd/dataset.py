@@ -67,12 +67,16 @@ class BlenderDataset:
         self._directions = self._directions.to(device)
         return self
 
-    def sample_batch(self, batch_size, bg):
+    def sample_batch(self, batch_size, bg, shard=None):
         """Training batch from GPU-resident frames: one uniform draw over all pixels of all frames (the same
         distribution as the reference's three draws, dataset.py:147-150) and one kernel that forms the rays
-        AND the composited target rgb * a + bg * (1 - a) (run.py:317-322)."""
+        AND the composited target rgb * a + bg * (1 - a) (run.py:317-322).  ``shard`` = (lo, hi): every data-parallel
+        rank draws the SAME ``batch_size`` pixels (same torch seed on every rank) and forms rays [lo, hi) of them --
+        the ranks' batches are the shards of one global batch."""
         from . import ops
         idx = torch.randint(0, len(self) * self.H * self.W, (batch_size,), device=self.images.device)
+        if shard is not None:
+            idx = idx[shard[0]:shard[1]].contiguous()
         o, d, target, _ = ops.gather_batch(self.images, self.poses, idx, self.focal, self.scene_scale, bg=bg)
         return o, d, target
 

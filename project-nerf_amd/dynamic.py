@@ -103,6 +103,29 @@ def part3_regularisers(model, cfg, step, mean_delta_x, generator=None, probes=No
     return terms
 
 
+def part4_param_groups(model, lr):
+    """AdamW parameter groups of the reference's Part 4 loop (run.py:1684-1738): 2x the base rate for the three
+    deformation grids and the canonical grid, 5x for ``deform_decoder.displacement_scale``, 1x for the deformation MLP
+    and everything else (time modulation, canonical decoder)."""
+    groups = []
+    for name in ("deform_grid_start", "deform_grid_mid", "deform_grid_end"):
+        if hasattr(model, name):
+            groups.append({"params": list(getattr(model, name).parameters()), "lr": lr * 2.0, "name": name})
+    if not hasattr(model, "deform_grid_start") and hasattr(model, "deformation_grid"):
+        groups.append({"params": list(model.deformation_grid.parameters()), "lr": lr * 2.0, "name": "deformation_grid"})
+    if hasattr(model, "canonical_repr"):
+        groups.append({"params": list(model.canonical_repr.parameters()), "lr": lr * 2.0, "name": "canonical_repr"})
+    if hasattr(model, "deform_decoder"):
+        groups.append({"params": [model.deform_decoder.displacement_scale], "lr": lr * 5.0, "name": "displacement_scale"})
+        groups.append({"params": [p for n, p in model.deform_decoder.named_parameters() if "displacement_scale" not in n], "lr": lr,
+                       "name": "deform_decoder"})
+    excluded = ("deform_grid_start", "deform_grid_mid", "deform_grid_end", "deformation_grid", "canonical_repr", "deform_decoder")
+    others = [p for n, p in model.named_parameters() if not any(ex in n for ex in excluded)]
+    if others:
+        groups.append({"params": others, "lr": lr, "name": "others"})
+    return groups
+
+
 def run_dynamic(cfg, args):
     from .core import NeuralField
     from .dataset import DynamicDataset
@@ -128,14 +151,17 @@ def run_dynamic(cfg, args):
     test_set = DynamicDataset(args.data_dir, split, downscale, white_bkgd, cfg.get("scene_scale", 1.0))
     model = NeuralField(cfg).to(device)
     grid = None
-    if cfg.get("use_density_grid", True):
-        grid = DensityGrid(cfg.get("grid_resolution", 64), cfg.get("scene_bound", 1.5), cfg.get("grid_threshold", 0.01)).to(device)
+    # Part 3 builds the occupancy grid only around a hash-grid canonical field (run.py:985-1000), Part 4 always
+    # (run.py:1648-1661); resolution default 128 in both
+    if cfg.get("use_density_grid", True) and (not part3 or cfg.get("canonical_type", "nerf") == "instant"):
+        grid = DensityGrid(cfg.get("grid_resolution", 128), cfg.get("scene_bound", 1.5), cfg.get("grid_threshold", 0.01)).to(device)
     if args.checkpoint:
         ckpt = torch.load(args.checkpoint, map_location=device)
         model.load_state_dict(ckpt["model_state_dict"])
         if grid is not None and "density_grid" in ckpt:
             grid.load_state_dict(ckpt["density_grid"])
     bg = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)
+    eval_bg = bg                                    # validation / test always composite onto the dataset's background
 
     def evaluate(indices):
         model.eval()
@@ -145,7 +171,7 @@ def run_dynamic(cfg, args):
                 o, d, tgt, t = test_set.get_image_rays(idx, device)
                 o, d = o.reshape(-1, 3), d.reshape(-1, 3)
                 pred = torch.cat([render_rays(model, o[i:i + chunk], d[i:i + chunk], near, far, render_n, False, density_grid=grid,
-                                              times=t.expand(min(chunk, o.shape[0] - i), 1), bg_color=bg)[0]
+                                              times=t.expand(min(chunk, o.shape[0] - i), 1), bg_color=eval_bg)[0]
                                   for i in range(0, o.shape[0], chunk)], 0)
                 vals.append(compute_psnr_torch(pred.clamp(0, 1), tgt.reshape(-1, 3)))
         model.train()
@@ -153,13 +179,18 @@ def run_dynamic(cfg, args):
 
     best = 0.0
     if not args.eval_only:
-        opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=cfg.get("weight_decay", 1e-5))
+        # Part 3: one group (run.py:1016); Part 4: the reference's per-group learning rates (run.py:1684-1738)
+        opt = torch.optim.AdamW(model.parameters() if part3 else part4_param_groups(model, lr), lr=lr,
+                                weight_decay=cfg.get("weight_decay", 1e-5))
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=cfg.get("eta_min", 1e-4))
         warm, stop, decay = cfg.get("grid_warmup_iters", 256), cfg.get("grid_stop_ratio", 0.9), cfg.get("grid_decay", 0.95)
         active = 1.0
+        # random-background augmentation (run.py:1043-1044, 1771-1772): a fresh colour per step for target AND render
+        random_bg_start = cfg.get("random_bg_start", 0) if cfg.get("use_random_bg", False) else float("inf")
         model.train()
         for step in range(1, iters + 1):
             o, d, rgba, t = train_set.sample_random_rays(batch, device)
+            bg = torch.rand(3, device=device) if step >= random_bg_start else eval_bg
             target = rgba[:, :3] * rgba[:, 3:4] + bg * (1 - rgba[:, 3:4])
             pred, _, _, extras = render_rays(model, o, d, near, far, n_samples, True, density_grid=grid, times=t, bg_color=bg)
             loss_rgb = torch.nn.functional.mse_loss(pred, target)

@@ -152,7 +152,9 @@ class VanillaNerfEngine:
         mark("wgrad")
         if sync_grads is not None:
             sync_grads(self.grads)            # RCCL all-reduce (sum); averaged by grad_scale in apply_gradients
-        return loss[0]
+        # a copy, not a view of the scalar ring: the ring is cleared every 1024 steps, a caller that keeps loss
+        # tensors (to average them later) must not see them zeroed or overwritten
+        return loss[0].clone()
 
     def apply_gradients(self) -> None:
         self.step_count += 1
@@ -300,7 +302,7 @@ class InstantNgpEngine:
         cuts.append(self.levels.n_levels)
         return [(cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1) if cuts[k] < cuts[k + 1]]
 
-    def prepare_batch(self, rays_o: Tensor, rays_d: Tensor, n_samples: int = 128, u: Optional[Tensor] = None):
+    def prepare_batch(self, rays_o: Tensor, rays_d: Tensor, n_samples: int = 128, u: Optional[Tensor] = None, first_ray: int = 0):
         """Queues the data-only front of a step -- stratified depths, occupancy mask, compaction (rows a1-a4) --
         and the read-back of the active count WITHOUT waiting for it.  A loop that prepares batch i+1 before it
         runs step i never stalls on the count: it arrives while step i computes (the reference, and
@@ -311,7 +313,7 @@ class InstantNgpEngine:
             self._jitter_counter = getattr(self, "_jitter_counter", -1) + 1
             jitter = (self.seed, self._jitter_counter)
         return ops.sample_compact_async(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid, self.bound, u=u,
-                                        jitter=jitter)
+                                        jitter=jitter, first_ray=first_ray)
 
     def compute_gradients(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
                           u: Optional[Tensor] = None, sync_grads_async=None, reduce_dtype=None, prepared=None) -> Tensor:
@@ -343,12 +345,22 @@ class InstantNgpEngine:
                 wire = view.to(reduce_dtype)                      # comm plumbing: narrow, sum, widen
                 handles.append((sync_grads_async(wire), wire, view))
 
+        def table_slice(lo, hi):
+            e0 = 2 * int(self.levels.offset[lo])
+            e1 = 2 * (int(self.levels.offset[hi]) if hi < self.levels.n_levels else self.levels.entries)
+            return self.g_table[e0:e1]
+
         if n == 0:
+            # no active sample on THIS rank (its rays miss the occupied cells): zero gradients, but exactly the
+            # collectives its peers issue -- the tiny-MLP gradient, then one all-reduce per level group with the same
+            # element counts (mismatched collectives across ranks hang or corrupt memory in RCCL)
             self.g_net.zero_()
             pred = self.bg.expand(R, 3)
             loss = ((pred - target) ** 2).mean()
             reduce(self.g_net)
-            reduce(self.g_table)
+            if sync_grads_async is not None:
+                for lo, hi in self.level_groups():
+                    reduce(table_slice(lo, hi))
         else:
             rgb, sigma, ws = self._field(pts, dirs, True)
             P = lambda t: t.data_ptr()
@@ -364,9 +376,7 @@ class InstantNgpEngine:
             else:
                 for lo, hi in self.level_groups():
                     ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, level_range=(lo, hi), workspace=hws)
-                    e0 = 2 * int(self.levels.offset[lo])
-                    e1 = 2 * (int(self.levels.offset[hi]) if hi < self.levels.n_levels else self.levels.entries)
-                    reduce(self.g_table[e0:e1])
+                    reduce(table_slice(lo, hi))
             loss = loss[0]
         for h, wire, view in handles:
             if h is not None:

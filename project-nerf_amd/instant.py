@@ -46,7 +46,11 @@ def run_instant(cfg, args):
         raise ValueError("Part 2 Instant requires --data_dir pointing to a NeRF dataset root.")
     if not torch.cuda.is_available():
         raise RuntimeError("the NeRF hot path runs on a HIP device only (no CPU fallback)")
-    device = torch.device("cuda")
+    from . import parallel
+    rank, world = parallel.rank_world()              # data parallelism: see run.py's module docstring
+    main_rank = rank == 0
+    say = print if main_rank else (lambda *a, **k: None)
+    device = torch.device("cuda", torch.cuda.current_device())
     downscale, white_bkgd = cfg.get("downscale", 2), cfg.get("white_bkgd", True)
     near, far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
     n_samples = cfg.get("n_samples", 32)
@@ -68,17 +72,27 @@ def run_instant(cfg, args):
         if grid is not None and "density_grid" in ckpt:
             grid.load_state_dict(ckpt["density_grid"])
 
+    def render_band(o, d):
+        rows, width = o.shape[0], o.shape[1]
+        o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+        if o.shape[0] == 0:
+            return o.new_zeros(0, width, 3)
+        pred = torch.cat([render_rays(model, o[i:i + chunk], d[i:i + chunk], near, far, render_n, False,
+                                      white_bkgd=white_bkgd, density_grid=grid)[0]
+                          for i in range(0, o.shape[0], chunk)], 0)
+        return pred.view(rows, width, 3)
+
     def evaluate(ds, indices):
+        """PSNR over the given views; under data parallelism every rank renders a row band of each view, rank 0 gathers
+        (every rank must call this with the same indices; the value is valid on rank 0)"""
         model.eval()
         out = []
         with torch.no_grad():
             for idx in indices:
                 o, d, tgt = ds.get_image_rays(idx, device)
-                o, d = o.reshape(-1, 3), d.reshape(-1, 3)
-                pred = torch.cat([render_rays(model, o[i:i + chunk], d[i:i + chunk], near, far, render_n, False,
-                                              white_bkgd=white_bkgd, density_grid=grid)[0]
-                                  for i in range(0, o.shape[0], chunk)], 0)
-                out.append(compute_psnr_torch(pred.clamp(0, 1), tgt.reshape(-1, 3)))
+                pred = parallel.render_row_bands(render_band, o, d)
+                if main_rank:
+                    out.append(compute_psnr_torch(pred.reshape(-1, 3).clamp(0, 1), tgt.reshape(-1, 3)))
         model.train()
         return float(np.mean(out)) if out else 0.0
 
@@ -92,7 +106,15 @@ def run_instant(cfg, args):
     if use_engine:
         from .engine import InstantNgpEngine
         eng = InstantNgpEngine({**cfg, "scene_bound": cfg.get("scene_bound", 1.5), "grid_threshold": grid.threshold,
-                                "grid_resolution": grid.resolution, "train_iters": iters, "learning_rate": lr}, device=str(device))
+                                "grid_resolution": grid.resolution, "train_iters": iters, "learning_rate": lr}, device=str(device),
+                               seed=int(cfg.get("seed", 0) or 0), world_size=world)
+        local = batch // world                               # this rank's shard [lo, hi) of the step's global batch
+        lo, hi = rank * local, (rank + 1) * local
+        sync_async = parallel.allreduce_sum_async if world > 1 else None
+        wire = torch.bfloat16 if (world > 1 and cfg.get("dp_gradient_wire", "bf16") == "bf16") else None
+        if world > 1:
+            say(f">>> data parallel: {world} ranks x {local} rays (global batch {local * world}); table gradient all-reduced level "
+                f"group by level group ({'bf16' if wire is not None else 'fp32'} on the wire), clip after the all-reduce")
         with torch.no_grad():                               # start from the NeuralField's weights (its init or the checkpoint)
             eng.table.copy_(model.representation.encoding.params)
             eng.net.copy_(model.decoder.flat_parameters())
@@ -113,28 +135,31 @@ def run_instant(cfg, args):
         active, ahead = 1.0, []
 
         def draw():
-            o, d, target = train_set.sample_batch(batch, eng.bg)
-            return o, d, target, eng.prepare_batch(o, d, n_samples)
+            # every rank draws the same global batch of pixels (same torch seed) and forms rays [lo, hi) of it; the jitter of
+            # sample g of the shard is draw (lo * n_samples + g) of the step: the union over the ranks is one GPU's batch
+            o, d, target = train_set.sample_batch(local * world, eng.bg, shard=(lo, hi) if world > 1 else None)
+            return o, d, target, eng.prepare_batch(o, d, n_samples, first_ray=lo)
 
         for step in range(1, iters + 1):
             if not ahead:
                 ahead.append(draw())
             o, d, target, prepared = ahead.pop()
             ahead.append(draw())
-            loss_rgb = eng.train_step(o, d, target, n_samples, prepared=prepared)
+            loss_rgb = eng.train_step(o, d, target, n_samples, prepared=prepared, sync_grads_async=sync_async, reduce_dtype=wire)
             if step < iters * stop:
                 interval = 32 if step < iters * 0.1 else (128 if step < iters * 0.5 else 512)
                 if step >= warm and step % interval == 0:
                     active = eng.update_grid()
                     ahead.clear()                           # the waiting batch was compacted against the previous grid
             if step % log_every == 0:
-                print(f">>> Step {step}/{iters} | Loss {loss_rgb.item():.6f} | PSNR {compute_psnr(loss_rgb.item()):.2f} dB"
-                      f" | Skip: {(1 - active) * 100:.1f}%")
+                loss_val = parallel.mean_over_ranks(loss_rgb).item()
+                say(f">>> Step {step}/{iters} | Loss {loss_val:.6f} | PSNR {compute_psnr(loss_val):.2f} dB"
+                    f" | Skip: {(1 - active) * 100:.1f}%")
             if step % cfg.get("val_every", 500) == 0:
                 sync()
                 v = evaluate(test_set, val_idx)
-                print(f"    [Validation] PSNR: {v:.2f} dB")
-                if v > best:
+                say(f"    [Validation] PSNR: {v:.2f} dB")
+                if v > best and main_rank:
                     best = v
                     torch.save({"model_state_dict": model.state_dict(), "config": cfg, "step": step, "val_psnr": best,
                                 "density_grid": grid.state_dict()}, os.path.join(log_dir, "best_model.pth"))
@@ -148,8 +173,10 @@ def run_instant(cfg, args):
         val_idx = random.sample(range(len(test_set)), n_val)
         active = 1.0
         model.train()
+        local = batch // world
         for step in range(1, iters + 1):
-            o, d, rgba = train_set.sample_random_rays(batch, device)
+            o, d, rgba = train_set.sample_random_rays(local * world, device)       # same draw on every rank, own shard kept
+            o, d, rgba = (t[rank * local:(rank + 1) * local].contiguous() for t in (o, d, rgba))
             bg = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)
             target = rgba[:, :3] * rgba[:, 3:4] + bg * (1 - rgba[:, 3:4])
             pred, _, _ = render_rays(model, o, d, near, far, n_samples, True, white_bkgd=white_bkgd,
@@ -161,6 +188,7 @@ def run_instant(cfg, args):
                 loss = loss + torch.mean(torch.abs(p[1:] - p[:-1])) * tv_w
             opt.zero_grad()
             loss.backward()
+            parallel.allreduce_mean_grads_(list(model.parameters()))           # clip AFTER the all-reduce: the global norm
             torch.nn.utils.clip_grad_norm_(model.representation.parameters(), max_norm=1.0)
             torch.nn.utils.clip_grad_norm_(model.decoder.parameters(), max_norm=1.0)
             opt.step()
@@ -172,12 +200,12 @@ def run_instant(cfg, args):
                     active = grid.update(model, device=device, time=None)
                     model.train()
             if step % log_every == 0:
-                print(f">>> Step {step}/{iters} | Loss {loss.item():.6f} | PSNR {compute_psnr(loss_rgb.item()):.2f} dB"
-                      f" | Skip: {(1 - active) * 100:.1f}%")
+                say(f">>> Step {step}/{iters} | Loss {parallel.mean_over_ranks(loss).item():.6f} | PSNR "
+                    f"{compute_psnr(parallel.mean_over_ranks(loss_rgb).item()):.2f} dB | Skip: {(1 - active) * 100:.1f}%")
             if step % cfg.get("val_every", 500) == 0:
                 v = evaluate(test_set, val_idx)
-                print(f"    [Validation] PSNR: {v:.2f} dB")
-                if v > best:
+                say(f"    [Validation] PSNR: {v:.2f} dB")
+                if v > best and main_rank:
                     best = v
                     save = {"model_state_dict": model.state_dict(), "config": cfg, "step": step, "val_psnr": best}
                     if grid is not None:
@@ -185,5 +213,5 @@ def run_instant(cfg, args):
                     torch.save(save, os.path.join(log_dir, "best_model.pth"))
     n_eval = len(test_set) if args.render_n in (None, -1) else min(args.render_n, len(test_set))
     avg = evaluate(test_set, range(n_eval))
-    print(f">>> Test PSNR: {avg:.2f} dB (best validation {best:.2f} dB)")
+    say(f">>> Test PSNR: {avg:.2f} dB (best validation {best:.2f} dB)")
     return avg

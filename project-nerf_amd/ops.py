@@ -166,10 +166,11 @@ class CompactedSamples:
 
 def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_samples: int,
                          binary_grid: Tensor, bound: float, u: Optional[Tensor] = None,
-                         jitter: Optional[Tuple[int, int]] = None) -> CompactedSamples:
+                         jitter: Optional[Tuple[int, int]] = None, first_ray: int = 0) -> CompactedSamples:
     """``sample_compact`` without the host wait: same kernel, same outputs; the count comes back asynchronously.
     ``jitter=(seed, counter)`` (with ``u`` None): the stratified jitter is drawn inside the kernel (nerf_sample_compact_jitter)
-    instead of being read from a [R, S] tensor of uniforms."""
+    instead of being read from a [R, S] tensor of uniforms; ``first_ray``: these rays are rays [first_ray, first_ray + R)
+    of a larger batch (data-parallel shards of one global batch draw the jitter one GPU would draw)."""
     lib = _lib.load()
     rays_o, rays_d = _dev(rays_o, "rays_o"), _dev(rays_d, "rays_d")
     grid = _dev(binary_grid, "binary_grid", torch.bool)
@@ -183,9 +184,9 @@ def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float
     pts, dirs = torch.empty(max(n, 1), 3, device=dev), torch.empty(max(n, 1), 3, device=dev)
     count = torch.zeros(1, device=dev, dtype=torch.int32)
     if u is None and jitter is not None:
-        _lib.check(lib.nerf_sample_compact_jitter(_p(rays_o), _p(rays_d), int(jitter[0]), int(jitter[1]) & 0xFFFFFF, R, n_samples,
-                                                  near, far, _p(grid), grid.shape[0], float(bound), _p(z), _p(slots), _p(pts),
-                                                  _p(dirs), _p(count), _stream()), "nerf_sample_compact_jitter")
+        _lib.check(lib.nerf_sample_compact_jitter_shard(_p(rays_o), _p(rays_d), int(jitter[0]), int(jitter[1]) & 0xFFFFFF, int(first_ray),
+                                                        R, n_samples, near, far, _p(grid), grid.shape[0], float(bound), _p(z), _p(slots),
+                                                        _p(pts), _p(dirs), _p(count), _stream()), "nerf_sample_compact_jitter")
     else:
         _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
                                            float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),

@@ -19,6 +19,8 @@ def init_distributed(device_type: Optional[str] = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("NERF_SINGLE_DEVICE") or os.environ.get("NERF_BENCH_SINGLE_DEVICE"):
+        local_rank = 0            # rehearsal of the N > 1 control flow on a one-GPU box (tests only; use with NERF_DIST_BACKEND=gloo)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -28,8 +30,52 @@ def init_distributed(device_type: Optional[str] = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
+            if use_gpu:
+                torch.cuda.set_device(local_rank)
             dist.init_process_group(backend)
     return rank, local_rank, world
+
+
+def rank_world() -> Tuple[int, int]:
+    """(rank, world) of the initialised process group, (0, 1) without one"""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def mean_over_ranks(value: torch.Tensor) -> torch.Tensor:
+    """mean of a (scalar) tensor over the ranks -- logging only; every rank must call it"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        value = value.detach().clone()
+        dist.all_reduce(value, op=dist.ReduceOp.SUM)
+        value /= dist.get_world_size()
+    return value
+
+
+def allreduce_mean_grads_(params) -> None:
+    """module path (torch.optim on nn.Parameters): one summing all-reduce of the flattened gradients, averaged"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if grads:
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+
+def render_row_bands(render_fn, rays_o: torch.Tensor, rays_d: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
+    """Evaluation under data parallelism: rays_o / rays_d [H, W, 3]; every rank renders rows shard_range(H, rank, world)
+    with ``render_fn(o_band, d_band) -> [rows, W, C]`` and the bands are gathered on ``dst`` (None elsewhere).  A band
+    rendered alone is bit-identical to the same rows of the full frame (rays are independent)."""
+    rank, world = rank_world()
+    H = rays_o.shape[0]
+    lo, hi = shard_range(H, rank, world)
+    band = render_fn(rays_o[lo:hi].contiguous(), rays_d[lo:hi].contiguous())
+    return gather_row_bands(band, H, dst=dst)
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -88,6 +134,7 @@ def native_allreduce_sum_async(comm):
 
     def start(flat: torch.Tensor):
         side.wait_stream(torch.cuda.current_stream())
+        flat.record_stream(side)          # the caching allocator must not recycle the buffer while the side stream uses it
         with torch.cuda.stream(side):
             comm.allreduce_sum_(flat)
             event = torch.cuda.Event()

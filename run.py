@@ -8,6 +8,13 @@ Only the static hot path is built (modes part2_nerf, part2_instant); the loops b
 repository's own counterparts of run_part2 / run_part2_instant and drive the MI355X kernels
 through the reference's module surface (NeuralField, render_rays, DensityGrid, BlenderDataset).
 Checkpoints use the reference format: {"model_state_dict", "config"[, "step", "val_psnr", "density_grid"]}.
+
+Data parallelism (the reference is single-process): launched as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 run.py --config ...
+every rank holds a replica, forms ITS shard of one global batch (``batch_size`` stays the global batch), the flat
+gradients are summed over RCCL/xGMI (overlapped with the backward pass) and averaged, gradient clipping happens after
+the all-reduce, optimiser steps are replicated; evaluation renders row bands and gathers them on rank 0, which alone
+prints, logs and writes checkpoints.  The process group is created before the first GPU call.
 """
 import argparse
 import os
@@ -33,7 +40,11 @@ def run_part2(cfg, args):
         raise ValueError("Part 2 requires --data_dir pointing to a NeRF dataset root.")
     if not torch.cuda.is_available():
         raise RuntimeError("the NeRF hot path runs on a HIP device only (no CPU fallback)")
-    device = torch.device("cuda")
+    from project_nerf_amd import parallel
+    rank, world = parallel.rank_world()
+    main_rank = rank == 0
+    say = print if main_rank else (lambda *a, **k: None)
+    device = torch.device("cuda", torch.cuda.current_device())
     downscale, white_bkgd = cfg.get("downscale", 1), cfg.get("white_bkgd", True)
     scene_scale = cfg.get("scene_scale", 1.0)
     near, far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
@@ -54,7 +65,11 @@ def run_part2(cfg, args):
     model = NeuralField(cfg).to(device)
     if args.checkpoint:
         model.load_state_dict(torch.load(args.checkpoint, map_location=device)["model_state_dict"])
-        print(f">>> Loaded checkpoint: {args.checkpoint}")
+        say(f">>> Loaded checkpoint: {args.checkpoint}")
+    local_batch = batch_size // world                       # this rank's shard of the global batch
+    first_ray = rank * local_batch
+    if world > 1:
+        say(f">>> data parallel: {world} ranks x {local_batch} rays (global batch {local_batch * world}), RCCL all-reduce of the flat gradient")
 
     # The reference's default decoder shape trains on the flat-parameter engine (what bench.py times: one kernel for the
     # batch draw, fused compositing + loss + backward, fused Adam + weight repack); its weights are copied into the
@@ -65,50 +80,68 @@ def run_part2(cfg, args):
                   and (dec.pos_dim, dec.dir_dim) == (63, 27))
     if use_engine:
         from project_nerf_amd.engine import VanillaNerfEngine
-        tb = TensorBoardLogger(os.path.join(log_dir, "tensorboard"))
-        eng = VanillaNerfEngine(params=dec.flat_parameters(), device=str(device), lr=lr, near=near, far=far, white_bkgd=white_bkgd)
+        tb = TensorBoardLogger(os.path.join(log_dir, "tensorboard")) if main_rank else None
+        eng = VanillaNerfEngine(params=dec.flat_parameters(), device=str(device), lr=lr, near=near, far=far, white_bkgd=white_bkgd,
+                                world_size=world)
+        sync_async = parallel.allreduce_sum_async if world > 1 else None
 
         def sync_model():
             model.load_state_dict({**model.state_dict(), **eng.state_dict("decoder.")})
 
         for step in range(1, train_iters + 1):
-            rays_o, rays_d, target, z = train_set.train_batch(batch_size, n_samples, near, far, eng.bg, seed=cfg.get("seed", 0), counter=step)
-            loss = eng.train_step(rays_o, rays_d, target, n_samples, z=z)
+            # every rank forms rays [first_ray, first_ray + local_batch) of the step's global batch (same seed and counter)
+            rays_o, rays_d, target, z = train_set.train_batch(local_batch, n_samples, near, far, eng.bg, seed=cfg.get("seed", 0),
+                                                              counter=step, first_ray=first_ray)
+            loss = eng.train_step(rays_o, rays_d, target, n_samples, z=z, sync_grads_async=sync_async)
             if step % log_every == 0:
-                psnr = compute_psnr(loss.item())
-                print(f">>> Step {step}/{train_iters} | Loss {loss.item():.6f} | PSNR {psnr:.2f} dB")
-                tb.log_scalar("Train/Loss", loss.item(), step)
-                tb.log_scalar("Train/PSNR", psnr, step)
-            if save_every and step % save_every == 0:
+                loss_val = parallel.mean_over_ranks(loss).item()          # mean of the shards' means = the global batch's loss
+                psnr = compute_psnr(loss_val)
+                say(f">>> Step {step}/{train_iters} | Loss {loss_val:.6f} | PSNR {psnr:.2f} dB")
+                if not bool((eng.grads != 0).any()):
+                    # the reference's density head is a bare ReLU (src/decoders.py:78): once every density of the batches is
+                    # zero, every gradient is exactly zero and the run cannot recover
+                    say(">>> WARNING: all gradients are exactly zero -- every density of the batch is zero (dead ReLU density "
+                        "head); this run will not recover: restart with another `seed:` in the YAML")
+                if tb is not None:
+                    tb.log_scalar("Train/Loss", loss_val, step)
+                    tb.log_scalar("Train/PSNR", psnr, step)
+            if save_every and step % save_every == 0 and main_rank:
                 sync_model()
                 torch.save({"model_state_dict": model.state_dict(), "config": cfg},
                            os.path.join(ckpt_dir, f"model_step_{step:06d}.pth"))
         sync_model()
-        torch.save({"model_state_dict": model.state_dict(), "config": cfg}, os.path.join(ckpt_dir, "model_final.pth"))
-        tb.close()
+        if main_rank:
+            torch.save({"model_state_dict": model.state_dict(), "config": cfg}, os.path.join(ckpt_dir, "model_final.pth"))
+            tb.close()
     elif not args.eval_only:
-        tb = TensorBoardLogger(os.path.join(log_dir, "tensorboard"))
+        tb = TensorBoardLogger(os.path.join(log_dir, "tensorboard")) if main_rank else None
         optimizer = torch.optim.Adam(model.parameters(), lr=lr)
         bg = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)
         model.train()
         for step in range(1, train_iters + 1):
-            rays_o, rays_d, rgba = train_set.sample_random_rays(batch_size, device)
+            # module path: every rank draws the same global batch (same torch seed) and keeps its shard
+            rays_o, rays_d, rgba = train_set.sample_random_rays(local_batch * world, device)
+            rays_o, rays_d, rgba = (t[first_ray:first_ray + local_batch].contiguous() for t in (rays_o, rays_d, rgba))
             target = _target(rgba, bg)
             pred, _, _ = render_rays(model, rays_o, rays_d, near, far, n_samples, True, white_bkgd=white_bkgd)
             loss = torch.nn.functional.mse_loss(pred, target)
             optimizer.zero_grad()
             loss.backward()
+            parallel.allreduce_mean_grads_(list(model.parameters()))
             optimizer.step()
             if step % log_every == 0:
-                psnr = compute_psnr(loss.item())
-                print(f">>> Step {step}/{train_iters} | Loss {loss.item():.6f} | PSNR {psnr:.2f} dB")
-                tb.log_scalar("Train/Loss", loss.item(), step)
-                tb.log_scalar("Train/PSNR", psnr, step)
-            if save_every and step % save_every == 0:
+                loss_val = parallel.mean_over_ranks(loss).item()
+                psnr = compute_psnr(loss_val)
+                say(f">>> Step {step}/{train_iters} | Loss {loss_val:.6f} | PSNR {psnr:.2f} dB")
+                if tb is not None:
+                    tb.log_scalar("Train/Loss", loss_val, step)
+                    tb.log_scalar("Train/PSNR", psnr, step)
+            if save_every and step % save_every == 0 and main_rank:
                 torch.save({"model_state_dict": model.state_dict(), "config": cfg},
                            os.path.join(ckpt_dir, f"model_step_{step:06d}.pth"))
-        torch.save({"model_state_dict": model.state_dict(), "config": cfg}, os.path.join(ckpt_dir, "model_final.pth"))
-        tb.close()
+        if main_rank:
+            torch.save({"model_state_dict": model.state_dict(), "config": cfg}, os.path.join(ckpt_dir, "model_final.pth"))
+            tb.close()
 
     model.eval()
     psnrs = []
@@ -116,7 +149,11 @@ def run_part2(cfg, args):
     with torch.no_grad():
         for idx in range(n_eval):
             rays_o, rays_d, target = test_set.get_image_rays(idx, device)
-            pred = render_image_safe(render_image, model, rays_o, rays_d, near, far, render_n_samples, chunk, white_bkgd)
+            # row bands over the ranks, gathered on rank 0 (one rank: the whole frame)
+            pred = parallel.render_row_bands(
+                lambda o, d: render_image_safe(render_image, model, o, d, near, far, render_n_samples, chunk, white_bkgd), rays_o, rays_d)
+            if not main_rank:
+                continue
             pred = torch.clamp(pred, 0.0, 1.0)
             psnrs.append(compute_psnr_torch(pred, target))
             try:
@@ -126,7 +163,7 @@ def run_part2(cfg, args):
             except ImportError:
                 pass
     avg = float(np.mean(psnrs)) if psnrs else 0.0
-    print(f">>> Test PSNR: {avg:.2f} dB")
+    say(f">>> Test PSNR: {avg:.2f} dB")
     return avg
 
 
@@ -199,9 +236,19 @@ def main():
     with open(args.config, "r", encoding="utf-8") as f:
         cfg = yaml.safe_load(f)
     mode = cfg.get("mode")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # one process per GPU (torch.distributed.run): the process group -- RCCL over xGMI -- and the device are chosen
+        # BEFORE anything touches the GPU; replicas must start from the same weights and draw the same global batches,
+        # so a data-parallel run is always seeded (`seed:` in the YAML, default 0)
+        from project_nerf_amd import parallel
+        parallel.init_distributed("cuda")
+        cfg.setdefault("seed", 0)
     if cfg.get("seed") is not None:        # extension: the reference seeds nothing; a YAML `seed` makes a run repeatable
         torch.manual_seed(int(cfg["seed"]))
         np.random.seed(int(cfg["seed"]))
+        import random
+        random.seed(int(cfg["seed"]))
     if mode == "part1_fourier":
         run_part1(cfg, args)
     elif mode == "part2_nerf":
@@ -212,6 +259,10 @@ def main():
         run_part4(cfg, args)           # one loop for both dynamic modes (project-nerf_amd/dynamic.py)
     else:
         raise ValueError(f"mode {mode!r} is not built (part1_fourier, part2_nerf, part2_instant, part3, part4 are); see DESIGN.md")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

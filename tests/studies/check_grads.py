@@ -1,7 +1,9 @@
-"""Per-tensor gradient errors of the decoder backward (development aid): both kernel families against the
-fp32 oracle and against the oracle with the family's own rounding points."""
+"""Per-tensor gradient errors of the decoder backward: every kernel family against the fp32 oracle and against
+the oracle with the family's own rounding points.  Lives under tests/ because it calls the oracle (test
+infrastructure: nothing outside tests/, smoke() and bench.py's cpu_baseline may).
+    python tests/studies/check_grads.py [R S]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import project_nerf_amd  # noqa
@@ -19,12 +21,12 @@ d_rgb, d_sigma = torch.randn(n, 3, generator=gen), torch.randn(n, generator=gen)
 pts, dirs = O.ray_points(o, d, z)
 ref32 = T.oracle_param_grads(params, pts, dirs, d_rgb, d_sigma)
 packed = ops.mlp_pack(T.dev(T.flat_params(params)))
-for fam in ("asm-stream", "compiler-scheduled"):
-    ops._lib.set_option("chain_legacy", int(fam != "asm-stream"))
+for fam in T.FAMILIES:
+    T.select_family(fam)
     stash = torch.empty(ops.mlp_stash_bytes(n), dtype=torch.uint8, device="cuda")
     rgb, sigma = ops.mlp_fwd(packed, T.dev(o), T.dev(d), T.dev(z), stash)
     grads = ops.mlp_bwd(packed, stash, rgb, sigma, T.dev(d_rgb), T.dev(d_sigma)).cpu()
-    ref16 = T.bf16_param_grads(params, pts, dirs, d_rgb, d_sigma, fp8_images=fam == "asm-stream")
+    ref16 = T.bf16_param_grads(params, pts, dirs, d_rgb, d_sigma, fp8_images=fam == "asm-stream-fp8")
     print(f"== {fam}: stash {stash.numel() / n:.0f} B/sample")
     off = 0
     for name, shape in O.nerf_param_shapes():
@@ -33,4 +35,4 @@ for fam in ("asm-stream", "compiler-scheduled"):
         rel32 = float((g - ref32[name]).norm() / (ref32[name].norm() + 1e-12))
         cos32 = float((g * ref32[name]).sum() / (g.norm() * ref32[name].norm() + 1e-20))
         print(f"{name:28s} matched {rel16:.4f}  fp32 {rel32:.4f} cos {cos32:.5f}  |g| {float(g.norm()):.3e}")
-ops._lib.set_option("chain_legacy", 0)
+T.select_family("asm-stream")

@@ -193,3 +193,39 @@ def test_bench_two_rank_control_flow_on_one_device(workload, tmp_path):
     else:
         assert set(out["kernels_in_step"]) >= {"fwd", "loss", "dgrad", "wgrad", "adam+pack"}
         assert all(v["ms"] > 0 for v in out["kernels_in_step"].values())
+
+
+def test_instant_rank_without_active_samples_issues_the_same_collectives():
+    """A rank whose whole shard misses the occupied cells (n == 0) must enter exactly the collectives its peers
+    enter -- same order, same element counts, same wire dtype -- or RCCL hangs / corrupts memory (round-2 advisor
+    finding: the empty branch all-reduced the whole table in one call, the others per level group)."""
+    from project_nerf_amd.engine import InstantNgpEngine
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    R, S = 256, 32
+    o, d, target, g = _rays(R, 21)
+    u = torch.rand(R, S, generator=g).cuda()
+    eng = InstantNgpEngine(cfg, seed=0)
+
+    def schedule(grid, wire):
+        calls = []
+        eng.binary_grid = grid
+        loss = eng.compute_gradients(o, d, target, S, u=u, sync_grads_async=lambda v: calls.append((v.numel(), v.dtype)), reduce_dtype=wire)
+        assert torch.isfinite(loss)
+        return calls
+    full = torch.ones(128, 128, 128, dtype=torch.bool, device="cuda")
+    for wire in (None, torch.bfloat16):
+        busy, idle = schedule(full, wire), schedule(torch.zeros_like(full), wire)
+        assert busy == idle and len(busy) == 1 + len(eng.level_groups()), (busy, idle)
+        assert sum(nel for nel, _ in busy[1:]) == eng.g_table.numel()
+    assert float(eng.g_table.abs().max()) == 0.0 and float(eng.g_net.abs().max()) == 0.0     # the idle rank contributes zeros
+
+
+def test_vanilla_loss_is_a_copy_not_a_view_of_the_scalar_ring():
+    from project_nerf_amd.engine import VanillaNerfEngine
+    o, d, target, g = _rays(64, 3)
+    eng = VanillaNerfEngine(seed=0)
+    first = eng.compute_gradients(o, d, target, 64)
+    kept = float(first)
+    eng._scalars.zero_()                                   # what happens to the ring every 1024 steps
+    eng.compute_gradients(o, d, target, 64)
+    assert float(first) == kept and kept > 0.0

@@ -40,7 +40,10 @@ def trained_vanilla(scene):
     # steps can push every density below zero, after which all gradients are exactly zero ("dead sigma").
     # Which way a run goes is decided by rounding-level noise (measured here: 4 of 10 runs of the bf16
     # kernels and 6 of 10 of the 8-bit-image kernels die within 100 steps, same seed, same box), so the
-    # fixture restarts from the next seed until the loss has left the all-white plateau.
+    # fixture restarts from the next seed until the loss has left the all-white plateau -- it SAYS which seeds it
+    # skipped, and more than two skipped seeds is a failure, not a retry (same-seed evidence that the fp32 torch trainer
+    # dies on the same model: tests/studies/collapse_study.py, profiles/r03_collapse_study.txt).
+    skipped = []
     for seed in range(8):
         eng = VanillaNerfEngine(seed=seed, lr=5e-4)
         torch.manual_seed(seed)
@@ -48,10 +51,14 @@ def trained_vanilla(scene):
             o, d, rgba = ds.sample_random_rays(4096, "cuda")
             loss = eng.train_step(o, d, rgba[:, :3] * rgba[:, 3:4] + (1 - rgba[:, 3:4]), 64)
             if step == 150 and float(loss) > 0.1:
+                skipped.append((seed, float(loss)))
                 break
         else:
+            print(f"[trained_vanilla] trained on seed {seed}; skipped (dead density at step 150): {skipped or 'none'}")
             return eng, {k[len("decoder."):]: v.cpu() for k, v in eng.state_dict().items()}
-    pytest.fail("no seed escaped the dead-density plateau")
+        if len(skipped) > 2:
+            pytest.fail(f"more than two seeds collapsed into the dead-density plateau: {skipped}")
+    pytest.fail(f"no seed escaped the dead-density plateau: {skipped}")
 
 
 def test_vanilla_trained_weights_psnr_delta_vs_fp32_oracle(scene, trained_vanilla):

@@ -4,9 +4,8 @@ import sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import project_nerf_amd
 from project_nerf_amd import ops
-from oracle import nerf_oracle as O
-params = O.nerf_init_params(seed=0)
-flat = torch.cat([params[k].reshape(-1) for k, _ in O.nerf_param_shapes()]).cuda()
+from project_nerf_amd.engine import default_init
+flat = default_init(0).cuda()
 packed = ops.mlp_pack(flat)
 def timeit(fn, it=10, warm=3):
     for _ in range(warm): fn()
