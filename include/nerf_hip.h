@@ -387,6 +387,15 @@ int nerf_composite_mse_bwd(const float* rgb, const float* sigma, const int* slot
                            const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
                            float loss_weight, int64_t n_rays, int n_samples, float* pred_out, float* loss_accum,
                            float* d_rgb, float* d_sigma, float* amax_accum, nerf_stream_t stream);
+/* ... with the displacement regulariser of the dynamic fields (Part 3 / 4): `extra` [n,3] (compact, like rgb) is
+ * composited with the same weights into extra_map [R,3] (optional) = render_rays' extras['mean_delta_x']
+ * (src/renderer.py:363-380), reg_accum += reg_weight * sum_rays |mean_delta_x|^2 (run.py:1838 with reg_weight =
+ * deformation_reg_weight / (3 n_rays)), and its gradient is added: d_extra [n,3] and, through the weights, d_sigma. */
+int nerf_composite_mse_reg_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
+                               const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
+                               float loss_weight, const float* extra, float reg_weight, int64_t n_rays, int n_samples,
+                               float* pred_out, float* extra_map, float* loss_accum, float* reg_accum, float* d_rgb,
+                               float* d_sigma, float* d_extra, nerf_stream_t stream);
 
 /* ---- a14: optimiser ---------------------------------------------------------
  * replaces torch.optim.Adam / AdamW .step() (run.py:307,338; run.py:546,629) for
@@ -408,6 +417,11 @@ int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  *                         norm = grad_scale * sqrt(*normsq_dev); normsq_dev NULL or max_norm <= 0: no clip. */
 int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
                    float* normsq_dev, nerf_stream_t stream);
+/* the same pass WITHOUT zeroing normsq_dev first: several parameter groups accumulate ONE global squared norm
+ * (torch.nn.utils.clip_grad_norm_(model.parameters()) of the Part 3 / 4 loops, run.py:1172, 1943); the caller
+ * zeroes the scalar once per step and hands it to every group's nerf_adamw_clip_step */
+int nerf_tv_normsq_accum(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
+                         float* normsq_dev, nerf_stream_t stream);
 int nerf_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                          int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                          const float* normsq_dev, float max_norm, float grad_scale, nerf_stream_t stream);
@@ -415,6 +429,45 @@ int nerf_adamw_clip_step(float* params, const float* grads, float* exp_avg, floa
 int nerf_adamw_clip_step_shadow(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                          int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                          const float* normsq_dev, float max_norm, float grad_scale, void* params_f16_out, nerf_stream_t stream);
+
+/* ---- f3: Part 4 dual-hash dynamic field (csrc/p4mlp.hip) ------------------------------------------------------
+ * replaces, for NeuralField(mode part4).forward (src/core.py:282-352), the tinycudann FullyFusedMLP networks
+ * HashDeformationDecoder.deform_net (src/decoders.py:285-295, 313-316) and InstantNeRFDecoder at pos_dim 32 + 21
+ * (src/decoders.py:111-134, 149-160 with src/core.py:222), the nn.Linear TimeModulationNetwork
+ * (src/decoders.py:321-371), the time Fourier code and the tri-grid blend (src/core.py:300-336).  Compiled for the
+ * reference's example shapes: time code L = 10 (21 columns), time modulation 21 -> 64 -> 64, deformation grids of at
+ * most 16 levels x 2 features, deformation decoder 88 -> 64 -> 64 -> 3, hidden 64, direction code L = 4.
+ * params_f32 [nerf_p4_param_count()]: T1W [64,21] T1b [64] T2W [64,64] T2b [64] | D1 [64,96] D2 [64,64] D3 [16,64] |
+ * S1 [64,64] S2 [16,64] | C1 [64,48] C2 [64,64] C3 [16,64] | displacement_scale [1] (module state-dict layouts).
+ * One workspace of nerf_p4_workspace_bytes(n) carries the hash-grid operand images and every training image:
+ * nerf_p4_workspace_offset(n, which): 0..2 nat images of the three deformation grids (write them with
+ * nerf_hash_encode_fwd*(..., out_nat)), 3 the canonical grid's; 4..6 d features [n,24] of the three deformation grids,
+ * 7 d features [n,32] of the canonical grid (read them with nerf_hash_encode_bwd*). */
+int64_t nerf_p4_param_count(void);
+size_t nerf_p4_packed_bytes(void);
+size_t nerf_p4_workspace_bytes(int64_t n);
+size_t nerf_p4_workspace_offset(int64_t n, int which);
+int nerf_p4_pack(const float* params_f32, void* packed, nerf_stream_t stream);
+/* per-sample inputs of the field (src/core.py:289-297): t' [n] = time of the sample's ray, x' [n,3] = its position; with
+ * coord_noise_std / time_noise_std > 0 (training, use_coord_noise) Gaussian noise from the counter-based generator keyed by
+ * (seed, counter) and the sample's index in the global batch (first_ray * n_samples + g), t' clamped to [0,1].
+ * n_samples > 0: slot_of_sample [n_rays * n_samples] maps samples to compact rows (-1 = skipped), ray_times [n_rays];
+ * n_samples == 0: point mode, n_rays points with ray_times per point.  x_deform may be NULL (no coordinate noise). */
+int nerf_p4_sample_inputs(const int* slot_of_sample, const float* pts_compact, const float* ray_times, int64_t n_rays,
+                          int n_samples, float coord_noise_std, float time_noise_std, uint64_t seed, uint64_t counter,
+                          int64_t first_ray, float* x_deform, float* t_deform, nerf_stream_t stream);
+/* deformation chain: delta_x [n,3] and x_canonical = pts + delta_x.  blend [n,3] or NULL: explicit weights of the
+ * three grids (the regulariser probes evaluate single grids) instead of the triangle weights of t'. */
+int nerf_p4_deform_fwd(const void* packed, const float* params_f32, void* workspace, const float* pts, const float* t_deform,
+                       const float* blend, int64_t n, float* delta_x, float* x_canonical, int train, nerf_stream_t stream);
+/* canonical chain on the canonical grid's features (workspace slot 3), t' and unit view directions */
+int nerf_p4_canon_fwd(const void* packed, void* workspace, const float* t_deform, const float* dirs, int64_t n, float* rgb,
+                      float* sigma, int train, nerf_stream_t stream);
+/* backward passes; parameter gradients are ACCUMULATED into grads_f32 [nerf_p4_param_count()] (zero it once per step) */
+int nerf_p4_canon_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma, const float* d_rgb,
+                      const float* d_sigma, int64_t n, float* grads_f32, nerf_stream_t stream);
+int nerf_p4_deform_bwd(const void* packed, const float* params_f32, void* workspace, const float* d_delta_x, int64_t n,
+                       float* grads_f32, nerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,19 @@ PROTOTYPES = {
     "nerf_imlp_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_adam_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, c_ptr]),
     "nerf_tv_normsq": (i32, [c_ptr, c_ptr, i64, f32, f32, c_ptr, c_ptr]),
+    "nerf_tv_normsq_accum": (i32, [c_ptr, c_ptr, i64, f32, f32, c_ptr, c_ptr]),
+    "nerf_composite_mse_reg_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, f32, c_ptr, f32, i64, i32, c_ptr, c_ptr,
+                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_p4_param_count": (i64, []),
+    "nerf_p4_packed_bytes": (size_t, []),
+    "nerf_p4_workspace_bytes": (size_t, [i64]),
+    "nerf_p4_workspace_offset": (size_t, [i64, i32]),
+    "nerf_p4_pack": (i32, [c_ptr, c_ptr, c_ptr]),
+    "nerf_p4_sample_inputs": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, ctypes.c_uint64, ctypes.c_uint64, i64, c_ptr, c_ptr, c_ptr]),
+    "nerf_p4_deform_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
+    "nerf_p4_canon_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
+    "nerf_p4_canon_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
+    "nerf_p4_deform_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
     "nerf_adamw_clip_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr]),
     "nerf_adamw_clip_step_shadow": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, c_ptr]),
 }

@@ -160,10 +160,23 @@ __global__ void __launch_bounds__(256) f32_to_f16_kernel(const float* __restrict
 
 }  // namespace nerf
 
+static int tv_normsq_impl(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
+                          float* normsq_dev, bool zero_first, nerf_stream_t stream);
+
 extern "C" int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
                               float* normsq_dev, nerf_stream_t stream) {
+  return tv_normsq_impl(params, grads, n, tv_weight, grad_scale, normsq_dev, true, stream);
+}
+
+extern "C" int nerf_tv_normsq_accum(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
+                                    float* normsq_dev, nerf_stream_t stream) {
+  return tv_normsq_impl(params, grads, n, tv_weight, grad_scale, normsq_dev, false, stream);
+}
+
+static int tv_normsq_impl(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
+                          float* normsq_dev, bool zero_first, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && normsq_dev, "nerf_tv_normsq: bad arguments");
-  if (hipMemsetAsync(normsq_dev, 0, sizeof(float), nerf::as_stream(stream)) != hipSuccess)
+  if (zero_first && hipMemsetAsync(normsq_dev, 0, sizeof(float), nerf::as_stream(stream)) != hipSuccess)
     return nerf::fail(NERF_ELAUNCH, "nerf_tv_normsq: memset failed");
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads, "nerf_tv_normsq: NULL pointer");

@@ -219,17 +219,23 @@ composite_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ si
 // above fused with the four elementwise / reduction launches of the loss in between.
 // amax_out (optional): running maximum of the vanilla decoder's output-layer derivatives
 // |d_rgb rgb (1 - rgb)| and |d_sigma| (sigma > 0), which nerf_mlp_bwd_dgrad_ex takes instead of its own pass.
+// extra / d_extra / reg_out (optional, Part 3 / 4): a per-sample 3-vector e_s (the displacement delta_x) composited
+// with the same weights, m = sum_s w_s e_s (render_rays' extras['mean_delta_x'], src/renderer.py:363-380), and the
+// regulariser reg_weight * |m|^2 added to the objective (run.py:1838: mean(mean_delta_x^2) * deformation_reg_weight
+// with reg_weight = deformation_reg_weight / (3 n_rays)): its gradient reaches e_s (d_extra) AND sigma (through w_s).
 template <int K>
 __global__ void __launch_bounds__(256)
 composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ sigma, const float* __restrict__ z,
                          const float* __restrict__ rays_d, const float* __restrict__ bg, int64_t bg_rows,
                          const float* __restrict__ target, float loss_weight, const int* __restrict__ slots, int64_t R, int S,
                          float* __restrict__ pred_out, float* __restrict__ loss_out, float* __restrict__ d_rgb,
-                         float* __restrict__ d_sigma, float* __restrict__ amax_out) {
+                         float* __restrict__ d_sigma, float* __restrict__ amax_out,
+                         const float* __restrict__ extra, float reg_weight, float* __restrict__ d_extra,
+                         float* __restrict__ reg_out, float* __restrict__ extra_map) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  float loss_local = 0.0f, amax = 0.0f;
+  float loss_local = 0.0f, amax = 0.0f, reg_local = 0.0f;
   for (int64_t r = wave; r < R; r += nwave) {
     RayCtx<K> c;
     float sg[K];
@@ -237,6 +243,7 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
     ray_setup<K>(sigma, z, rays_d, slots, r, S, lane, c, sg, row);
     float col[K][3], w[K];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, aw = 0.f;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int s = lane * K + k;
@@ -248,11 +255,24 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
           const float* p = rgb + row[k] * 3;
           col[k][0] = p[0]; col[k][1] = p[1]; col[k][2] = p[2];
           a0 += w[k] * p[0]; a1 += w[k] * p[1]; a2 += w[k] * p[2];
+          if (extra != nullptr) {
+            const float* e = extra + row[k] * 3;
+            m0 += w[k] * e[0]; m1 += w[k] * e[1]; m2 += w[k] * e[2];
+          }
         }
         aw += w[k];
       }
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); aw = wave_sum(aw);
+    float gm0 = 0.f, gm1 = 0.f, gm2 = 0.f;
+    if (extra != nullptr) {
+      m0 = wave_sum(m0); m1 = wave_sum(m1); m2 = wave_sum(m2);
+      gm0 = 2.0f * reg_weight * m0; gm1 = 2.0f * reg_weight * m1; gm2 = 2.0f * reg_weight * m2;
+      if (lane == 0) {
+        reg_local += reg_weight * (m0 * m0 + m1 * m1 + m2 * m2);
+        if (extra_map != nullptr) { extra_map[r * 3 + 0] = m0; extra_map[r * 3 + 1] = m1; extra_map[r * 3 + 2] = m2; }
+      }
+    }
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
     if (bg != nullptr) {
       const float* b = bg + (bg_rows > 1 ? r * 3 : 0);
@@ -276,6 +296,12 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
         float g = ga;
         if (row[k] >= 0) {
           g += gr0 * col[k][0] + gr1 * col[k][1] + gr2 * col[k][2];
+          if (extra != nullptr) {
+            const float* e = extra + row[k] * 3;
+            g += gm0 * e[0] + gm1 * e[1] + gm2 * e[2];
+            float* oe = d_extra + row[k] * 3;
+            oe[0] = w[k] * gm0; oe[1] = w[k] * gm1; oe[2] = w[k] * gm2;
+          }
           float* o = d_rgb + row[k] * 3;
           const float d0 = w[k] * gr0, d1 = w[k] * gr1, d2 = w[k] * gr2;
           o[0] = d0; o[1] = d1; o[2] = d2;
@@ -301,14 +327,16 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
     }
   }
   // one atomic per workgroup for the loss and for the maximum (same-address atomics serialise in L2)
-  __shared__ float part[8];
+  __shared__ float part[12];
   loss_local = wave_sum(loss_local);
+  reg_local = wave_sum(reg_local);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-  if (lane == 0) { part[threadIdx.x >> 6] = loss_local; part[4 + (threadIdx.x >> 6)] = amax; }
+  if (lane == 0) { part[threadIdx.x >> 6] = loss_local; part[4 + (threadIdx.x >> 6)] = amax; part[8 + (threadIdx.x >> 6)] = reg_local; }
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(loss_out, (part[0] + part[1]) + (part[2] + part[3]));
+    if (reg_out != nullptr) atomicAdd(reg_out, (part[8] + part[9]) + (part[10] + part[11]));
     if (amax_out != nullptr) {
       const float m = fmaxf(fmaxf(part[4], part[5]), fmaxf(part[6], part[7]));
       if (m == m && m < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, m));
@@ -429,6 +457,27 @@ extern "C" int nerf_composite_mse_bwd(const float* rgb, const float* sigma, cons
   if (blocks > 256 * 8) blocks = 256 * 8;
   const dim3 grid((int)blocks);
   DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
-             slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, amax_accum);
+             slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, amax_accum,
+             (const float*)nullptr, 0.0f, (float*)nullptr, (float*)nullptr, (float*)nullptr);
   return check_launch("nerf_composite_mse_bwd");
+}
+
+extern "C" int nerf_composite_mse_reg_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
+                                          const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
+                                          float loss_weight, const float* extra, float reg_weight, int64_t n_rays, int n_samples,
+                                          float* pred_out, float* extra_map, float* loss_accum, float* reg_accum, float* d_rgb,
+                                          float* d_sigma, float* d_extra, nerf_stream_t stream) {
+  NERF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 64 * kMaxPerLane,
+               "nerf_composite_mse_reg_bwd: n_rays=%lld n_samples=%d (max %d)", (long long)n_rays, n_samples, 64 * kMaxPerLane);
+  if (n_rays == 0) return NERF_OK;
+  NERF_REQUIRE(rgb && sigma && z && rays_d && target && loss_accum && d_rgb && d_sigma && extra && d_extra && reg_accum,
+               "nerf_composite_mse_reg_bwd: NULL pointer");
+  NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_mse_reg_bwd: bg_rows=%lld", (long long)bg_rows);
+  int64_t blocks = (n_rays + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const dim3 grid((int)blocks);
+  DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
+             slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, (float*)nullptr, extra, reg_weight, d_extra,
+             reg_accum, extra_map);
+  return check_launch("nerf_composite_mse_reg_bwd");
 }

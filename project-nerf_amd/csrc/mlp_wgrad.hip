@@ -49,7 +49,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p) {
 
 // LDS ring geometry of a stage: the decoder's jobs need 16 + 16 + 4 KiB, the Instant tiny-MLP jobs 4 + 4 + 2 KiB
 struct BigStage { static constexpr int A = kWgStageA, B = kWgStageB, Bytes = kWgStageBytes; };
-struct SmallStage { static constexpr int A = 4096, B = 4096, Bytes = 4096 + 4096 + 2048; };
+struct SmallStage { static constexpr int A = 4096, B = 4096, N = 2048, Bytes = 4096 + 4096 + 2048; };
+// the Part 4 tiny-MLP jobs (kinds 6..12): two natural-order tiles (the sigma-net's [hash | time code] input)
+struct SmallStageP4 { static constexpr int A = 4096, B = 4096, N = 4096, Bytes = 4096 + 4096 + 4096; };
 
 struct LaneGeo {
   int lane, wave, fhalf, off_acc, off_nat;
@@ -478,7 +480,11 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
 // The Instant tiny-MLP jobs (kinds 6..9) on their own: 10 KiB stages and few accumulators, so that several
 // workgroups share a CU -- the loop is barrier- and DMA-latency-bound on such small stages, a second and third
 // workgroup fill the waits of the first (the decoder's kernel holds 256 VGPRs and 144 KiB of LDS: one per CU)
+// P4 = false: the Part 2 Instant jobs (kinds 6..9); true: the Part 4 field's jobs (kinds 6..12, p4mlp.hip) -- its own
+// instantiation so that the three-tile jobs' registers do not lower the occupancy of the Instant step's kernel
+template <bool P4>
 __global__ void __launch_bounds__(512) mlp_wgrad_small_kernel(const WgradArgs args) {
+  using Stage = std::conditional_t<P4, SmallStageP4, SmallStage>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   LaneGeo g;
   g.lane = threadIdx.x & 63;
@@ -498,11 +504,19 @@ __global__ void __launch_bounds__(512) mlp_wgrad_small_kernel(const WgradArgs ar
     const long long a0 = lo > j0 ? lo - j0 : 0, a1 = (hi < j1 ? hi : j1) - j0;
     const int wt0 = (int)((a0 + job.cost - 1) / job.cost), wt1 = (int)((a1 + job.cost - 1) / job.cost);
     if (wt0 >= wt1) continue;
+    if constexpr (P4) {
+      switch (job.kind) {
+        case 10: run_job<2, 0, true, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;    // time modulation layer 2 (+ bias)
+        case 11: run_job<2, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;   // displacement decoder layer 1
+        case 12: run_job<0, 2, false, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;   // sigma-net layer 1 on [hash | time code]
+        default: break;
+      }
+    }
     switch (job.kind) {
-      case 6: run_job<0, 1, false, false, false, SmallStage>(args, job, wt0, wt1, smem, g); break;   // sigma-net layer 1
-      case 7: run_job<2, 0, false, false, false, SmallStage>(args, job, wt0, wt1, smem, g); break;   // 64-wide layers
-      case 8: run_job<1, 1, false, false, false, SmallStage>(args, job, wt0, wt1, smem, g); break;   // colour-net layer 1
-      default: run_job<2, 0, false, true, false, SmallStage>(args, job, wt0, wt1, smem, g); break;   // rgb layer
+      case 6: run_job<0, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); break;   // sigma-net layer 1
+      case 7: run_job<2, 0, false, false, false, Stage>(args, job, wt0, wt1, smem, g); break;   // 64-wide layers
+      case 8: run_job<1, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); break;   // colour-net layer 1
+      default: run_job<2, 0, false, true, false, Stage>(args, job, wt0, wt1, smem, g); break;   // rgb layer
     }
   }
 }
@@ -694,16 +708,18 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   if (args.slab == nullptr && zero_hi > zero_lo &&
       hipMemsetAsync(grads + zero_lo, 0, sizeof(float) * (zero_hi - zero_lo), stream) != hipSuccess)
     return fail(NERF_ELAUNCH, "nerf_mlp_bwd: memset failed");
-  bool small = args.amax == nullptr && args.slab == nullptr && !options().wgrad_big_only;
+  bool small = args.amax == nullptr && args.slab == nullptr && !options().wgrad_big_only, p4 = false;
   for (int j = 0; j < args.n_jobs; ++j) {
     const WgradJob& jb = args.jobs[j];
-    small = small && jb.kind >= 6 && jb.a_bytes <= SmallStage::A && jb.b_acc_bytes <= SmallStage::B && jb.b_nat_bytes <= 2048;
+    p4 = p4 || jb.kind >= 10;
+    small = small && jb.kind >= 6 && jb.a_bytes <= SmallStage::A && jb.b_acc_bytes <= SmallStage::B && jb.b_nat_bytes <= SmallStageP4::N;
   }
+  if (p4 && !small) return fail(NERF_EINVAL, "wgrad: Part 4 job kinds run on the small-stage kernel only");
   if (small) {
-    const int lds = kWgStages * SmallStage::Bytes;
     long long g3 = want < 1 ? 1 : (want > 3LL * n_cu ? 3LL * n_cu : want);
-    hipLaunchKernelGGL(mlp_wgrad_small_kernel, dim3((int)g3), dim3(512), lds, stream, args);
-    return check_launch("nerf_imlp_bwd (wgrad)");
+    if (p4) hipLaunchKernelGGL(mlp_wgrad_small_kernel<true>, dim3((int)g3), dim3(512), kWgStages * SmallStageP4::Bytes, stream, args);
+    else hipLaunchKernelGGL(mlp_wgrad_small_kernel<false>, dim3((int)g3), dim3(512), kWgStages * SmallStage::Bytes, stream, args);
+    return check_launch("tiny-MLP wgrad");
   }
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid), dim3(512), kWgLds, stream, args);
   if (args.slab != nullptr) {

@@ -1,0 +1,256 @@
+"""Part 4 on the fused HIP chains (csrc/p4mlp.hip; pytest -m gpu): the operator behind NeuralField('part4') and the
+flat-parameter DualHashEngine, against
+  * the reference's own Part 4 forward / autograd around the stand-in tinycudann (golden g14) -- bf16-MFMA chains against
+    fp32: tolerances stated from measurement below;
+  * the fp32 module path of this build (``fused_part4: false``: the same arithmetic composed from stand-alone operators,
+    itself pinned to g14 at fp32 tolerance by tests/test_gpu_part4.py);
+  * torch.optim.AdamW + clip_grad_norm_ with the reference's parameter groups for the optimiser step."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from test_gpu_part4 import PART4_CFG, part4_table
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def build_model(fused):
+    from src.core import NeuralField
+    g = golden("g14_part4")
+    m = NeuralField(dict(PART4_CFG, fused_part4=fused))
+    sd = m.state_dict()
+    for name, ph in (("canonical_repr", 0.0), ("deform_grid_start", 1.0), ("deform_grid_mid", 2.0), ("deform_grid_end", 3.0)):
+        sd[name + ".encoding.params"] = part4_table(sd[name + ".encoding.params"].numel(), ph)
+    sd["deformation_grid.encoding.params"] = sd["deform_grid_start.encoding.params"]
+    for k, v in g.items():
+        if k.startswith("w:"):
+            sd[k[2:]] = T(v)
+    m.load_state_dict(sd)
+    return m.cuda(), g
+
+
+@pytest.fixture(scope="module")
+def fused_model():
+    m, g = build_model(True)
+    assert m._p4_fused
+    return m.eval(), g
+
+
+@pytest.fixture(scope="module")
+def plain_model():
+    m, g = build_model(False)
+    assert not m._p4_fused
+    return m.eval(), g
+
+
+def rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def test_fused_forward_vs_reference_golden(fused_model):
+    m, g = fused_model
+    with torch.no_grad():
+        rgb, sigma, delta = m(T(g["pts"]).cuda(), T(g["dirs"]).cuda(), t=T(g["times"]).cuda())
+    assert rgb.shape == (400, 3) and sigma.shape == (400, 1) and delta.shape == (400, 3)
+    e_d = np.abs(delta.cpu().numpy() - g["delta"]).max()
+    e_c = np.abs(rgb.cpu().numpy() - g["rgb"]).max()
+    e_s = (np.abs(sigma.cpu().numpy() - g["sigma"]) / np.maximum(np.abs(g["sigma"]), 1.0)).max()
+    print(f"[part4 fused forward vs g14] max |d delta| {e_d:.2e} (|delta| max {np.abs(g['delta']).max():.2e}), |d rgb| {e_c:.2e}, rel d sigma {e_s:.2e}")
+    # bf16 operands, fp32 accumulation, fp16 hash features: stated tolerance
+    assert e_d < 3e-3 * max(1.0, float(np.abs(g["delta"]).max()) * 10) and e_c < 2e-2 and e_s < 3e-2
+
+
+def test_fused_gradients_vs_reference_autograd(fused_model):
+    m, g = fused_model
+    m.train()
+    m.zero_grad()
+    rgb, sigma, delta = m(T(g["pts"]).cuda(), T(g["dirs"]).cuda(), t=T(g["times"]).cuda())
+    ((rgb * T(g["w_rgb"]).cuda()).sum() + sigma.sum() + (delta * T(g["w_dx"]).cuda()).sum()).backward()
+    m.eval()
+    params = dict(m.named_parameters())
+    worst, checked = 0.0, 0
+    for k, v in g.items():
+        if k.startswith("g:"):
+            got, want = params[k[2:]].grad.cpu(), T(v)
+        elif k.startswith("gi:"):
+            got, want = params[k[3:]].grad.cpu()[T(v)], T(g["gv:" + k[3:]])
+        else:
+            continue
+        r = rel(got, want)
+        print(f"[part4 fused grads vs g14] {k:50s} rel {r:.4f}")
+        worst = max(worst, r)
+        checked += 1
+    assert checked >= 11 and worst < 6e-2, worst       # bf16 chains against the reference's fp32 autograd
+
+
+def batch(R, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(R, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * 4.0311
+    tgt = (torch.rand(R, 3, generator=g) - 0.5) * 1.6
+    d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o.cuda(), d.cuda(), torch.rand(R, 3, generator=g).cuda(), torch.rand(R, 1, generator=g).cuda()
+
+
+def make_engine(m, **over):
+    from project_nerf_amd.part4 import DualHashEngine
+    cfg = dict(PART4_CFG, grid_resolution=32, learning_rate=1e-2, train_iters=100, deformation_reg_weight=0.05, **over)
+    eng = DualHashEngine(cfg, seed=3)
+    eng.load_from_model(m)
+    return eng, cfg
+
+
+def test_engine_gradients_equal_module_path_autograd(plain_model):
+    """One batch through DualHashEngine.compute_gradients against torch autograd of the fp32 module path (render_rays with
+    times + MSE + the displacement regulariser) on the same samples."""
+    from src.renderer import DensityGrid, render_rays
+    from project_nerf_amd import ops
+    from project_nerf_amd.part4 import GRIDS, MODULE_SLICES
+    m, _ = plain_model
+    eng, cfg = make_engine(m, use_tv_displacement=False, tv_loss_weight=0.0)
+    R, S = 512, 32
+    o, d, target, t = batch(R, S, 5)
+    ax = torch.linspace(-1.5, 1.5, 32)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    eng.binary_grid = ((gx ** 2 + gy ** 2 + gz ** 2) < 1.2 ** 2).cuda()
+    torch.manual_seed(7)
+    u = torch.rand(R, S, device="cuda")                    # the draw render_rays makes below after the same seed
+    prepared = ops.sample_compact_async(o, d, 2.0, 6.0, S, eng.binary_grid, 1.5, u=u)
+    loss = float(eng.compute_gradients(o, d, target, t, S, prepared=(prepared, 1)))
+    reg = float(eng._scalars[1])
+    # the module path on the same batch
+    grid = DensityGrid(32, 1.5, 0.01).cuda()
+    grid.binary_grid = eng.binary_grid
+    m.train()
+    m.zero_grad()
+    torch.manual_seed(7)
+    pred, _, _, extras = render_rays(m, o, d, 2.0, 6.0, S, True, density_grid=grid, times=t, bg_color=eng.bg)
+    l_rgb = torch.nn.functional.mse_loss(pred, target)
+    l_reg = torch.mean(extras["mean_delta_x"] ** 2) * cfg["deformation_reg_weight"]
+    (l_rgb + l_reg).backward()
+    m.eval()
+    assert abs(loss - float(l_rgb)) < 2e-2 * float(l_rgb) and abs(reg - float(l_reg)) < 5e-2 * float(l_reg) + 1e-9, (loss, float(l_rgb), reg, float(l_reg))
+    sd = dict(m.named_parameters())
+    worst = 0.0
+    for key, off, cnt in MODULE_SLICES:
+        r = rel(eng.g_net[off:off + cnt].cpu(), sd[key].grad.reshape(-1).cpu())
+        print(f"[part4 engine vs module autograd] {key:45s} rel {r:.4f}")
+        worst = max(worst, r)
+    for k, name in enumerate(GRIDS):
+        r = rel(eng.g_table(k).cpu(), getattr(m, name).encoding.params.grad.cpu())
+        print(f"[part4 engine vs module autograd] {name:45s} rel {r:.4f}")
+        worst = max(worst, r)
+    assert worst < 8e-2, worst
+
+
+def test_engine_probe_regularisers_equal_module_path_autograd(plain_model):
+    """temporal smoothness / unsupervised consistency / tri-grid anchor through the engine's kernels against autograd of
+    dynamic.part4_regularisers on the golden's probe points"""
+    from project_nerf_amd.dynamic import part4_regularisers
+    from project_nerf_amd.part4 import GRIDS, MODULE_SLICES
+    m, g = plain_model
+    cfg = dict(PART4_CFG, use_unsupervised_consistency=True, grid_warmup_iters=8)
+    probes = {k[len("probe:"):]: T(v).cuda() for k, v in g.items() if k.startswith("probe:")}
+    m.train()
+    m.zero_grad()
+    terms = part4_regularisers(m, cfg, 32, T(g["r_mean_delta"]).cuda(), probes=probes)
+    (terms["temporal"] + terms["unsup"] + terms["anchor"]).backward()
+    m.eval()
+    eng, _ = make_engine(m)
+    eng.g_net.zero_(); eng.g_tables.zero_()
+    eng._probe_regularisers({
+        "temporal": (probes["temporal_x"], probes["temporal_t"], float(cfg.get("temporal_epsilon", 0.02)), float(cfg.get("temporal_smooth_weight", 1e-4))),
+        "unsup": (probes["unsup_x"], probes["unsup_t"], float(cfg.get("unsup_consistency_weight", 0.001))),
+        "anchor": (probes["anchor_x"], float(cfg.get("static_anchor_weight", 0.01)))})
+    sd = dict(m.named_parameters())
+    worst = 0.0
+    for key, off, cnt in MODULE_SLICES:
+        if sd[key].grad is None:
+            assert float(eng.g_net[off:off + cnt].abs().max()) == 0.0, key
+            continue
+        r = rel(eng.g_net[off:off + cnt].cpu(), sd[key].grad.reshape(-1).cpu())
+        print(f"[part4 probes vs module autograd] {key:45s} rel {r:.4f}")
+        worst = max(worst, r)
+    for k, name in enumerate(GRIDS[:2]):
+        r = rel(eng.g_table(k).cpu(), getattr(m, name).encoding.params.grad.cpu())
+        print(f"[part4 probes vs module autograd] {name:45s} rel {r:.4f}")
+        worst = max(worst, r)
+    assert float(eng.g_table(2).abs().max()) == 0.0 and float(eng.g_table(3).abs().max()) == 0.0
+    assert worst < 8e-2, worst
+
+
+def test_engine_optimizer_step_equals_adamw_with_reference_groups(plain_model):
+    """TV terms + ONE global-norm clip + AdamW with 2x / 5x / 1x rates and the cosine schedule, against torch.optim.AdamW
+    on the reference's parameter groups fed the same gradients"""
+    from project_nerf_amd.dynamic import part4_param_groups
+    from project_nerf_amd.part4 import GRIDS, MODULE_SLICES
+    m, _ = build_model(False)
+    eng, cfg = make_engine(m, tv_displacement_weight=3e-3, tv_loss_weight=2e-3)
+    gen = torch.Generator().manual_seed(11)
+    sd = dict(m.named_parameters())
+    opt = torch.optim.AdamW(part4_param_groups(m, cfg["learning_rate"]), weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=cfg["train_iters"], eta_min=1e-4)
+    tv = lambda p: torch.mean(torch.abs(p[1:] - p[:-1]))
+    for step in range(3):
+        m.zero_grad()
+        loss_tv = sum(tv(getattr(m, n).encoding.params) for n in GRIDS[:3]) * 3e-3 / 3.0 + tv(m.canonical_repr.encoding.params) * 2e-3
+        loss_tv.backward()
+        for key, off, cnt in MODULE_SLICES:
+            gr = torch.randn(cnt, generator=gen) * 0.05
+            eng.g_net[off:off + cnt].copy_(gr)
+            sd[key].grad = gr.view(sd[key].shape).cuda() + (0 if sd[key].grad is None else sd[key].grad)
+        for k, name in enumerate(GRIDS):
+            gr = torch.randn(eng.table_sizes[k], generator=gen) * 0.02
+            eng.g_table(k).copy_(gr)
+            getattr(m, name).encoding.params.grad += gr.cuda()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)
+        opt.step()
+        sched.step()
+        eng.apply_gradients()
+    for key, off, cnt in MODULE_SLICES:
+        np.testing.assert_allclose(eng.net[off:off + cnt].cpu().numpy(), sd[key].detach().reshape(-1).cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=key)
+    for k, name in enumerate(GRIDS):
+        np.testing.assert_allclose(eng.table(k).cpu().numpy(), getattr(m, name).encoding.params.detach().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(eng.table(k, half=True).float().cpu().numpy(), eng.table(k).half().float().cpu().numpy())
+
+
+def test_engine_trains_and_updates_its_grid(tmp_path):
+    """DualHashEngine on a small dynamic scene: the loss falls, the occupancy grid prunes, evaluation renders"""
+    from src.dataset import look_at_pose, render_analytic_frame
+    from project_nerf_amd.part4 import DualHashEngine
+    size, n_frames = 32, 6
+    focal = 0.5 * size / np.tan(0.5 * 0.6911112070083618)
+    poses = torch.stack([torch.tensor(look_at_pose(4.0311 * np.array([np.cos(k), np.sin(k), 0.5]) / np.sqrt(1.25)), dtype=torch.float32)
+                         for k in range(n_frames)]).cuda()
+    frames = torch.stack([render_analytic_frame(poses[k].cpu(), size, focal, 96) for k in range(n_frames)]).cuda()
+    times = torch.linspace(0, 1, n_frames).cuda()
+    from src.dataset import BlenderDataset
+    ds = BlenderDataset.from_tensors(frames, poses, 0.6911112070083618)
+    cfg = dict(PART4_CFG, grid_resolution=32, learning_rate=1e-2, train_iters=120, use_coord_noise=True, coord_noise_std=1e-3,
+               time_noise_std=1e-2, log2_hashmap_size=14, deform_log2_hashmap_size=12)
+    torch.manual_seed(0)
+    eng = DualHashEngine(cfg, seed=0)
+    from src.core import NeuralField
+    eng.load_from_model(NeuralField(cfg).cuda())
+    R, S = 2048, 32
+    losses = []
+    for step in range(1, 121):
+        idx = torch.randint(0, n_frames * size * size, (R,), device="cuda")
+        from project_nerf_amd import ops
+        o, d, target, _ = ops.gather_batch(frames, poses, idx, ds.focal, 1.0, bg=eng.bg)
+        t = times[idx // (size * size)].view(R, 1)
+        probes = None
+        if step % 16 == 0:
+            rnd = lambda *s: torch.rand(*s, device="cuda")
+            probes = {"temporal": ((rnd(64, 3) * 2 - 1) * 1.5, rnd(64, 1) * 0.98, 0.02, 1e-4), "anchor": ((rnd(128, 3) * 2 - 1) * 1.5, 0.01)}
+        losses.append(float(eng.train_step(o, d, target, t, S, probes=probes)))
+        if step in (60, 100):
+            ratio = eng.update_grid(decay=0.95)
+            assert 0.0 < ratio <= 1.0
+    assert np.mean(losses[-10:]) < 0.6 * np.mean(losses[:5]), (losses[:5], losses[-10:])
+    assert float(eng.net[30144]) != pytest.approx(0.1)          # displacement_scale moved (its own 5x group)
+    img = eng.render_image(*ds.get_image_rays(0, "cuda")[:2], times[0], S)
+    assert img.shape == (size, size, 3) and bool(torch.isfinite(img).all())
