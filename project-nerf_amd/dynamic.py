@@ -4,8 +4,9 @@ NeuralField('part4'), render_rays with per-ray times, AdamW + cosine LR, occupan
 time anchors, best-on-validation checkpoints, and the loss terms of the reference's loop
 (``part4_regularisers``: displacement magnitude, total variation on the deformation grids and on the canonical
 grid, temporal smoothness, unsupervised consistency, tri-grid anchor; run.py:1832-1938) with its YAML keys,
-defaults and every-n-steps schedule.  They are compositions of the field's own operators -- the hash encodings
-run in HIP with their table gradients, the small MLPs as library GEMMs."""
+defaults and every-n-steps schedule.  Part 4 at the reference's example shapes trains on part4.DualHashEngine (fused HIP
+chains, no torch autograd / optimiser / library GEMM in the loop); other shapes and Part 3 compose the field from the
+stand-alone operators (hash encodings and Fourier codes in HIP, the small MLPs as library GEMMs) under torch autograd."""
 import os
 
 import numpy as np
@@ -126,7 +127,32 @@ def part4_param_groups(model, lr):
     return groups
 
 
+def part4_probe_draws(cfg, step, device, generator=None):
+    """The random probe points of the reference's every-n-steps regularisers (run.py:1861-1938) in DualHashEngine's form, or
+    None on the steps that evaluate none of them: 64 temporal probes every 16th step, 128 anchor probes every 16th step,
+    128 consistency probes every 32nd step, all after the occupancy-grid warm-up."""
+    warm = cfg.get("grid_warmup_iters", 256)
+    if step <= warm or step % 16:
+        return None
+    bound = float(cfg.get("scene_bound", 1.5))
+    rand = lambda *shape: torch.rand(*shape, device=device, generator=generator)
+    probes = {}
+    if cfg.get("use_temporal_smooth", True):
+        eps = float(cfg.get("temporal_epsilon", 0.02))
+        probes["temporal"] = ((rand(64, 3) * 2 - 1) * bound, rand(64, 1) * (1.0 - eps), eps, float(cfg.get("temporal_smooth_weight", 1e-4)))
+    if cfg.get("use_unsupervised_consistency", False) and step % 32 == 0:
+        t = rand(128, 1)
+        probes["unsup"] = ((rand(128, 3) * 2 - 1) * bound, t, float(cfg.get("unsup_consistency_weight", 0.001)))
+    if cfg.get("use_static_anchor", True):
+        probes["anchor"] = ((rand(128, 3) * 2 - 1) * bound, float(cfg.get("static_anchor_weight", 0.01)))
+    return probes or None
+
+
 def run_dynamic(cfg, args):
+    """Part 3 / Part 4 loop.  Data parallelism as in run.py's module docstring: every rank forms its shard of one global
+    batch (same torch seed on every rank), gradients are summed over RCCL and averaged, the global-norm clip follows the
+    all-reduce, evaluation renders row bands gathered on rank 0."""
+    from . import parallel
     from .core import NeuralField
     from .dataset import DynamicDataset
     from .renderer import DensityGrid, render_rays
@@ -135,7 +161,10 @@ def run_dynamic(cfg, args):
         raise ValueError("Part 3 / Part 4 require --data_dir pointing to a D-NeRF dataset root.")
     if not torch.cuda.is_available():
         raise RuntimeError("the NeRF hot path runs on a HIP device only (no CPU fallback)")
-    device = torch.device("cuda")
+    rank, world = parallel.rank_world()
+    main_rank = rank == 0
+    say = print if main_rank else (lambda *a, **k: None)
+    device = torch.device("cuda", torch.cuda.current_device())
     downscale, white_bkgd = cfg.get("downscale", 2), cfg.get("white_bkgd", True)
     near, far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
     n_samples = cfg.get("n_samples", 64)
@@ -163,33 +192,111 @@ def run_dynamic(cfg, args):
     bg = torch.ones(3, device=device) if white_bkgd else torch.zeros(3, device=device)
     eval_bg = bg                                    # validation / test always composite onto the dataset's background
 
+    def render_band(o, d, t):
+        rows, width = o.shape[0], o.shape[1]
+        o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+        if o.shape[0] == 0:
+            return o.new_zeros(0, width, 3)
+        pred = torch.cat([render_rays(model, o[i:i + chunk], d[i:i + chunk], near, far, render_n, False, density_grid=grid,
+                                      times=t.expand(min(chunk, o.shape[0] - i), 1), bg_color=eval_bg)[0]
+                          for i in range(0, o.shape[0], chunk)], 0)
+        return pred.view(rows, width, 3)
+
     def evaluate(indices):
+        """every rank renders a row band of each view, rank 0 gathers and scores (valid on rank 0)"""
         model.eval()
         vals = []
         with torch.no_grad():
             for idx in indices:
                 o, d, tgt, t = test_set.get_image_rays(idx, device)
-                o, d = o.reshape(-1, 3), d.reshape(-1, 3)
-                pred = torch.cat([render_rays(model, o[i:i + chunk], d[i:i + chunk], near, far, render_n, False, density_grid=grid,
-                                              times=t.expand(min(chunk, o.shape[0] - i), 1), bg_color=eval_bg)[0]
-                                  for i in range(0, o.shape[0], chunk)], 0)
-                vals.append(compute_psnr_torch(pred.clamp(0, 1), tgt.reshape(-1, 3)))
+                pred = parallel.render_row_bands(lambda ob, db: render_band(ob, db, t), o, d)
+                if main_rank:
+                    vals.append(compute_psnr_torch(pred.reshape(-1, 3).clamp(0, 1), tgt.reshape(-1, 3)))
         model.train()
         return float(np.mean(vals)) if vals else 0.0
 
+    def save_best(step, value):
+        save = {"model_state_dict": model.state_dict(), "config": cfg, "step": step, "val_psnr": value}
+        if grid is not None:
+            save["density_grid"] = grid.state_dict()
+        torch.save(save, os.path.join(log_dir, "best_model.pth"))
+
     best = 0.0
-    if not args.eval_only:
+    local = batch // world                                  # this rank's shard [lo, hi) of the step's global batch
+    lo = rank * local
+    warm, stop, decay = cfg.get("grid_warmup_iters", 256), cfg.get("grid_stop_ratio", 0.9), cfg.get("grid_decay", 0.95)
+    # random-background augmentation (run.py:1043-1044, 1771-1772): a fresh colour per step for target AND render
+    random_bg_start = cfg.get("random_bg_start", 0) if cfg.get("use_random_bg", False) else float("inf")
+    from . import part4 as p4
+    use_engine = (not args.eval_only and not part3 and cfg.get("engine", True) and grid is not None
+                  and getattr(model, "_p4_fused", False) and p4.supported(cfg) is None)
+    if world > 1 and not args.eval_only:
+        say(f">>> data parallel: {world} ranks x {local} rays (global batch {local * world}); clip after the all-reduce")
+    if use_engine:
+        # The example shapes train on the flat-parameter engine (part4.DualHashEngine: fused chains, fused compositing + loss
+        # + regulariser + backward, one global-norm clip + AdamW with the reference's group rates, no torch autograd / optimiser
+        # / library GEMM in the loop); weights and occupancy grid are copied into the NeuralField / DensityGrid for
+        # validation, checkpoints and evaluation.  `engine: false` in the YAML or another shape: the module path below.
+        from . import ops
+        eng = p4.DualHashEngine({**cfg, "train_iters": iters, "learning_rate": lr, "grid_resolution": grid.resolution,
+                                 "grid_threshold": grid.threshold, "scene_bound": grid.bound}, device=str(device),
+                                seed=int(cfg.get("seed", 0) or 0), world_size=world)
+        eng.load_from_model(model)
+        with torch.no_grad():
+            eng.grid.copy_(grid.grid)
+            eng.binary_grid.copy_(grid.binary_grid)
+        sync_async = parallel.allreduce_sum_async if world > 1 else None
+        pixels = train_set.H * train_set.W
+
+        def sync():
+            eng.copy_to_model(model)
+            grid.grid, grid.binary_grid = eng.grid.clone(), eng.binary_grid.clone()
+
+        def draw(step):
+            # one uniform draw over all pixels of all frames (the same draw on every rank), this rank's shard of it; the time
+            # stamp of a ray is its frame's
+            idx = torch.randint(0, len(train_set) * pixels, (local * world,), device=device)[lo:lo + local].contiguous()
+            step_bg = torch.rand(3, device=device) if step >= random_bg_start else eval_bg
+            o, d, target, _ = ops.gather_batch(train_set.rgba, train_set.poses, idx, train_set.focal, train_set.scene_scale, bg=step_bg)
+            t = train_set.times[idx // pixels].view(-1, 1)
+            return o, d, target, t, step_bg, eng.prepare_batch(o, d, n_samples, first_ray=lo)
+
+        active, ahead = 1.0, []
+        for step in range(1, iters + 1):
+            if not ahead:
+                ahead.append(draw(step))
+            o, d, target, t, step_bg, prepared = ahead.pop()
+            if step < iters:
+                ahead.append(draw(step + 1))                # compaction of the next batch queued ahead of this step's kernels
+            loss_rgb = eng.train_step(o, d, target, t, n_samples, prepared=prepared, first_ray=lo, bg=step_bg,
+                                      sync_grads_async=sync_async, probes=part4_probe_draws(cfg, step, device))
+            if step < iters * stop:
+                interval = 32 if step < iters * 0.1 else (128 if step < iters * 0.5 else 512)
+                if step >= warm and step % interval == 0:
+                    active = eng.update_grid(decay=decay)   # three time anchors, running maximum (replicated)
+                    ahead.clear()                           # the waiting batch was compacted against the previous grid
+            if step % log_every == 0:
+                loss_val = parallel.mean_over_ranks(loss_rgb).item()
+                say(f">>> Step {step}/{iters} | Loss {loss_val:.6f} | PSNR {compute_psnr(loss_val):.2f} dB | LR {eng.lr():.6f}"
+                    f" | Skip: {(1 - active) * 100:.1f}%")
+            if step % cfg.get("val_every", 500) == 0 or step == iters:
+                sync()
+                v = evaluate(range(min(len(test_set), cfg.get("val_views", 4))))
+                say(f"    [Validation] PSNR: {v:.2f} dB")
+                if v > best and main_rank:
+                    best = v
+                    save_best(step, best)
+        sync()
+    elif not args.eval_only:
         # Part 3: one group (run.py:1016); Part 4: the reference's per-group learning rates (run.py:1684-1738)
         opt = torch.optim.AdamW(model.parameters() if part3 else part4_param_groups(model, lr), lr=lr,
                                 weight_decay=cfg.get("weight_decay", 1e-5))
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=cfg.get("eta_min", 1e-4))
-        warm, stop, decay = cfg.get("grid_warmup_iters", 256), cfg.get("grid_stop_ratio", 0.9), cfg.get("grid_decay", 0.95)
         active = 1.0
-        # random-background augmentation (run.py:1043-1044, 1771-1772): a fresh colour per step for target AND render
-        random_bg_start = cfg.get("random_bg_start", 0) if cfg.get("use_random_bg", False) else float("inf")
         model.train()
         for step in range(1, iters + 1):
-            o, d, rgba, t = train_set.sample_random_rays(batch, device)
+            o, d, rgba, t = train_set.sample_random_rays(local * world, device)         # the same draw on every rank
+            o, d, rgba, t = (x[lo:lo + local].contiguous() for x in (o, d, rgba, t))
             bg = torch.rand(3, device=device) if step >= random_bg_start else eval_bg
             target = rgba[:, :3] * rgba[:, 3:4] + bg * (1 - rgba[:, 3:4])
             pred, _, _, extras = render_rays(model, o, d, near, far, n_samples, True, density_grid=grid, times=t, bg_color=bg)
@@ -198,6 +305,7 @@ def run_dynamic(cfg, args):
             loss = loss_rgb + sum(regs(model, cfg, step, extras["mean_delta_x"]).values())
             opt.zero_grad()
             loss.backward()
+            parallel.allreduce_mean_grads_(list(model.parameters()))                    # clip AFTER the all-reduce
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=float(cfg.get("max_grad_norm", 1.0)))
             opt.step()
             sched.step()
@@ -216,18 +324,15 @@ def run_dynamic(cfg, args):
                     active = grid.update(model, device=device, decay=decay)      # three time anchors, running maximum
                     model.train()
             if step % log_every == 0:
-                print(f">>> Step {step}/{iters} | Loss {loss.item():.6f} | PSNR {compute_psnr(loss_rgb.item()):.2f} dB"
-                      f" | Skip: {(1 - active) * 100:.1f}%")
+                say(f">>> Step {step}/{iters} | Loss {parallel.mean_over_ranks(loss).item():.6f} | PSNR "
+                    f"{compute_psnr(parallel.mean_over_ranks(loss_rgb).item()):.2f} dB | Skip: {(1 - active) * 100:.1f}%")
             if step % cfg.get("val_every", 500) == 0 or step == iters:
                 v = evaluate(range(min(len(test_set), cfg.get("val_views", 4))))
-                print(f"    [Validation] PSNR: {v:.2f} dB")
-                if v > best:
+                say(f"    [Validation] PSNR: {v:.2f} dB")
+                if v > best and main_rank:
                     best = v
-                    save = {"model_state_dict": model.state_dict(), "config": cfg, "step": step, "val_psnr": best}
-                    if grid is not None:
-                        save["density_grid"] = grid.state_dict()
-                    torch.save(save, os.path.join(log_dir, "best_model.pth"))
+                    save_best(step, best)
     n_eval = len(test_set) if args.render_n in (None, -1) else min(args.render_n, len(test_set))
     avg = evaluate(range(n_eval))
-    print(f">>> Test PSNR: {avg:.2f} dB (best validation {best:.2f} dB)")
+    say(f">>> Test PSNR: {avg:.2f} dB (best validation {best:.2f} dB)")
     return avg

@@ -30,10 +30,32 @@ CONFIGS = {
 }
 
 
+CONFIGS["part4"] = dict(
+    mode="part4", downscale=1, white_bkgd=True, near=2.0, far=6.0, n_samples=32, render_n_samples=32, batch_size=2048, chunk=4096,
+    train_iters=48, learning_rate=1e-2, weight_decay=1e-5, eta_min=1e-4, max_grad_norm=1.0, log_every=4, val_every=10000,
+    use_tv_displacement=True, tv_displacement_weight=1e-4, tv_loss_weight=1e-6, deformation_reg_weight=1e-4,
+    use_temporal_smooth=True, use_static_anchor=True, use_unsupervised_consistency=True, use_coord_noise=True, coord_noise_std=1e-3,
+    time_noise_std=1e-2, use_random_bg=True, random_bg_start=24, deform_n_levels=12, deform_n_features_per_level=2,
+    deform_log2_hashmap_size=12, deform_base_resolution=16, deform_per_level_scale=1.5, deform_hidden_dim=64, L_embed_time=10,
+    time_modulation_dim=64, time_modulation_layers=2, n_levels=16, n_features_per_level=2, log2_hashmap_size=14, base_resolution=16,
+    per_level_scale=1.5, scene_bound=1.5, hidden_dim=64, use_density_grid=True, grid_resolution=32, grid_threshold=0.01,
+    grid_warmup_iters=8, grid_stop_ratio=0.9, seed=0)
+
+
 @pytest.fixture(scope="module")
 def scene(tmp_path_factory):
+    """static frames for Part 2, the same frames with time stamps (a D-NeRF style root) for Part 4"""
+    import json
     from src.dataset import write_synthetic_scene
-    return write_synthetic_scene(str(tmp_path_factory.mktemp("dp_scene") / "s"), n_train=8, n_test=2, size=48)
+    root = write_synthetic_scene(str(tmp_path_factory.mktemp("dp_scene") / "s"), n_train=8, n_test=2, size=48)
+    for split in ("train", "test"):
+        path = os.path.join(root, f"transforms_{split}.json")
+        meta = json.load(open(path))
+        n = len(meta["frames"])
+        for k, frame in enumerate(meta["frames"]):
+            frame["time"] = k / max(n - 1, 1)
+        json.dump(meta, open(path, "w"))
+    return root
 
 
 def _run(cfg_path, scene, log_dir, world, port):
@@ -70,7 +92,7 @@ def test_two_rank_cli_run_follows_the_single_rank_trajectory(mode, scene, tmp_pa
     # same global batch, same jitter, gradients summed and averaged: the trajectories agree up to summation order (float
     # atomics in the small launches' flush, bf16 rounding flips downstream of it)
     for a, b in zip(l1, l2):
-        assert abs(a - b) <= 2e-2 * max(a, 1e-3), (l1, l2)
-    assert abs(l1[0] - l2[0]) <= 2e-3 * l1[0], (l1[0], l2[0])              # the first logged steps: before any drift
+        assert abs(a - b) <= (5e-2 if mode == "part4" else 2e-2) * max(a, 1e-3), (l1, l2)
+    assert abs(l1[0] - l2[0]) <= (1e-2 if mode == "part4" else 2e-3) * l1[0], (l1[0], l2[0])   # the first logged steps: before any drift
     assert l1[-1] < l1[0]                                                  # and it trains
     assert abs(p1[0] - p2[0]) < 0.5, (p1, p2)                              # row-band evaluation = whole-frame evaluation
