@@ -156,7 +156,9 @@ def test_run_py_cli_part3_trains_and_evaluates(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Test PSNR" in r.stdout
     ckpt = torch.load(tmp_path / "out" / "dyn" / "best_model.pth", map_location="cpu")
-    assert "deform_net.net.0.weight" in ckpt["model_state_dict"] and "density_grid" in ckpt
+    # the occupancy grid exists only around a hash-grid canonical field (reference run.py:985-1000)
+    assert "deform_net.net.0.weight" in ckpt["model_state_dict"]
+    assert ("density_grid" in ckpt) == (cfg.get("canonical_type", "nerf") == "instant")
 
 
 def test_part3_loss_terms_schedule_and_gradients():
