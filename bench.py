@@ -200,8 +200,23 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
         "imlp_fwd": {"bound": "hbm", "kernel": "imlp_fwd_kernel<true>", "achieved": n * (64 + 12 + 16 + 2 * (64 + 16 + 64 + 64 + 48)) / k["imlp_fwd"] * 1e-6,
                      "note": "operand image in, rgb/sigma out, bf16 stash of every layer input"},
     }
-    for v in roof.values():
-        v.update({"peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": v["achieved"] / HBM_PEAK_GBS, "traffic": None})
+    # measured HBM bytes per launch from the committed rocprofv3 --pmc summary of `bench.py --workload instant`
+    # (tools/pmc_r03.sh: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes); multi-kernel entries sum
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_instant_pmc_summary.json")) as f:
+            pmc = json.load(f)
+    except OSError:
+        pass
+
+    def traffic(*names):
+        vals = [pmc.get(nm, {}).get("hbm_bytes_per_launch_corrected") for nm in names]
+        return sum(vals) if vals and all(v is not None for v in vals) else None
+    traffic_of = {"hash_fwd": ("hash_fwd_kernel<fp16 table>",),
+                  "hash_bwd": ("hash_bin_count_pm_kernel", "hash_bin_plan_kernel", "hash_bin_scatter_kernel<true>", "hash_bin_reduce_kernel"),
+                  "tv_clip_adamw(table)": ("tv_normsq_kernel<true>", "adamw_clip_kernel<true>"), "imlp_fwd": ("imlp_fwd_kernel<true>",)}
+    for name, v in roof.items():
+        v.update({"peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": v["achieved"] / HBM_PEAK_GBS, "traffic": traffic(*traffic_of[name])})
     H = W = 800
     focal = 0.5 * W / np.tan(0.5 * SYNTHETIC_CAMERA_ANGLE)
     c2w = torch.tensor(look_at_pose(4.0311 * np.array([0.6, 0.5, 0.62])), dtype=torch.float32)
@@ -233,6 +248,101 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
     if standalone:
         print(json.dumps(out))
     return out
+
+
+def bench_part4(args, device, steps=200):
+    """Part 4 dual-hash dynamic field (BASELINE.json configs[4], one GPU's share) on part4.DualHashEngine at
+    configs/part4.yaml.example: 8192 rays x 64 samples, 64^3 occupancy grid at ~12 % active cells (what training reaches
+    after pruning), 28.5 M parameters, the every-16th-step regulariser probes included.  HBM-bound (SURVEY 8(d) cfg C's
+    reasoning: hash gathers / scatters and parameter streaming); per-kernel-group rooflines with PMC traffic."""
+    import yaml
+    from src.core import NeuralField
+    from project_nerf_amd import ops
+    from project_nerf_amd import part4 as p4
+    from project_nerf_amd.dynamic import part4_probe_draws
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part4.yaml.example")))
+    torch.manual_seed(0)
+    model = NeuralField(cfg).to(device)
+    R, S = cfg["batch_size"], cfg["n_samples"]
+    o = torch.nn.functional.normalize(torch.randn(R, 3, device=device), dim=-1) * 4.03
+    d = torch.nn.functional.normalize(-o + 0.3 * torch.randn(R, 3, device=device), dim=-1)
+    t, target = torch.rand(R, 1, device=device), torch.rand(R, 3, device=device)
+    eng = p4.DualHashEngine(cfg, device=str(device), seed=0)
+    eng.load_from_model(model)
+    eng.binary_grid = torch.rand_like(eng.grid) < 0.12
+    step_no = [300]
+
+    def step():
+        step_no[0] += 1
+        return eng.train_step(o, d, target, t, S, probes=part4_probe_draws(cfg, step_no[0], device))
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # kernel groups launched back to back on the steady-state batch (HIP events on the launch stream)
+    z, slots, pts, dirs = ops.sample_compact(o, d, eng.near, eng.far, S, eng.binary_grid, eng.bound)
+    n = pts.shape[0]
+    ws = p4.Workspace(n, device)
+    _, t_def = p4.sample_inputs(slots, pts, t, R, S)
+    tabs = eng._tables_for_forward()
+    fwd = lambda: p4.forward_chain(eng.packed, eng.net, tabs, eng.levels_d, eng.levels_c, eng.bound, pts, None, t_def, dirs, ws, True)
+    rgb, sigma, dx, xc = fwd()
+    d_rgb, d_sigma, d_dx = torch.randn_like(rgb) * 1e-3, torch.randn_like(sigma) * 1e-3, torch.randn_like(dx) * 1e-3
+    g_tabs = [eng.g_table(i) for i in range(4)]
+    Ld, Lc = eng.levels_d.n_levels, eng.levels_c.n_levels
+    k = {
+        "hash_fwd (3 deformation grids + canonical)": event_ms(lambda: [ops.hash_encode_fwd(pts, tabs[i], eng.levels_d if i < 3 else eng.levels_c, eng.bound,
+                                                                                            want_f32=False, out_nat=ws.nat(i)) for i in range(4)], 20),
+        "hash_fwd + fused chains fwd": event_ms(fwd, 20),
+        "chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters": event_ms(
+            lambda: p4.backward_chain(eng.packed, eng.net, eng.table(3), eng.levels_d, eng.levels_c, eng.bound, pts, xc, ws, rgb, sigma, d_rgb, d_sigma,
+                                      d_dx.clone(), eng.g_net, g_tabs, hash_ws=eng._hash_scratch), 20),
+        "tv + clip + adamw (28.5 M parameters)": event_ms(eng.apply_gradients, 20),
+    }
+    n_par = eng.tables.numel() + eng.net.numel()
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_part4_pmc_summary.json")) as f:
+            pmc = json.load(f)
+    except OSError:
+        pass
+
+    def traffic(names):
+        vals = [pmc.get(nm, {}).get("hbm_bytes_per_launch_corrected") for nm in names]
+        return sum(v * c for v, c in zip(vals, names.values())) if vals and all(v is not None for v in vals) else None
+    # algorithmic bytes: forward gathers 8 corners x 4 B (fp16 pairs) per level and point; the scatter's read-modify-write 8 corners
+    # x 16 B (+ the canonical grid's input gradient: 8 corners x 8 B); the optimiser streams params / grads / moments
+    # (TV + norm: 12 B, AdamW + fp16 copy: 30 B per parameter)
+    gather = n * (3 * Ld + Lc) * 8 * 4
+    scatter = n * (3 * Ld + Lc) * 8 * 16 + n * Lc * 8 * 8
+    roof = {
+        "hash_fwd": {"kernel": "hash_fwd_kernel<fp16 table> x4", "work_per_launch": gather + n * (12 + 4 * 64),
+                     "ms": k["hash_fwd (3 deformation grids + canonical)"], "traffic": traffic({"hash_fwd_kernel<fp16 table>": 4})},
+        "backward": {"kernel": "p4 chains bwd + mlp_wgrad_small_kernel<true> x2 + hash_bwd_input_kernel + hash_bin_* x4", "work_per_launch": scatter,
+                     "ms": k["chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters"],
+                     "traffic": traffic({"hash_bin_count_pm_kernel": 4, "hash_bin_plan_kernel": 4, "hash_bin_scatter_kernel<true>": 4,
+                                         "hash_bin_reduce_kernel": 4, "hash_bwd_input_kernel": 1, "p4::canon_bwd_kernel": 1,
+                                         "p4::deform_bwd_kernel": 1, "mlp_wgrad_small_kernel<true>": 2})},
+        "tv_clip_adamw": {"kernel": "tv_normsq_kernel<true> x5 + adamw_clip_kernel<true> x3", "work_per_launch": n_par * 42,
+                          "ms": k["tv + clip + adamw (28.5 M parameters)"],
+                          "traffic": traffic({"tv_normsq_kernel<true>": 5, "adamw_clip_kernel<true>": 3})},
+    }
+    for v in roof.values():
+        v.update({"bound": "hbm", "achieved": v["work_per_launch"] / v["ms"] * 1e-6, "peak": HBM_PEAK_GBS, "unit": "GB/s"})
+        v["frac"] = v["achieved"] / HBM_PEAK_GBS
+    step_bytes = gather + scatter + n_par * 42 + n * 1200          # + ~1.2 kB per sample of tiny-MLP training images
+    return {"value": R * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "bf16",
+            "config": {"workload": "Part 4 dual-hash dynamic field train step (configs/part4.yaml.example), DualHashEngine", "rays_per_gpu": R,
+                       "samples_per_ray": S, "active_samples": n, "parameters": n_par,
+                       "regulariser_probes": "every 16th / 32nd step, through the same kernels"},
+            "kernels": {kk: {"ms": v} for kk, v in k.items()}, "rooflines": roof,
+            "step_roofline": {"bound": "hbm", "achieved": step_bytes / (dt / steps) * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": step_bytes / (dt / steps) * 1e-9 / HBM_PEAK_GBS, "work_per_step": step_bytes},
+            "round2_module_path_ms_per_step": 9.39}
 
 
 def bench_instant_dp(args, device, rank, world, dist):
@@ -335,8 +445,10 @@ def main():
     ap.add_argument("--no-instant", action="store_true", help="skip the shortened Instant-NGP block of the default run")
     ap.add_argument("--render-frames", type=int, default=10)
     ap.add_argument("--frames", type=int, default=100, help="GPU-resident 800x800 training frames the batches are drawn from")
-    ap.add_argument("--workload", choices=["vanilla", "instant"], default="vanilla",
-                    help="vanilla = BASELINE.json configs[1] (default, the judged line); instant = configs[2] / configs[3]")
+    ap.add_argument("--no-part4", action="store_true", help="skip the Part 4 block of the default run")
+    ap.add_argument("--workload", choices=["vanilla", "instant", "part4"], default="vanilla",
+                    help="vanilla = BASELINE.json configs[1] (default, the judged line); instant = configs[2] / configs[3]; "
+                         "part4 = configs[4] on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -354,6 +466,11 @@ def main():
     from src.dataset import BlenderDataset, SYNTHETIC_CAMERA_ANGLE
     if args.workload == "instant" and world == 1:
         return bench_instant(args, device, standalone=True)
+    if args.workload == "part4":
+        if world != 1:
+            raise SystemExit("--workload part4 is a one-GPU measurement (its data-parallel path: run.py, tests/test_gpu_cli_dp.py)")
+        print(json.dumps(bench_part4(args, device, steps=max(args.steps, 200))))
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -604,6 +721,10 @@ def main():
         inst = bench_instant(args, device)
         out["instant"] = {key: inst[key] for key in ("value", "unit", "ms_per_step", "render_fps", "render_ms_per_frame", "psnr_curve",
                                                      "kernels", "rooflines", "active_samples", "config", "reference_headline")}
+
+    if rank == 0 and world == 1 and not args.no_part4:
+        torch.cuda.empty_cache()
+        out["part4"] = bench_part4(args, device)
 
     if rank == 0:
         print(json.dumps(out))

@@ -1,0 +1,28 @@
+"""Steady-state Part 4 engine steps for the profilers (rocprofv3 --stats / --pmc): the loop of bench.py's part4 block only.
+    python tools/part4_profile_loop.py [n_steps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+from src.core import NeuralField  # noqa: E402
+from project_nerf_amd.dynamic import part4_probe_draws  # noqa: E402
+from project_nerf_amd.part4 import DualHashEngine  # noqa: E402
+
+dev = "cuda"
+cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "part4.yaml.example")))
+torch.manual_seed(0)
+R, S = cfg["batch_size"], cfg["n_samples"]
+o = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=-1) * 4.03
+d = torch.nn.functional.normalize(-o + 0.3 * torch.randn(R, 3, device=dev), dim=-1)
+t, target = torch.rand(R, 1, device=dev), torch.rand(R, 3, device=dev)
+eng = DualHashEngine(cfg, device=dev, seed=0)
+eng.load_from_model(NeuralField(cfg).to(dev))
+eng.binary_grid = torch.rand_like(eng.grid) < 0.12
+n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+for step in range(301, 301 + n_steps):
+    eng.train_step(o, d, target, t, S, probes=part4_probe_draws(cfg, step, dev))
+torch.cuda.synchronize()
+print("done", n_steps)

@@ -18,40 +18,45 @@ import statistics
 import sys
 
 
-KEEP = {"pack_kernel", "pack16_kernel", "sample_rays_kernel", "sample_pdf_kernel", "adam_kernel", "train_batch_kernel", "bwd_amax_kernel",
-        "sample_compact_kernel", "tv_normsq_kernel", "adamw_clip_kernel", "gather_rays_kernel"}
-
-
 def short(name):
-    m = re.search(r"nerf::(\w+)", name)
-    if m and m.group(1) == "hash_fwd_kernel":          # template argument is a vector type: nested brackets
+    """key of a kernel in the summary: its name inside namespace nerf (nerf::p4::x -> p4::x) with its template arguments;
+    every kernel of the library is kept (round 2 dropped tv_normsq_kernel<true> & co. here, not in rocprofv3)"""
+    if "nerf::" not in name and "_ZN4nerf" not in name:
+        return None
+    m = re.search(r"nerf::((?:\w+::)*\w+)", name)
+    if m is None:
+        return name.split("(")[0]
+    base = m.group(1)
+    if base == "hash_fwd_kernel":                        # template argument is a vector type: nested brackets
         return "hash_fwd_kernel<fp16 table>" if "_Float16" in name else "hash_fwd_kernel<fp32 table>"
-    m = re.search(r"nerf::(\w+(?:<[^>]*>)?)", name)
-    return m.group(1) if m else name.split("(")[0]
+    t = re.match(r"<[^()]*>", name[m.end():])
+    return base + (t.group(0) if t else "")
 
 
 def load(path):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     with open(path) as f:
         for r in csv.DictReader(f):
-            per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            key = short(r["Kernel_Name"])
+            if key is not None:
+                per[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return per
 
 
 def main(src, dst):
-    fetch, write, sq = (load(f"{src}/{n}_counter_collection.csv") for n in ("fetch", "write", "sq"))
+    import os
+    fetch, write = (load(f"{src}/{n}_counter_collection.csv") for n in ("fetch", "write"))
+    sq = load(f"{src}/sq_counter_collection.csv") if os.path.exists(f"{src}/sq_counter_collection.csv") else {}
     out = {}
     for k in fetch:
-        if k not in KEEP and not k.startswith(("mlp_", "composite_", "imlp_", "hash_", "wgrad_", "adam")):
-            continue
         f = statistics.median(fetch[k]["FETCH_SIZE"])
         w = statistics.median(write[k]["WRITE_SIZE"]) if k in write else 0.0
         e = {"launches": len(fetch[k]["FETCH_SIZE"]), "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w,
              "hbm_bytes_per_launch_corrected": 2 * f * 1024 + w * 1024}
-        if k in sq:
+        if k in sq and sq[k].get("GRBM_GUI_ACTIVE"):
             s = {c: statistics.median(v) for c, v in sq[k].items()}
             e["mfma_busy_frac"] = s["SQ_VALU_MFMA_BUSY_CYCLES"] / (s["GRBM_GUI_ACTIVE"] / 8 * 1024)
-            e["wait_any/wave_cycles"] = s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"]
+            e["wait_any/wave_cycles"] = s["SQ_WAIT_ANY"] / max(s["SQ_WAVE_CYCLES"], 1.0)
         out[k] = e
     with open(dst, "w") as fh:
         json.dump(out, fh, indent=1)
