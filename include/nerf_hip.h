@@ -328,6 +328,15 @@ int nerf_hash_encode_bwd_ws(const float* pts, int64_t n, int n_levels, const flo
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table, int first_level, int end_level,
                          void* workspace, size_t workspace_bytes, nerf_stream_t stream);
+/* the OVERWRITE form of the same pass: the table gradient of levels [first_level, end_level) is STORED, not accumulated --
+ * the caller neither zeroes d_table nor is it read back (the 52 MB memset and the 52 MB read of a 13 M-entry table per
+ * step).  Every slice of those levels is written exactly once: by the one work item that owns it, or -- slices cut into
+ * several items, the coarse dense levels -- zeroed by the scatter launch and then added to with atomics. */
+int nerf_hash_encode_bwd_ws_store(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                  const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                  const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                                  int first_level, int end_level, void* workspace, size_t workspace_bytes,
+                                  nerf_stream_t stream);
 /* gradient with respect to the encoded positions (dynamic fields encode x + delta_x: reference
  * src/core.py:268-271, 341-344): d_pts [n,3] = d_feat . d features / d x, zero along an axis on which
  * HashRepresentation's clamp is active; d_pts is OVERWRITTEN. */

@@ -259,8 +259,12 @@ struct BinHeader {                             // start of the workspace
   unsigned n_items, n_records, amax_bits, pad;  // amax_bits: largest |d_feat| of the call as fp32 bits
 };
 struct BinItem {
-  unsigned entry0, begin, end, atomic;         // first table entry of the slice, record range, flush mode
+  unsigned entry0, begin, end, atomic;         // first table entry of the slice, record range, flush: mode | live entries << 2
 };
+// flush modes of an item: read-modify-write of the non-zero sums (the slice belongs to this item, d_table holds other
+// contributions: the accumulate form), float atomics (the bin was cut into several items), plain STORE of the whole slice
+// (the overwrite form: d_table needs no zeroing and is not read back)
+constexpr unsigned kFlushRmw = 0, kFlushAtomic = 1, kFlushStore = 2;
 // one corner contribution, 8 bytes: bits [0,12) slot in the slice, [12,38) and [38,64) the two feature gradients as
 // 26-bit signed fixed point at the call's scale (fixed_shift: the largest |d_feat| of the call keeps 25 bits, i.e. a
 // resolution of 3e-8 of it -- finer than one fp32 ulp of that largest term; tinycudann accumulates these in fp16)
@@ -389,7 +393,7 @@ __device__ __forceinline__ int fixed_shift(unsigned amax_bits) {
 // one workgroup of 1024: bins in rounds of 1024 with a carried total
 __global__ void __launch_bounds__(1024)
 hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ count, unsigned* __restrict__ cursor,
-                     BinItem* __restrict__ items, BinHeader* __restrict__ header) {
+                     BinItem* __restrict__ items, BinHeader* __restrict__ header, int overwrite) {
   __shared__ unsigned scan_r[1024], scan_i[1024];
   __shared__ unsigned carry_r, carry_i;
   const unsigned n_bins = plan.bin0[plan.count];
@@ -398,7 +402,8 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
   for (unsigned base = 0; base < n_bins; base += 1024) {
     const unsigned b = base + threadIdx.x;
     const unsigned c = b < n_bins ? count[b] : 0u;
-    const unsigned it = (c + kChunk - 1) / kChunk;
+    // overwrite form: every bin gets an item (an empty bin's item stores a slice of zeros)
+    const unsigned it = (b < n_bins && overwrite && c == 0) ? 1u : (c + kChunk - 1) / kChunk;
     scan_r[threadIdx.x] = c;
     scan_i[threadIdx.x] = it;
     __syncthreads();
@@ -414,13 +419,15 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
       cursor[b] = r0;
       int li = 0;
       while (li + 1 < plan.count && plan.bin0[li + 1] <= b) ++li;
-      const unsigned entry0 = L.offset[plan.first + li] + ((b - plan.bin0[li]) << kSliceLog2);
+      const unsigned first = (b - plan.bin0[li]) << kSliceLog2;
+      const unsigned entry0 = L.offset[plan.first + li] + first;
+      const unsigned live = min(kSlice, L.size[plan.first + li] - first);      // the level's last slice may be partial
       for (unsigned j = 0; j < it; ++j) {
         BinItem item;
         item.entry0 = entry0;
         item.begin = r0 + j * kChunk;
         item.end = r0 + min(c, (j + 1) * kChunk);
-        item.atomic = it > 1 ? 1u : 0u;
+        item.atomic = (it > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2);
         items[i0 + j] = item;
       }
     }
@@ -445,7 +452,7 @@ template <bool STAGED>
 __global__ void __launch_bounds__(512)
 hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
                         unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header,
-                        const float2* __restrict__ grad_lm) {
+                        const float2* __restrict__ grad_lm, const unsigned* __restrict__ count, float* __restrict__ zero_table) {
   constexpr unsigned kBins = STAGED ? kStagedBins : kMaxSlices;
   __shared__ unsigned cnt[kBins], base[kBins];
   __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
@@ -454,6 +461,16 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
   const int lvl = plan.first + blockIdx.y;
   const unsigned bins = plan.bin0[blockIdx.y + 1] - plan.bin0[blockIdx.y], offset = L.offset[lvl];
   if (STAGED != (bins <= kStagedBins)) return;                 // the other instantiation owns this level
+  if (zero_table != nullptr) {
+    // overwrite form: a bin that was cut into several items is flushed with atomics by the reduce pass (a later launch),
+    // so its slice is zeroed here -- the coarse dense levels in steady state, 1.8 MB of a 52 MB table
+    for (unsigned b = blockIdx.x; b < bins; b += gridDim.x) {
+      if (count[plan.bin0[blockIdx.y] + b] <= kChunk) continue;
+      const unsigned first = b << kSliceLog2, live = min(kSlice, L.size[lvl] - first);
+      float2* dst = reinterpret_cast<float2*>(zero_table) + offset + first;
+      for (unsigned i = threadIdx.x; i < live; i += blockDim.x) dst[i] = make_float2(0.0f, 0.0f);
+    }
+  }
   const float scale = __uint_as_float((unsigned)(127 + fixed_shift(header->amax_bits)) << 23);
   for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) cnt[i] = 0;
   __syncthreads();
@@ -562,8 +579,11 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
     }
     __syncthreads();
     float2* dst = reinterpret_cast<float2*>(d_table) + item.entry0;
-    const unsigned live = min(kSlice, table_entries - item.entry0);
-    if (item.atomic) {
+    const unsigned live = min(item.atomic >> 2, table_entries - item.entry0), mode = item.atomic & 3u;
+    if (mode == kFlushStore) {
+      for (unsigned i = threadIdx.x; i < live; i += blockDim.x)
+        dst[i] = make_float2(__ll2float_rn((long long)acc[2 * i]) * inv_scale, __ll2float_rn((long long)acc[2 * i + 1]) * inv_scale);
+    } else if (mode == kFlushAtomic) {
       for (unsigned i = threadIdx.x; i < live; i += blockDim.x) {
         const long long a0 = (long long)acc[2 * i], a1 = (long long)acc[2 * i + 1];
         if (a0 != 0) atomicAdd(&dst[i].x, __ll2float_rn(a0) * inv_scale);
@@ -661,7 +681,8 @@ static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const 
 static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float* scale_host,
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
-                         int level0, int level1, nerf_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
+                         int level0, int level1, nerf_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0,
+                         bool overwrite = false) {
   NERF_REQUIRE(level0 >= 0 && level0 <= level1 && level1 <= n_levels, "nerf_hash_encode_bwd: levels [%d, %d) of %d", level0, level1, n_levels);
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
@@ -710,20 +731,28 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
         hipLaunchKernelGGL(hash_bin_count_kernel, dim3((int)bx_count, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan, d_feat,
                            w.count, w.header);
       const float2* grad_lm = point_major ? w.grad_lm : nullptr;
-      hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header);
+      hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header,
+                         overwrite ? 1 : 0);
+      float* zero_table = overwrite ? d_table : nullptr;
       bool any_staged = false, any_direct = false;
       for (int i = 0; i < plan.count; ++i) (plan.bin0[i + 1] - plan.bin0[i] <= kStagedBins ? any_staged : any_direct) = true;
       if (any_staged)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header, grad_lm);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table);
       if (any_direct)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header, grad_lm);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table);
       size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
       if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
       hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,
                          d_table, table_entries);
     }
+  }
+  if (overwrite && !binned && level0 < level1) {
+    // the atomic forms accumulate: give them the zeroed range the overwrite contract promises
+    const size_t e0 = offset_host[level0], e1 = offset_host[level1 - 1] + size_host[level1 - 1];
+    if (hipMemsetAsync(d_table + 2 * e0, 0, sizeof(float) * 2 * (e1 - e0), as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws_store: memset failed");
   }
   if (level0 < n_small && !binned) {
     const int hi = level1 < n_small ? level1 : n_small;
@@ -775,6 +804,24 @@ extern "C" int nerf_hash_encode_bwd_ws(const float* pts, int64_t n, int n_levels
                                        nerf_stream_t stream) {
   return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table,
                        first_level, end_level, stream, workspace, workspace_bytes);
+}
+
+extern "C" int nerf_hash_encode_bwd_ws_store(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                             const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                             const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                                             int first_level, int end_level, void* workspace, size_t workspace_bytes,
+                                             nerf_stream_t stream) {
+  NERF_REQUIRE(first_level >= 0 && first_level <= end_level && end_level <= n_levels, "nerf_hash_encode_bwd_ws_store: levels [%d, %d) of %d",
+               first_level, end_level, n_levels);
+  if (n == 0 && first_level < end_level) {            // nothing to scatter: the levels' range is still OVERWRITTEN (with zeros)
+    NERF_REQUIRE(d_table && size_host && offset_host, "nerf_hash_encode_bwd_ws_store: NULL pointer");
+    const size_t e0 = offset_host[first_level], e1 = offset_host[end_level - 1] + size_host[end_level - 1];
+    if (hipMemsetAsync(d_table + 2 * e0, 0, sizeof(float) * 2 * (e1 - e0), as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws_store: memset failed");
+    return NERF_OK;
+  }
+  return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table,
+                       first_level, end_level, stream, workspace, workspace_bytes, true);
 }
 
 extern "C" int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const float* table, int n_levels,

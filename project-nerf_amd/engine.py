@@ -267,6 +267,7 @@ class InstantNgpEngine:
         self.binary_grid = torch.ones(res, res, res, dtype=torch.bool, device=self.device)
         self.step_count, self.world_size = 0, world_size
         self._scratch = torch.empty(1, device=self.device)
+        self._loss_ring = torch.zeros(1024, device=self.device)
 
     def lr(self) -> float:
         import math
@@ -333,7 +334,6 @@ class InstantNgpEngine:
             z, slots, pts, dirs = ops.sample_compact(rays_o, rays_d, self.near, self.far, n_samples, self.binary_grid,
                                                      self.bound, u=u)
         n = pts.shape[0]
-        self.g_table.zero_()
         handles = []
 
         def reduce(view):
@@ -355,6 +355,7 @@ class InstantNgpEngine:
             # collectives its peers issue -- the tiny-MLP gradient, then one all-reduce per level group with the same
             # element counts (mismatched collectives across ranks hang or corrupt memory in RCCL)
             self.g_net.zero_()
+            self.g_table.zero_()
             pred = self.bg.expand(R, 3)
             loss = ((pred - target) ** 2).mean()
             reduce(self.g_net)
@@ -364,20 +365,26 @@ class InstantNgpEngine:
         else:
             rgb, sigma, ws = self._field(pts, dirs, True)
             P = lambda t: t.data_ptr()
-            loss = torch.zeros(1, device=self.device)
+            # a fresh zeroed loss slot per step out of a ring cleared once per lap (no fill launch per step)
+            self._grad_calls = getattr(self, "_grad_calls", -1) + 1
+            slot = self._grad_calls % self._loss_ring.numel()
+            if slot == 0:
+                self._loss_ring.zero_()
+            loss = self._loss_ring[slot:slot + 1]
             d_rgb, d_sigma, _ = ops.composite_mse_bwd(rgb, sigma, z, rays_d, self.bg, target, loss, slots=slots)
             d_feat = torch.empty(n, 2 * self.levels.n_levels, device=self.device)
             ops._lib.check(lib.nerf_imlp_bwd(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
                                              P(self.g_net), P(d_feat), ops._stream()), "nerf_imlp_bwd")
             reduce(self.g_net)
             hws = self._hash_bwd_workspace(n)
+            # overwrite form: the table gradient is stored slice by slice -- no 52 MB memset, no read-back
             if sync_grads_async is None:
-                ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, workspace=hws)
+                ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, workspace=hws, overwrite=True)
             else:
                 for lo, hi in self.level_groups():
-                    ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, level_range=(lo, hi), workspace=hws)
+                    ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, level_range=(lo, hi), workspace=hws, overwrite=True)
                     reduce(table_slice(lo, hi))
-            loss = loss[0]
+            loss = loss[0].clone()
         for h, wire, view in handles:
             if h is not None:
                 h.wait()

@@ -627,16 +627,23 @@ def hash_encode_bwd_workspace_bytes(n: int, n_levels: int) -> int:
 
 
 def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor, d_table: Tensor,
-                    level_range: Optional[Tuple[int, int]] = None, workspace: Optional[Tensor] = None) -> None:
+                    level_range: Optional[Tuple[int, int]] = None, workspace: Optional[Tensor] = None, overwrite: bool = False) -> None:
     """Scatter-add into ``d_table`` (caller zeroes it); ``level_range`` (lo, hi) restricts the pass to those levels.
     ``workspace`` (uint8, >= hash_encode_bwd_workspace_bytes(n, L)) selects the binned form: partial sort by
-    table slice + LDS sums instead of global float atomics."""
+    table slice + LDS sums instead of global float atomics.  ``overwrite`` (workspace form): the levels' gradient is
+    STORED -- no zeroing by the caller, no read-back (nerf_hash_encode_bwd_ws_store)."""
     lib = _lib.load()
     pts, d_feat = _dev(pts, "pts"), _dev(d_feat, "d_feat")
     lo, hi = level_range if level_range is not None else (0, levels.n_levels)
+    if overwrite and workspace is None:
+        raise ValueError("hash_encode_bwd: overwrite needs the workspace form")
     if workspace is None:
         _lib.check(lib.nerf_hash_encode_bwd_levels(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
                                                    _p(d_feat), _p(d_table), lo, hi, _stream()), "nerf_hash_encode_bwd")
+    elif overwrite:
+        _lib.check(lib.nerf_hash_encode_bwd_ws_store(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
+                                                     _p(d_feat), _p(d_table), lo, hi, _p(workspace), workspace.numel(), _stream()),
+                   "nerf_hash_encode_bwd_ws_store")
     else:
         _lib.check(lib.nerf_hash_encode_bwd_ws(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
                                                _p(d_feat), _p(d_table), lo, hi, _p(workspace), workspace.numel(), _stream()),

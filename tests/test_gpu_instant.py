@@ -569,3 +569,39 @@ def test_run_py_cli_part2_instant_trains_and_evaluates(tmp_path, engine):
     assert {"representation.encoding.params", "decoder.sigma_net.params", "decoder.color_net.params"} <= set(sd)
     assert float(sd["representation.encoding.params"].abs().max()) > 1.5e-4       # trained away from the +-1e-4 initialisation
     assert "density_grid" in ckpt and ckpt["density_grid"]["binary_grid"].shape == (32, 32, 32)
+
+
+@pytest.mark.parametrize("case", ["steady", "one_cell", "tiny", "large_table", "part4_deform"])
+def test_hash_backward_overwrite_form_equals_accumulate_form(ops, case):
+    """nerf_hash_encode_bwd_ws_store: the table gradient STORED (no zeroing by the caller, no read-back) equals the
+    accumulate form on a zeroed table -- slices owned by one work item, slices cut into several items (zeroed by the
+    scatter launch, then atomics), empty slices (stored zeros), partial last slices of the dense levels (must not touch
+    the next level's entries), level ranges (levels outside the range keep what they held)."""
+    shape = {"steady": (16, 19, 30000, 3.0, None), "one_cell": (16, 19, 40000, 0.05, (0.31, -0.22, 0.4)), "tiny": (3, 10, 5, 3.0, None),
+             "large_table": (8, 21, 20000, 3.0, None), "part4_deform": (12, 16, 9000, 3.0, None)}[case]
+    n_levels, log2_t, n, spread, centre = shape
+    t = ops.HashLevelTable(n_levels, log2_t, 16, 1.5 if case != "large_table" else 2.0)
+    gen = torch.Generator().manual_seed(n)
+    pts = (torch.rand(n, 3, generator=gen) - 0.5) * spread
+    if centre is not None:
+        pts = pts + torch.tensor(centre)
+    pts, d_feat = pts.cuda(), torch.randn(n, 2 * n_levels, generator=gen).cuda()
+    ws = torch.empty(ops.hash_encode_bwd_workspace_bytes(n, n_levels), dtype=torch.uint8, device="cuda")
+    ref = torch.zeros(t.entries, 2, device="cuda")
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, ref, workspace=ws)
+    scale = float(ref.abs().max())
+    out = torch.full_like(ref, float("nan"))                            # whatever the buffer held is gone afterwards
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, out, workspace=ws, overwrite=True)
+    assert bool(torch.isfinite(out).all())
+    assert float((out - ref).abs().max()) <= 1e-6 * scale, case          # cut bins meet through float atomics in both forms
+    # level ranges: only the range is rewritten
+    lo, hi = (1, min(3, n_levels))
+    part = torch.full_like(ref, 7.0)
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, part, level_range=(lo, hi), workspace=ws, overwrite=True)
+    e0, e1 = int(t.offset[lo]), int(t.offset[hi]) if hi < n_levels else t.entries
+    assert float((part[e0:e1] - ref[e0:e1]).abs().max()) <= 1e-6 * scale
+    assert bool((part[:e0] == 7.0).all()) and bool((part[e1:] == 7.0).all())
+    # no points at all: the range is still overwritten, with zeros
+    empty = torch.full_like(ref, 3.0)
+    ops.hash_encode_bwd(pts[:0], t, 1.5, d_feat[:0], empty, workspace=ws, overwrite=True)
+    assert float(empty.abs().max()) == 0.0

@@ -18,7 +18,36 @@ import statistics
 import sys
 
 
+_DEMANGLED = {}
+
+
+def demangle(name):
+    """rocprofv3 leaves kernels with _Float16 parameters mangled, and this image's c++filt does not know DF16_: the few
+    shapes the library has are decoded here (namespace nerf [:: p4], name, bool / fp16-vector template arguments)"""
+    if not name.startswith("_ZN4nerf"):
+        return name
+    rest, parts = name[len("_ZN4nerf"):], ["nerf"]
+    while rest and rest[0].isdigit():
+        m = re.match(r"(\d+)", rest)
+        n = int(m.group(1))
+        parts.append(rest[m.end():m.end() + n])
+        rest = rest[m.end() + n:]
+    targs = ""
+    if rest.startswith("ILb1E"):
+        targs = "<true>"
+    elif rest.startswith("ILb0E"):
+        targs = "<false>"
+    elif rest.startswith("IDv2_DF16_"):
+        targs = "<_Float16 vector>"
+    return "::".join(parts) + targs + "("
+
+
 def short(name):
+    name = demangle(name)
+    return _short(name)
+
+
+def _short(name):
     """key of a kernel in the summary: its name inside namespace nerf (nerf::p4::x -> p4::x) with its template arguments;
     every kernel of the library is kept (round 2 dropped tv_normsq_kernel<true> & co. here, not in rocprofv3)"""
     if "nerf::" not in name and "_ZN4nerf" not in name:
@@ -28,7 +57,7 @@ def short(name):
         return name.split("(")[0]
     base = m.group(1)
     if base == "hash_fwd_kernel":                        # template argument is a vector type: nested brackets
-        return "hash_fwd_kernel<fp16 table>" if "_Float16" in name else "hash_fwd_kernel<fp32 table>"
+        return "hash_fwd_kernel<fp16 table>" if ("_Float16" in name.split("(")[0] or "DF16_" in name.split("(")[0]) else "hash_fwd_kernel<fp32 table>"
     t = re.match(r"<[^()]*>", name[m.end():])
     return base + (t.group(0) if t else "")
 
@@ -51,8 +80,12 @@ def main(src, dst):
     for k in fetch:
         f = statistics.median(fetch[k]["FETCH_SIZE"])
         w = statistics.median(write[k]["WRITE_SIZE"]) if k in write else 0.0
-        e = {"launches": len(fetch[k]["FETCH_SIZE"]), "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w,
-             "hbm_bytes_per_launch_corrected": 2 * f * 1024 + w * 1024}
+        n = len(fetch[k]["FETCH_SIZE"])
+        total = 2 * sum(fetch[k]["FETCH_SIZE"]) * 1024 + (sum(write[k]["WRITE_SIZE"]) * 1024 if k in write else 0.0)
+        # median: the steady-state launch of a kernel that always runs at one size; mean / total: kernels launched at several
+        # sizes per step (the four hash grids of Part 4, the optimiser over tables and tiny networks)
+        e = {"launches": n, "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w,
+             "hbm_bytes_per_launch_corrected": 2 * f * 1024 + w * 1024, "hbm_bytes_per_launch_mean": total / n, "hbm_bytes_total": total}
         if k in sq and sq[k].get("GRBM_GUI_ACTIVE"):
             s = {c: statistics.median(v) for c, v in sq[k].items()}
             e["mfma_busy_frac"] = s["SQ_VALU_MFMA_BUSY_CYCLES"] / (s["GRBM_GUI_ACTIVE"] / 8 * 1024)

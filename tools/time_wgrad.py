@@ -26,6 +26,15 @@ for dbg in (0, 1, 2, 3):
     ms = t()
     print(f"debug={dbg}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s", flush=True)
 ops._lib.set_option("wgrad_debug", 0)
+if stash.numel() > 4000 * n:          # bf16 images (the default): the byte-based span cost model's fixed share per ring stage
+    for ovh in (16384, 49152, 98304, 196608, 393216):
+        ops._lib.set_option("wgrad_overhead", ovh)
+        print(f"wgrad_overhead {ovh}: {t():.3f} ms", flush=True)
+    ops._lib.set_option("wgrad_overhead", 98304)
+    ops._lib.set_option("wgrad_atomic", 1)
+    print(f"wgrad_atomic=1: {t():.3f} ms", flush=True)
+    ops._lib.set_option("wgrad_atomic", 0)
+    sys.exit(0)
 for bw, fixed in ((192, 2000), (192, 400), (192, 1000), (192, 3000), (128, 2000), (256, 2000), (384, 2000), (160, 2000), (224, 1500), (100000, 2000)):
     ops._lib.set_option("wgrad_bw_x16", bw); ops._lib.set_option("wgrad_fixed", fixed)
     print(f"bw_x16 {bw} fixed {fixed}: {t():.3f} ms", flush=True)
