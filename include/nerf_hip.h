@@ -47,7 +47,7 @@ int nerf_abi_version(void);
  * environment ONCE per process (NERF_CHAIN_LEGACY, NERF_FWD_CYCLES, NERF_WGRAD_OVH,
  * NERF_WGRAD_DEBUG, NERF_WGRAD_ONLY, NERF_HASH_BWD_ONLY_LEVEL, NERF_STASH_FP8); afterwards they
  * change only through nerf_set_option.  Names: "chain_legacy", "fwd_cycles", "wgrad_overhead",
- * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "wgrad_atomic", "wgrad_k16", "wgrad_big_only", "stash_fp8", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed", "chain_grid", "hash_fwd_lds_kb".  No hot-path launch reads the
+ * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "wgrad_atomic", "wgrad_k16", "wgrad_big_only", "stash_fp8", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed", "chain_grid", "wgrad_grid", "hash_fwd_lds_kb".  No hot-path launch reads the
  * environment. */
 int nerf_set_option(const char* name, int value);
 int nerf_get_option(const char* name, int* value_out);

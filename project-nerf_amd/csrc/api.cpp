@@ -34,6 +34,7 @@ static const OptionSlot kSlots[] = {
     {"infer_shape32", "NERF_INFER_SHAPE32", &Options::infer_shape32},
     {"stash_fp8", "NERF_STASH_FP8", &Options::stash_fp8},
     {"chain_grid", "NERF_CHAIN_GRID", &Options::chain_grid},
+    {"wgrad_grid", "NERF_WGRAD_GRID", &Options::wgrad_grid},
     {"hash_fwd_lds_kb", "NERF_HASH_FWD_LDS_KB", &Options::hash_fwd_lds_kb},
 };
 

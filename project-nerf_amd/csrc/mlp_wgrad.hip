@@ -676,6 +676,7 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
   if (int rc = ensure_dynamic_lds((const void*)mlp_wgrad_kernel, kWgLds, "nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
   long long want = (long long)args.wave_tiles * nj / 4;   // at least ~4 wave tiles per span
+  if (options().wgrad_grid > 0 && options().wgrad_grid < n_cu) n_cu = options().wgrad_grid;
   int grid = (int)(want < 1 ? 1 : (want > n_cu ? n_cu : want));
   // slab mode: which workgroups hold a partial tile of which job -- the kernel's own span arithmetic, replayed
   args.slab = nullptr;

@@ -127,3 +127,55 @@ def test_world_size_2_allreduce_and_gather():
         out = mgr.dict()
         mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def _loop_helpers_worker(rank, world, port, out):
+    """the helpers run.py's data-parallel loops are built from (parallel.rank_world / mean_over_ranks /
+    allreduce_mean_grads_ / render_row_bands) and the Part 4 engine's collective schedule, with real gloo collectives"""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import parallel as P
+    P.init_distributed("cpu")
+    ok = P.rank_world() == (rank, world)
+    ok = ok and abs(float(P.mean_over_ranks(torch.tensor(float(rank + 1)))) - (world + 1) / 2) < 1e-6
+    # module path: every rank's gradients of ITS shard's mean loss, averaged = gradient of the global batch's mean loss
+    g = torch.Generator().manual_seed(3)
+    x, w0 = torch.randn(64, 5, generator=g), torch.randn(5, 2, generator=g)
+    lin = torch.nn.Linear(5, 2)
+    with torch.no_grad():
+        lin.weight.copy_(w0.t())
+        lin.bias.zero_()
+    lo, hi = P.shard_range(64, rank, world)
+    lin(x[lo:hi]).pow(2).mean().backward()
+    P.allreduce_mean_grads_(list(lin.parameters()))
+    ref = torch.nn.Linear(5, 2)
+    with torch.no_grad():
+        ref.weight.copy_(w0.t())
+        ref.bias.zero_()
+    ref(x).pow(2).mean().backward()
+    ok = ok and torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-6) and torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-5, atol=1e-6)
+    # evaluation: row bands rendered per rank, gathered on rank 0 -- also when there are fewer rows than ranks would like
+    for H in (13, 1):
+        o = torch.arange(H * 4 * 3, dtype=torch.float32).view(H, 4, 3)
+        img = P.render_row_bands(lambda ob, db: ob * 2 + db, o, o * 0 + 1)
+        ok = ok and ((img is None) if rank else torch.equal(img, o * 2 + 1))
+    # the Part 4 engine's reduce schedule on a rank WITHOUT active samples equals the busy ranks' (canonical grid, the three
+    # deformation grids, then the networks): here only the order / sizes of the collectives matter
+    sizes = [40, 12, 12, 12, 9]
+    bufs = [torch.full((s,), float(rank + 1)) for s in sizes]
+    handles = [P.allreduce_sum_async(b) for b in bufs]
+    for h in handles:
+        h.wait()
+    ok = ok and all(bool((b == sum(range(1, world + 1))).all()) for b in bufs)
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world_size_2_training_loop_helpers():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_loop_helpers_worker, args=(2, port, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
