@@ -295,8 +295,8 @@ def bench_part4(args, device, steps=200):
     g_tabs = [eng.g_table(i) for i in range(4)]
     Ld, Lc = eng.levels_d.n_levels, eng.levels_c.n_levels
     k = {
-        "hash_fwd (3 deformation grids + canonical)": event_ms(lambda: [ops.hash_encode_fwd(pts, tabs[i], eng.levels_d if i < 3 else eng.levels_c, eng.bound,
-                                                                                            want_f32=False, out_nat=ws.nat(i)) for i in range(4)], 20),
+        "hash_fwd (3 deformation grids + canonical)": event_ms(lambda: [ops.hash_encode_fwd_nat(pts, tabs[i], eng.levels_d if i < 3 else eng.levels_c, eng.bound,
+                                                                                                ws.nat(i), fp16=True) for i in range(4)], 20),
         "hash_fwd + fused chains fwd": event_ms(fwd, 20),
         "chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters": event_ms(
             lambda: p4.backward_chain(eng.packed, eng.net, eng.table(3), eng.levels_d, eng.levels_c, eng.bound, pts, xc, ws, rgb, sigma, d_rgb, d_sigma,

@@ -306,6 +306,12 @@ int nerf_hash_encode_fwd_f16(const float* pts, int64_t n, const void* table_f16,
                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                          const unsigned* offset_host, const unsigned* dense_host, float bound,
                          float* out_f32, void* out_nat_bf16, nerf_stream_t stream);
+/* operand image only, from either table, as bf16 (nat_dtype 0: what nerf_imlp_fwd reads) or fp16 (nat_dtype 1: what the
+ * Part 4 forward chains read, nerf_p4_deform_fwd / nerf_p4_canon_fwd); exactly one of table_f32 / table_f16 is given */
+int nerf_hash_encode_fwd_nat(const float* pts, int64_t n, const float* table_f32, const void* table_f16, int n_levels,
+                             const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                             const unsigned* offset_host, const unsigned* dense_host, float bound,
+                             void* out_nat, int nat_dtype, nerf_stream_t stream);
 int nerf_f32_to_f16(const float* src, void* dst_f16, int64_t n, nerf_stream_t stream);
 int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float* scale_host,
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
@@ -450,7 +456,8 @@ int nerf_adamw_clip_step_shadow(float* params, const float* grads, float* exp_av
  * S1 [64,64] S2 [16,64] | C1 [64,48] C2 [64,64] C3 [16,64] | displacement_scale [1] (module state-dict layouts).
  * One workspace of nerf_p4_workspace_bytes(n) carries the hash-grid operand images and every training image:
  * nerf_p4_workspace_offset(n, which): 0..2 nat images of the three deformation grids (write them with
- * nerf_hash_encode_fwd*(..., out_nat)), 3 the canonical grid's; 4..6 d features [n,24] of the three deformation grids,
+ * nerf_hash_encode_fwd_nat(..., nat_dtype 1): the forward chains contract FP16 operands, as tinycudann's FullyFusedMLP
+ * does; the backward chains and training images are bf16), 3 the canonical grid's; 4..6 d features [n,24] of the three deformation grids,
  * 7 d features [n,32] of the canonical grid (read them with nerf_hash_encode_bwd*). */
 int64_t nerf_p4_param_count(void);
 size_t nerf_p4_packed_bytes(void);

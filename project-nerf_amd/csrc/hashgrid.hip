@@ -82,7 +82,7 @@ __device__ __forceinline__ float2 table_entry(const half2_t* t, unsigned i) {
 template <class TableT>
 __global__ void __launch_bounds__(256)
 hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const TableT* __restrict__ table, HashLevels L,
-                float* __restrict__ out_f32, __bf16* __restrict__ out_nat, unsigned* __restrict__ idx_out) {
+                float* __restrict__ out_f32, __bf16* __restrict__ out_nat, unsigned* __restrict__ idx_out, int nat_f16) {
   // the operand image is padded to whole 128-point tiles: pad rows repeat the last point so that
   // every stashed value is finite (their gradients are zero downstream)
   // level-major: blockIdx.y = level, consecutive lanes = consecutive points = neighbouring samples of a
@@ -112,8 +112,13 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const T
       const int col = (int)(p & 31);
       const int n_ks = (2 * L.n_levels + 15) / 16;
       __bf16* dst = out_nat + ((wt * n_ks + ks) * 64 + 2 * col + h) * 8 + j;
-      dst[0] = (__bf16)f0;
-      dst[1] = (__bf16)f1;
+      if (nat_f16) {                       // fp16 operand image (the Part 4 forward chains contract fp16 operands)
+        reinterpret_cast<_Float16*>(dst)[0] = (_Float16)f0;
+        reinterpret_cast<_Float16*>(dst)[1] = (_Float16)f1;
+      } else {
+        dst[0] = (__bf16)f0;
+        dst[1] = (__bf16)f1;
+      }
     }
   }
 }
@@ -630,7 +635,7 @@ using namespace nerf;
 static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                          const unsigned* offset_host, const unsigned* dense_host, float bound,
-                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream);
+                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream, int nat_f16 = 0);
 
 extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* table, int n_levels,
                                     const float* scale_host, const unsigned* res_host, const unsigned* size_host,
@@ -649,10 +654,21 @@ extern "C" int nerf_hash_encode_fwd_f16(const float* pts, int64_t n, const void*
                        out_nat_bf16, nullptr, stream);
 }
 
+extern "C" int nerf_hash_encode_fwd_nat(const float* pts, int64_t n, const float* table_f32, const void* table_f16, int n_levels,
+                                        const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                        const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                        void* out_nat, int nat_dtype, nerf_stream_t stream) {
+  NERF_REQUIRE((table_f32 == nullptr) != (table_f16 == nullptr), "nerf_hash_encode_fwd_nat: exactly one of table_f32 / table_f16");
+  NERF_REQUIRE(nat_dtype == 0 || nat_dtype == 1, "nerf_hash_encode_fwd_nat: nat_dtype=%d (0 bf16, 1 fp16)", nat_dtype);
+  NERF_REQUIRE(n == 0 || out_nat != nullptr, "nerf_hash_encode_fwd_nat: out_nat is NULL");
+  return hash_fwd_impl(pts, n, table_f32, table_f16, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound,
+                       nullptr, out_nat, nullptr, stream, nat_dtype);
+}
+
 static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                          const unsigned* offset_host, const unsigned* dense_host, float bound,
-                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream) {
+                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream, int nat_f16) {
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_fwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(pts && (table || table_f16) && scale_host && res_host && size_host && offset_host && dense_host,
@@ -671,10 +687,10 @@ static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const 
   const int lds = (lds_kb < 0 ? 0 : (lds_kb > 64 ? 64 : lds_kb)) * 1024;
   if (table_f16 != nullptr)
     hipLaunchKernelGGL(hash_fwd_kernel<half2_t>, dim3((int)blocks, n_levels), dim3(256), lds, as_stream(stream), pts, n, n_pad,
-                       static_cast<const half2_t*>(table_f16), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out);
+                       static_cast<const half2_t*>(table_f16), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out, nat_f16);
   else
     hipLaunchKernelGGL(hash_fwd_kernel<float2>, dim3((int)blocks, n_levels), dim3(256), lds, as_stream(stream), pts, n, n_pad,
-                       reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out);
+                       reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out, nat_f16);
   return check_launch("nerf_hash_encode_fwd");
 }
 

@@ -13,8 +13,12 @@
 //   canonical chain: InstantNeRFDecoder on [hash(x_c) (32) | tcode (21)] and the direction code  (core.py:344-349)
 //
 // Same register chain as imlp.hip / the 8x256 decoder (mlp_chain.h): 32 samples per wave on the MFMA column,
-// accumulator tiles -> bf16 B fragments, all weight fragments resident in LDS.  Training stashes every layer input
-// as a blocked bf16 image for the shared split-K weight-gradient kernel (mlp_wgrad.hip).
+// accumulator tiles -> 16-bit B fragments, all weight fragments resident in LDS.  The FORWARD chains contract fp16
+// operands (v_mfma_f32_32x32x16_f16, what tinycudann's FullyFusedMLP computes in): delta_x moves x_canonical inside a
+// hash grid whose finest cells are 4e-4 wide, and bf16's 8 mantissa bits put ~1e-3 of rounding on a displacement of
+// 0.2 -- several cells; fp16 keeps it below one.  The backward chains and the training images stay bf16 (gradients span
+// more binades than fp16 holds without a loss scale): every layer input is stashed as a blocked bf16 image for the
+// shared split-K weight-gradient kernel (mlp_wgrad.hip).
 //
 // Parameter vector (fp32, [out,in] row-major; the layouts of the module's state dict, concatenated):
 //   T1W [64,21] T1b [64] T2W [64,64] T2b [64]              time_modulation.net.{0,2}.{weight,bias}
@@ -101,22 +105,29 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ par
     const int ksn = st.ks_acc + st.ks_nat, rel = frag - st.frag0, mt = rel / ksn, ks = rel % ksn;
     const int row = mt * 32 + (lane & 31), h = lane >> 5;
     const bool nat = ks >= st.ks_acc;
-    bf16x8 out;
+    const bool fwd = step <= D3 || (step >= S1 && step <= C3);       // forward chains: fp16 fragments; backward: bf16
+    unsigned short out[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = nat ? 16 * (ks - st.ks_acc) + 8 * h + j : 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
       const int src = src_of(step, row, k, nat);
-      out[j] = (__bf16)(src >= 0 ? params[src] : 0.0f);
+      const float v = src >= 0 ? params[src] : 0.0f;
+      out[j] = fwd ? __builtin_bit_cast(unsigned short, (_Float16)v) : __builtin_bit_cast(unsigned short, (__bf16)v);
     }
-    *reinterpret_cast<bf16x8*>(packed + (size_t)frag * 1024 + lane * 16) = out;
+    uint4 bits;
+    bits.x = out[0] | ((unsigned)out[1] << 16); bits.y = out[2] | ((unsigned)out[3] << 16);
+    bits.z = out[4] | ((unsigned)out[5] << 16); bits.w = out[6] | ((unsigned)out[7] << 16);
+    *reinterpret_cast<uint4*>(packed + (size_t)frag * 1024 + lane * 16) = bits;
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) reinterpret_cast<float*>(packed + kPackBiasOff)[threadIdx.x] = params[kT2b + threadIdx.x];
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 // 1-D Fourier code of the time stamp, element f of [t | sin(2^0 pi t) | cos(2^0 pi t) | sin(2^1 pi t) | ...] (21 columns);
-// ONE: column 21 = 1 (bias column of the time-modulation layer), else 0
+// ONE: column 21 = 1 (bias column of the time-modulation layer), else 0.  v[ks][j] = column 16 ks + 8 half + j.
 template <int KS, bool ONE>
-__device__ __forceinline__ void time_operand(float t, int half, bf16x8 (&out)[KS]) {
+__device__ __forceinline__ void time_values(float t, int half, float (&v)[KS][8]) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -124,10 +135,66 @@ __device__ __forceinline__ void time_operand(float t, int half, bf16x8 (&out)[KS
       const int f = 16 * ks + 8 * half + j;                          // this lane's column: one sin/cos evaluation
       const int c = f > 0 ? f - 1 : 0;
       const float trig = sincos_rev(t, (float)(1u << (c >> 1)), (c & 1) ? 0.25f : 0.0f);
-      const float v = f == 0 ? t : (f < kTimeDim ? trig : ((ONE && f == kTimeDim) ? 1.0f : 0.0f));
-      out[ks][j] = (__bf16)v;
+      v[ks][j] = f == 0 ? t : (f < kTimeDim ? trig : ((ONE && f == kTimeDim) ? 1.0f : 0.0f));
     }
   }
+}
+// Fourier code of a unit direction (src/embeddings.py:28-32, L = 4: 27 columns, zero pad), as fourier_operand computes it
+template <int KS>
+__device__ __forceinline__ void dir_values(float x0, float x1, float x2, int half, float (&v)[KS][8]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const FeatSpec s0 = feat_spec<kDirDim>(16 * ks + j), s1 = feat_spec<kDirDim>(16 * ks + 8 + j);
+      const float v0 = s0.raw == 3 || s0.raw == 2 ? 0.0f : feat_eval<kDirDim>(s0, x0, x1, x2);
+      const float v1 = s1.raw == 3 || s1.raw == 2 ? 0.0f : feat_eval<kDirDim>(s1, x0, x1, x2);
+      v[ks][j] = half ? v1 : v0;
+    }
+  }
+}
+template <int KS>
+__device__ __forceinline__ void cast_values(const float (&v)[KS][8], f16x8 (&h)[KS], bf16x8 (&b)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h[ks][j] = (_Float16)v[ks][j]; b[ks][j] = (__bf16)v[ks][j]; }
+}
+
+// forward m-tile on fp16 operands (the same rotating fragment window as mlp_chain.h::mtile_mfma)
+template <int KS>
+__device__ __forceinline__ f32x16 mtile_mfma16(const char* a_base, int frag_off, const f16x8 (&b)[KS], f32x16 acc) {
+  constexpr int D = KS < kAhead ? KS : kAhead;
+  f16x8 win[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) win[i] = *reinterpret_cast<const f16x8*>(a_base + (frag_off + i) * 1024);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const f16x8 cur = win[ks % D];
+    if (ks + D < KS) win[ks % D] = *reinterpret_cast<const f16x8*>(a_base + (frag_off + ks + D) * 1024);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, b[ks], acc, 0, 0, 0);
+  }
+  return acc;
+}
+template <int STEP, int KS, class Epi>
+__device__ __forceinline__ void run16(const char* wbase, const f16x8 (&b)[KS], Epi&& epi) {
+  constexpr Step st = step_of(STEP);
+  static_assert(KS == st.ks_acc + st.ks_nat, "k-steps");
+  static_for<st.mt>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    acc = mtile_mfma16<KS>(wbase, st.frag0 + m * KS, b, acc);
+    epi(mc, acc);
+  });
+}
+__device__ __forceinline__ void acc_to_operand16(const f32x16& acc, f16x8& lo, f16x8& hi) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { lo[j] = (_Float16)acc[j]; hi[j] = (_Float16)acc[8 + j]; }
+}
+__device__ __forceinline__ f16x8 load_nat16(const __bf16* img, int64_t wt, int n_ks, int ks, int col, int half) {
+  return *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(img) + ((wt * n_ks + ks) * 64 + 2 * col + half) * 16);
 }
 
 template <int STEP, int KS, class Epi>
@@ -156,7 +223,7 @@ __device__ __forceinline__ void load_block(const __bf16* img, int64_t wt, int n_
 
 struct DeformArgs {
   const char* packed;
-  const __bf16* feat[3];   // nat images [n_pad,32] of the three deformation grids at x' (features 0..23 valid)
+  const __bf16* feat[3];   // nat images [n_pad,32] of the three deformation grids at x', FP16 (features 0..23 valid)
   const float* t;          // [n] per-sample time stamp t' (after the optional noise)
   const float* blend;      // [n,3] explicit grid weights or NULL: triangle weights of t' (core.py:324-332)
   const float* x;          // [n,3] sample positions (x_c = x + dx)
@@ -206,62 +273,78 @@ __global__ void __launch_bounds__(kThreads) deform_fwd_kernel(const DeformArgs a
     const bool live = n < a.n;
     const int64_t nc = live ? n : a.n - 1;
     const float t = a.t[nc];
-    bf16x8 tc[2];
-    time_operand<2, true>(t, half, tc);
+    f16x8 tc[2];
+    bf16x8 tc_b[2];
+    {
+      float v[2][8];
+      time_values<2, true>(t, half, v);
+      cast_values<2>(v, tc, tc_b);
+    }
     uint32_t mw[3] = {0, 0, 0};
-    auto relu_epi = [&](bf16x8* out, __bf16* stash, int layer) {
+    // relu epilogue: fp16 operand of the next step; training: bf16 image of the same values for the weight-gradient pass
+    auto relu_epi = [&](f16x8* out, __bf16* stash, int layer) {
       return [=, &mw](auto mc, f32x16 acc) {
         constexpr int m = decltype(mc)::value;
         uint32_t bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { bits |= (acc[r] > 0.0f ? 1u : 0u) << r; acc[r] = fmaxf(acc[r], 0.0f); }
         mw[layer] |= bits << (16 * m);
-        acc_to_operand(acc, out[2 * m], out[2 * m + 1]);
-        if constexpr (TRAIN) stash_block(stash, wt, 2, m, col, half, out[2 * m], out[2 * m + 1]);
+        acc_to_operand16(acc, out[2 * m], out[2 * m + 1]);
+        if constexpr (TRAIN) {
+          bf16x8 lo, hi;
+          acc_to_operand(acc, lo, hi);
+          stash_block(stash, wt, 2, m, col, half, lo, hi);
+        }
       };
     };
     // ---- time modulation (decoders.py:368-371) ----
-    bf16x8 ht1[4], tm[4];
-    run<T1, 2>(wbase, tc, relu_epi(ht1, a.ht1, 0));
-    run<T2, 4>(wbase, ht1, [&](auto mc, f32x16 acc) {
+    f16x8 ht1[4], tm[4];
+    run16<T1, 2>(wbase, tc, relu_epi(ht1, a.ht1, 0));
+    run16<T2, 4>(wbase, ht1, [&](auto mc, f32x16 acc) {
       constexpr int m = decltype(mc)::value;
       const f32x16 b = bias_tile(bias_lds, 32 * m, half);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 1.0f / (1.0f + __expf(-(acc[r] + b[r])));
-      acc_to_operand(acc, tm[2 * m], tm[2 * m + 1]);
-      if constexpr (TRAIN) stash_block(a.tm, wt, 2, m, col, half, tm[2 * m], tm[2 * m + 1]);
+      acc_to_operand16(acc, tm[2 * m], tm[2 * m + 1]);
+      if constexpr (TRAIN) {
+        bf16x8 lo, hi;
+        acc_to_operand(acc, lo, hi);
+        stash_block(a.tm, wt, 2, m, col, half, lo, hi);
+      }
     });
     // ---- tri-grid blend (core.py:313-336) ----
     float w[3];
     if (a.blend != nullptr) { w[0] = a.blend[nc * 3 + 0]; w[1] = a.blend[nc * 3 + 1]; w[2] = a.blend[nc * 3 + 2]; }
     else triangle_weights(t, w);
-    bf16x8 df[2];
+    f16x8 df[2];
+    bf16x8 df_b[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 f0 = load_nat(a.feat[0], wt, 2, ks, col, half), f1 = load_nat(a.feat[1], wt, 2, ks, col, half),
-                   f2 = load_nat(a.feat[2], wt, 2, ks, col, half);
+      const f16x8 f0 = load_nat16(a.feat[0], wt, 2, ks, col, half), f1 = load_nat16(a.feat[1], wt, 2, ks, col, half),
+                  f2 = load_nat16(a.feat[2], wt, 2, ks, col, half);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const bool valid = 16 * ks + 8 * half + j < kHashDeform;      // the hash forward leaves features 24..31 unwritten
-        const float v = w[0] * (float)f0[j] + w[1] * (float)f1[j] + w[2] * (float)f2[j];
-        df[ks][j] = (__bf16)(valid ? v : 0.0f);
+        const float v = valid ? w[0] * (float)f0[j] + w[1] * (float)f1[j] + w[2] * (float)f2[j] : 0.0f;
+        df[ks][j] = (_Float16)v;
+        df_b[ks][j] = (__bf16)v;
       }
     }
     if constexpr (TRAIN) {
-      stash_nat(a.tc, wt, 2, 0, col, half, tc[0]);
-      stash_nat(a.tc, wt, 2, 1, col, half, tc[1]);
-      stash_nat(a.df, wt, 2, 0, col, half, df[0]);
-      stash_nat(a.df, wt, 2, 1, col, half, df[1]);
+      stash_nat(a.tc, wt, 2, 0, col, half, tc_b[0]);
+      stash_nat(a.tc, wt, 2, 1, col, half, tc_b[1]);
+      stash_nat(a.df, wt, 2, 0, col, half, df_b[0]);
+      stash_nat(a.df, wt, 2, 1, col, half, df_b[1]);
       if (half == 0) *reinterpret_cast<f32x4*>(a.wts + n * 4) = f32x4{w[0], w[1], w[2], 0.0f};
     }
     // ---- displacement decoder (decoders.py:313-316) ----
-    bf16x8 hd1[4], hd2[4];
+    f16x8 hd1[4], hd2[4];
     {
-      bf16x8 cat[6] = {tm[0], tm[1], tm[2], tm[3], df[0], df[1]};
-      run<D1, 6>(wbase, cat, relu_epi(hd1, a.hd1, 1));
+      f16x8 cat[6] = {tm[0], tm[1], tm[2], tm[3], df[0], df[1]};
+      run16<D1, 6>(wbase, cat, relu_epi(hd1, a.hd1, 1));
     }
-    run<D2, 4>(wbase, hd1, relu_epi(hd2, a.hd2, 2));
-    run<D3, 4>(wbase, hd2, [&](auto, f32x16 acc) {
+    run16<D2, 4>(wbase, hd1, relu_epi(hd2, a.hd2, 2));
+    run16<D3, 4>(wbase, hd2, [&](auto, f32x16 acc) {
       if (live && half == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -354,7 +437,7 @@ __global__ void __launch_bounds__(kThreads) deform_bwd_kernel(const DeformArgs a
 // ------------------------------------------------------------------------------------------------ canonical chain
 struct CanonArgs {
   const char* packed;
-  const __bf16* hash_nat;  // nat [n_pad,32] from nerf_hash_encode_fwd at x_c
+  const __bf16* hash_nat;  // nat [n_pad,32] FP16 from nerf_hash_encode_fwd_nat (nat_dtype 1) at x_c
   const float* t;          // [n]
   const float* dirs;       // [n,3] unit view directions
   int64_t n, n_pad;
@@ -380,51 +463,69 @@ __global__ void __launch_bounds__(kThreads) canon_fwd_kernel(const CanonArgs a) 
     const int64_t wt = tile * 4 + wave, n = wt * 32 + col;
     const bool live = n < a.n;
     const int64_t nc = live ? n : a.n - 1;
-    bf16x8 sin[4], denc[2];
-    sin[0] = load_nat(a.hash_nat, wt, 2, 0, col, half);
-    sin[1] = load_nat(a.hash_nat, wt, 2, 1, col, half);
+    f16x8 sin[4], denc[2];
+    bf16x8 sin_b[4], denc_b[2];
+    sin[0] = load_nat16(a.hash_nat, wt, 2, 0, col, half);
+    sin[1] = load_nat16(a.hash_nat, wt, 2, 1, col, half);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sin_b[ks][j] = (__bf16)(float)sin[ks][j];
     {
-      bf16x8 tc[2];
-      time_operand<2, false>(a.t[nc], half, tc);                    // bias-free network: the pad columns stay zero
+      float v[2][8];
+      f16x8 tc[2];
+      bf16x8 tc_b[2];
+      time_values<2, false>(a.t[nc], half, v);                      // bias-free network: the pad columns stay zero
+      cast_values<2>(v, tc, tc_b);
       sin[2] = tc[0]; sin[3] = tc[1];
+      sin_b[2] = tc_b[0]; sin_b[3] = tc_b[1];
+      dir_values<2>(a.dirs[nc * 3 + 0], a.dirs[nc * 3 + 1], a.dirs[nc * 3 + 2], half, v);
+      cast_values<2>(v, denc, denc_b);
     }
-    fourier_operand<2, plan::kDirDim>(a.dirs[nc * 3 + 0], a.dirs[nc * 3 + 1], a.dirs[nc * 3 + 2], half, denc);
     if constexpr (TRAIN) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) stash_nat(a.sin_nat, wt, 4, ks, col, half, sin[ks]);
-      stash_nat(a.denc, wt, 2, 0, col, half, denc[0]);
-      stash_nat(a.denc, wt, 2, 1, col, half, denc[1]);
+      for (int ks = 0; ks < 4; ++ks) stash_nat(a.sin_nat, wt, 4, ks, col, half, sin_b[ks]);
+      stash_nat(a.denc, wt, 2, 0, col, half, denc_b[0]);
+      stash_nat(a.denc, wt, 2, 1, col, half, denc_b[1]);
     }
     uint32_t mw[3] = {0, 0, 0};
-    auto relu_epi = [&](bf16x8* out, __bf16* stash, int layer) {
+    auto relu_epi = [&](f16x8* out, __bf16* stash, int layer) {
       return [=, &mw](auto mc, f32x16 acc) {
         constexpr int m = decltype(mc)::value;
         uint32_t bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { bits |= (acc[r] > 0.0f ? 1u : 0u) << r; acc[r] = fmaxf(acc[r], 0.0f); }
         mw[layer] |= bits << (16 * m);
-        acc_to_operand(acc, out[2 * m], out[2 * m + 1]);
-        if constexpr (TRAIN) stash_block(stash, wt, 2, m, col, half, out[2 * m], out[2 * m + 1]);
+        acc_to_operand16(acc, out[2 * m], out[2 * m + 1]);
+        if constexpr (TRAIN) {
+          bf16x8 lo, hi;
+          acc_to_operand(acc, lo, hi);
+          stash_block(stash, wt, 2, m, col, half, lo, hi);
+        }
       };
     };
-    bf16x8 hs1[4], h16[2], hc1[4], hc2[4];
-    run<S1, 4>(wbase, sin, relu_epi(hs1, a.hs1, 0));
+    f16x8 hs1[4], h16[2], hc1[4], hc2[4];
+    run16<S1, 4>(wbase, sin, relu_epi(hs1, a.hs1, 0));
     float h0 = 0.0f;
-    run<S2, 4>(wbase, hs1, [&](auto, f32x16 acc) {
+    run16<S2, 4>(wbase, hs1, [&](auto, f32x16 acc) {
       h0 = acc[0];
-      acc_to_operand(acc, h16[0], h16[1]);
-      if constexpr (TRAIN) stash_block(a.h16, wt, 1, 0, col, half, h16[0], h16[1]);
+      acc_to_operand16(acc, h16[0], h16[1]);
+      if constexpr (TRAIN) {
+        bf16x8 lo, hi;
+        acc_to_operand(acc, lo, hi);
+        stash_block(a.h16, wt, 1, 0, col, half, lo, hi);
+      }
     });
     if (live && half == 0) {
       const float x = h0 - 5.0f;                                     // decoders.py:153
       a.sigma[n] = x > 20.0f ? x : log1pf(expf(x));
     }
     {
-      bf16x8 cat[3] = {h16[0], denc[0], denc[1]};
-      run<C1, 3>(wbase, cat, relu_epi(hc1, a.hc1, 1));
+      f16x8 cat[3] = {h16[0], denc[0], denc[1]};
+      run16<C1, 3>(wbase, cat, relu_epi(hc1, a.hc1, 1));
     }
-    run<C2, 4>(wbase, hc1, relu_epi(hc2, a.hc2, 2));
-    run<C3, 4>(wbase, hc2, [&](auto, f32x16 acc) {
+    run16<C2, 4>(wbase, hc1, relu_epi(hc2, a.hc2, 2));
+    run16<C3, 4>(wbase, hc2, [&](auto, f32x16 acc) {
       if (live && half == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) a.rgb[n * 3 + c] = 1.0f / (1.0f + __expf(-acc[c]));

@@ -607,6 +607,18 @@ def hash_encode_fwd(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: f
     return out, idx
 
 
+def hash_encode_fwd_nat(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: float, out_nat: Tensor, fp16: bool) -> None:
+    """operand image of the hash features (blocks of 32 points x 16 features) as bf16 or fp16, from the fp32 parameters or
+    their fp16 copy"""
+    lib = _lib.load()
+    pts = _dev(pts, "pts")
+    half = table.dtype == torch.float16
+    table = _dev(table, "table", torch.float16 if half else torch.float32)
+    _lib.check(lib.nerf_hash_encode_fwd_nat(_p(pts), pts.shape[0], None if half else _p(table), _p(table) if half else None, levels.n_levels,
+                                            *levels.host_args(), float(bound), _p(out_nat), 1 if fp16 else 0, _stream()),
+               "nerf_hash_encode_fwd_nat")
+
+
 def f32_to_f16(src: Tensor, dst: Optional[Tensor] = None) -> Tensor:
     """fp16 copy of a flat fp32 parameter vector (the shadow table of the hash forward)"""
     src = _dev(src, "src")

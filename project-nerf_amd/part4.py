@@ -105,13 +105,13 @@ def forward_chain(packed, params, tables, levels_d, levels_c, bound, pts, x_def,
     dev = pts.device
     x_in = pts if x_def is None else x_def
     for k in range(3):
-        ops.hash_encode_fwd(x_in, tables[k], levels_d, bound, want_f32=False, out_nat=ws.nat(k))
+        ops.hash_encode_fwd_nat(x_in, tables[k], levels_d, bound, ws.nat(k), fp16=True)
     dx, xc = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
     _lib.check(lib.nerf_p4_deform_fwd(P(packed), P(params), P(ws.buf), P(pts), P(t_def), P(blend), n, P(dx), P(xc), 1 if train else 0,
                                       ops._stream()), "nerf_p4_deform_fwd")
     if dirs is None:
         return None, None, dx, xc
-    ops.hash_encode_fwd(xc, tables[3], levels_c, bound, want_f32=False, out_nat=ws.nat(3))
+    ops.hash_encode_fwd_nat(xc, tables[3], levels_c, bound, ws.nat(3), fp16=True)
     rgb, sigma = torch.empty(n, 3, device=dev), torch.empty(n, device=dev)
     _lib.check(lib.nerf_p4_canon_fwd(P(packed), P(ws.buf), P(t_def), P(dirs), n, P(rgb), P(sigma), 1 if train else 0, ops._stream()),
                "nerf_p4_canon_fwd")

@@ -1,7 +1,7 @@
 """Part 4 on the fused HIP chains (csrc/p4mlp.hip; pytest -m gpu): the operator behind NeuralField('part4') and the
 flat-parameter DualHashEngine, against
-  * the reference's own Part 4 forward / autograd around the stand-in tinycudann (golden g14) -- bf16-MFMA chains against
-    fp32: tolerances stated from measurement below;
+  * the reference's own Part 4 forward / autograd around the stand-in tinycudann (golden g14) -- fp16-MFMA forward chains
+    (tinycudann's own operand precision) and bf16 backward chains against fp32: tolerances stated from measurement below;
   * the fp32 module path of this build (``fused_part4: false``: the same arithmetic composed from stand-alone operators,
     itself pinned to g14 at fp32 tolerance by tests/test_gpu_part4.py);
   * torch.optim.AdamW + clip_grad_norm_ with the reference's parameter groups for the optimiser step."""
@@ -89,7 +89,7 @@ def test_fused_forward_vs_reference_golden(fused_model, plain_model):
     assert rgb.shape == (400, 3) and sigma.shape == (400, 1) and delta.shape == (400, 3)
     e_d = float(np.abs(delta.cpu().numpy() - g["delta"]).max())
     print(f"[part4 fused forward vs g14] max |d delta_x| {e_d:.2e} of max |delta_x| {np.abs(g['delta']).max():.2e}")
-    assert e_d < 2e-2 * float(np.abs(g["delta"]).max())
+    assert e_d < 5e-3 * float(np.abs(g["delta"]).max())               # fp16 forward chain against fp32 (measured 1.3e-3)
     p, _ = plain_model
     saved = [mm.deform_decoder.displacement_scale.detach().clone() for mm in (m, p)]
     try:
@@ -104,7 +104,7 @@ def test_fused_forward_vs_reference_golden(fused_model, plain_model):
     e_c = float((r1 - r0).abs().max())
     e_s = float(((s1 - s0).abs() / s0.abs().clamp_min(1.0)).max())
     print(f"[part4 fused canonical chain vs fp32 module path at delta_x = 0] |d rgb| {e_c:.2e}, rel d sigma {e_s:.2e}")
-    assert float(d1.abs().max()) == 0.0 and e_c < 3e-2 and e_s < 0.1        # bf16 operands against fp32 (measured 8.7e-3 / 5.6e-2)
+    assert float(d1.abs().max()) == 0.0 and e_c < 3e-3 and e_s < 2.5e-2      # fp16 operands against fp32 (measured 6.4e-4 / 7.6e-3)
 
 
 def test_fused_field_vs_fp32_module_path_on_smooth_tables(smooth_pair):
@@ -125,7 +125,7 @@ def test_fused_field_vs_fp32_module_path_on_smooth_tables(smooth_pair):
     (r1, s1, d1), (r0, s0, d0) = outs
     e = (float((d1 - d0).abs().max() / d0.abs().max()), float((r1 - r0).abs().max()), float(((s1 - s0).abs() / s0.abs().clamp_min(1.0)).max()))
     print(f"[part4 fused vs fp32 module path, smooth tables] delta_x rel-to-max {e[0]:.2e}, |d rgb| {e[1]:.2e}, rel d sigma {e[2]:.2e}")
-    assert e[0] < 3e-2 and e[1] < 3e-2 and e[2] < 0.1            # measured 1.3e-2 / 6.9e-3 / 6.5e-2
+    assert e[0] < 8e-3 and e[1] < 3e-3 and e[2] < 2.5e-2         # measured 2.2e-3 / 5.0e-4 / 7.8e-3
     worst = 0.0
     pf, pp = dict(f.named_parameters()), dict(p.named_parameters())
     for k in pp:
@@ -135,11 +135,11 @@ def test_fused_field_vs_fp32_module_path_on_smooth_tables(smooth_pair):
         print(f"[part4 fused grads vs fp32 module path] {k:45s} rel {r:.4f}  |g| {float(pp[k].grad.norm()):.3e}")
         if k.endswith("displacement_scale"):
             # ONE scalar = sum over samples of d_x_canonical . raw displacement: signed terms through the finest hash levels
-            # cancel to a few percent of their magnitudes, so the bf16 rounding of the terms shows amplified (measured 0.26)
-            assert r < 0.4, (k, r)
+            # cancel to a few percent of their magnitudes, so rounding shows amplified (0.26 with a bf16 forward, 0.012 with fp16)
+            assert r < 0.15, (k, r)
         else:
             worst = max(worst, r)
-    assert worst < 0.2, worst                  # bf16 chains against fp32 autograd (measured <= 0.11)
+    assert worst < 0.15, worst                 # fp16 forward / bf16 backward chains against fp32 autograd (measured <= 0.08)
 
 
 def batch(R, S, seed):
@@ -201,7 +201,7 @@ def test_engine_gradients_equal_module_path_autograd(smooth_pair):
         r = rel(eng.g_table(k).cpu(), getattr(m, name).encoding.params.grad.cpu())
         print(f"[part4 engine vs module autograd] {name:45s} rel {r:.4f}")
         worst = max(worst, r)
-    assert worst < 0.2, worst                  # measured: networks <= 0.08, grids <= 0.12
+    assert worst < 0.12, worst                 # measured: networks <= 0.03, displacement_scale 0.06, grids <= 0.03
 
 
 def test_engine_probe_regularisers_equal_module_path_autograd(plain_model):
@@ -237,7 +237,7 @@ def test_engine_probe_regularisers_equal_module_path_autograd(plain_model):
         print(f"[part4 probes vs module autograd] {name:45s} rel {r:.4f}")
         worst = max(worst, r)
     assert float(eng.g_table(2).abs().max()) == 0.0 and float(eng.g_table(3).abs().max()) == 0.0
-    assert worst < 8e-2, worst
+    assert worst < 5e-2, worst                 # measured <= 0.021
 
 
 def test_engine_optimizer_step_equals_adamw_with_reference_groups(plain_model):
