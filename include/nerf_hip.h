@@ -343,6 +343,22 @@ int nerf_hash_encode_bwd_ws_store(const float* pts, int64_t n, int n_levels, con
                                   const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
                                   int first_level, int end_level, void* workspace, size_t workspace_bytes,
                                   nerf_stream_t stream);
+/* The count pass of the binned backward done where the information already exists (Instant-NGP step, all levels):
+ *   nerf_hash_encode_fwd_f16_hist  the forward also counts the corners per (level, table slice) into `bwd_workspace`
+ *                                  (>= nerf_hash_encode_bwd_workspace_bytes(n, L); its header and counts are zeroed here);
+ *   nerf_imlp_bwd_lm               the decoder's backward writes d features level-major and their largest magnitude straight
+ *                                  into that workspace (slots from nerf_hash_encode_bwd_ws_slots) instead of d_feat [n,32];
+ *   nerf_hash_encode_bwd_ws_store_precounted   plan + scatter + reduce only, overwrite form.
+ * The three calls must see the same points, level table and workspace, in this order, on one stream. */
+int nerf_hash_encode_fwd_f16_hist(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                  const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                  const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                  void* out_nat_bf16, void* bwd_workspace, size_t bwd_workspace_bytes, nerf_stream_t stream);
+int nerf_hash_encode_bwd_ws_slots(void* workspace, int64_t n, int n_levels, void** amax_bits_out, void** grad_lm_out);
+int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                             const unsigned* res_host, const unsigned* size_host,
+                                             const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                             float* d_table, void* workspace, size_t workspace_bytes, nerf_stream_t stream);
 /* gradient with respect to the encoded positions (dynamic fields encode x + delta_x: reference
  * src/core.py:268-271, 341-344): d_pts [n,3] = d_feat . d features / d x, zero along an axis on which
  * HashRepresentation's clamp is active; d_pts is OVERWRITTEN. */
@@ -375,6 +391,11 @@ int nerf_imlp_fwd_encoded(const void* packed, void* workspace, const float* x_en
 int nerf_imlp_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma,
                   const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
                   float* d_feat, nerf_stream_t stream);
+/* nerf_imlp_bwd with the feature gradients written level-major [16][n] float2 (grad_lm) and their largest magnitude
+ * max-accumulated into *amax_bits (fp32 bits): the inputs of nerf_hash_encode_bwd_ws_store_precounted */
+int nerf_imlp_bwd_lm(const void* packed, void* workspace, const float* rgb, const float* sigma,
+                     const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
+                     void* grad_lm, void* amax_bits, nerf_stream_t stream);
 
 /* ---- a10 + a11: evaluation of the vanilla field as one launch chain ----------------------------
  * replaces render_rays(perturb=False) / render_image's chunk loop (src/renderer.py:240-384, 387-418) for

@@ -73,6 +73,10 @@ PROTOTYPES = {
     "nerf_hash_encode_bwd_workspace_bytes": (size_t, [i64, i32]),
     "nerf_hash_encode_bwd_ws": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, i32, i32, c_ptr, size_t, c_ptr]),
     "nerf_hash_encode_bwd_ws_store": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, i32, i32, c_ptr, size_t, c_ptr]),
+    "nerf_hash_encode_fwd_f16_hist": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),
+    "nerf_hash_encode_bwd_ws_slots": (i32, [c_ptr, i64, i32, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr)]),
+    "nerf_hash_encode_bwd_ws_store_precounted": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),
+    "nerf_imlp_bwd_lm": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_input": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_imlp_packed_bytes": (size_t, []),
     "nerf_imlp_workspace_bytes": (size_t, [i64]),

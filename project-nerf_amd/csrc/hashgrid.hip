@@ -74,6 +74,9 @@ __device__ __forceinline__ Corner corners_of(const HashLevels& L, int lvl, float
 // (nerf_adamw_clip_step_shadow) -- half the bytes per gather and twice the entries per cache line; tinycudann
 // itself evaluates its grid from fp16 parameters next to an fp32 master copy.
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+// table slices of the binned backward (see below): the forward can already count the corners per (level, slice)
+constexpr unsigned kSliceLog2 = 12, kSlice = 1u << kSliceLog2;   // 4096 entries x 2 features x 8 B = 64 KiB of LDS
+struct LevelBins { unsigned bin0[kMaxLevels + 1]; };             // first bin of every level; bin0[n_levels] = number of bins
 __device__ __forceinline__ float2 table_entry(const float2* t, unsigned i) { return t[i]; }
 __device__ __forceinline__ float2 table_entry(const half2_t* t, unsigned i) {
   const half2_t h = t[i];
@@ -82,7 +85,12 @@ __device__ __forceinline__ float2 table_entry(const half2_t* t, unsigned i) {
 template <class TableT>
 __global__ void __launch_bounds__(256)
 hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const TableT* __restrict__ table, HashLevels L,
-                float* __restrict__ out_f32, __bf16* __restrict__ out_nat, unsigned* __restrict__ idx_out, int nat_f16) {
+                float* __restrict__ out_f32, __bf16* __restrict__ out_nat, unsigned* __restrict__ idx_out, int nat_f16,
+                unsigned* __restrict__ hist_count, LevelBins lb) {
+  // hist_count (training, optional): corners per (level, slice) of the points p < n -- the first pass of the binned
+  // backward (hash_bin_count_*), done here where the corner indices already exist; LDS histogram per workgroup (the dynamic
+  // LDS allocation, >= 4 bytes per slice of the level), one global add per non-empty bin and workgroup
+  extern __shared__ unsigned hist_lds[];
   // the operand image is padded to whole 128-point tiles: pad rows repeat the last point so that
   // every stashed value is finite (their gradients are zero downstream)
   // level-major: blockIdx.y = level, consecutive lanes = consecutive points = neighbouring samples of a
@@ -90,10 +98,19 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const T
   // 16 lanes of a wave hit 16 different level tables)
   const int64_t rows = out_nat != nullptr ? n_pad : n;
   const int lvl = blockIdx.y;
+  const unsigned hist_bins = hist_count != nullptr ? lb.bin0[lvl + 1] - lb.bin0[lvl] : 0u, lvl_offset = L.offset[lvl];
+  if (hist_count != nullptr) {
+    for (unsigned i = threadIdx.x; i < hist_bins; i += blockDim.x) hist_lds[i] = 0;
+    __syncthreads();
+  }
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < rows; p += (int64_t)gridDim.x * blockDim.x) {
     const int64_t g = p * L.n_levels + lvl;
     const int64_t ps = p < n ? p : n - 1;
     const Corner c = corners_of(L, lvl, pts[ps * 3 + 0], pts[ps * 3 + 1], pts[ps * 3 + 2]);
+    if (hist_count != nullptr && p < n) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(&hist_lds[(c.idx[k] - lvl_offset) >> kSliceLog2], 1u);
+    }
     float f0 = 0.0f, f1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -120,6 +137,11 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const T
         dst[1] = (__bf16)f1;
       }
     }
+  }
+  if (hist_count != nullptr) {
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < hist_bins; i += blockDim.x)
+      if (hist_lds[i] != 0) atomicAdd(hist_count + lb.bin0[lvl] + i, hist_lds[i]);
   }
 }
 
@@ -249,7 +271,6 @@ hash_bwd_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, int lvl0
 // The scale is a power of two taken from the largest |d_feat| of the call (found by the count pass), so that a
 // term keeps 25 bits below that maximum (the packed record's width) and 2^37 terms cannot overflow;
 // integer sums also make the result independent of the order of the records.
-constexpr unsigned kSliceLog2 = 12, kSlice = 1u << kSliceLog2;   // 4096 entries x 2 features x 8 B = 64 KiB of LDS
 constexpr unsigned kChunk = 32768;             // records per work item
 constexpr unsigned kMaxSlices = 4096;          // per level (LDS histogram); larger tables use the atomic form
 constexpr int kMaxBins = 65536;
@@ -457,7 +478,8 @@ template <bool STAGED>
 __global__ void __launch_bounds__(512)
 hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
                         unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header,
-                        const float2* __restrict__ grad_lm, const unsigned* __restrict__ count, float* __restrict__ zero_table) {
+                        const float2* __restrict__ grad_lm, const unsigned* __restrict__ count, float* __restrict__ zero_table,
+                        int all_live) {
   constexpr unsigned kBins = STAGED ? kStagedBins : kMaxSlices;
   __shared__ unsigned cnt[kBins], base[kBins];
   __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
@@ -489,7 +511,7 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
         const float2 g = grad_lm[(int64_t)blockIdx.y * n + p];
         g0 = g.x;
         g1 = g.y;
-        live = g0 != 0.0f || g1 != 0.0f;
+        live = all_live || g0 != 0.0f || g1 != 0.0f;     // counted by the forward: every point owns its eight records
       } else live = point_gradient(d_feat, p, L.n_levels, lvl, g0, g1);
     }
     Corner c;
@@ -635,7 +657,8 @@ using namespace nerf;
 static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                          const unsigned* offset_host, const unsigned* dense_host, float bound,
-                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream, int nat_f16 = 0);
+                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream, int nat_f16 = 0,
+                         void* bwd_workspace = nullptr, size_t bwd_workspace_bytes = 0);
 
 extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* table, int n_levels,
                                     const float* scale_host, const unsigned* res_host, const unsigned* size_host,
@@ -665,10 +688,28 @@ extern "C" int nerf_hash_encode_fwd_nat(const float* pts, int64_t n, const float
                        nullptr, out_nat, nullptr, stream, nat_dtype);
 }
 
+extern "C" int nerf_hash_encode_fwd_f16_hist(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                             const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                             const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                             void* out_nat_bf16, void* bwd_workspace, size_t bwd_workspace_bytes, nerf_stream_t stream) {
+  NERF_REQUIRE(n == 0 || (table_f16 && out_nat_bf16 && bwd_workspace), "nerf_hash_encode_fwd_f16_hist: NULL pointer");
+  return hash_fwd_impl(pts, n, nullptr, table_f16, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, nullptr,
+                       out_nat_bf16, nullptr, stream, 0, bwd_workspace, bwd_workspace_bytes);
+}
+
+extern "C" int nerf_hash_encode_bwd_ws_slots(void* workspace, int64_t n, int n_levels, void** amax_bits_out, void** grad_lm_out) {
+  NERF_REQUIRE(workspace && n > 0 && n_levels >= 1 && n_levels <= kMaxLevels && amax_bits_out && grad_lm_out, "nerf_hash_encode_bwd_ws_slots: bad arguments");
+  const BinWorkspace w = carve(workspace, n, n_levels);
+  *amax_bits_out = &w.header->amax_bits;
+  *grad_lm_out = w.grad_lm;
+  return NERF_OK;
+}
+
 static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                          const unsigned* offset_host, const unsigned* dense_host, float bound,
-                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream, int nat_f16) {
+                         float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream, int nat_f16,
+                         void* bwd_workspace, size_t bwd_workspace_bytes) {
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_fwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(pts && (table || table_f16) && scale_host && res_host && size_host && offset_host && dense_host,
@@ -684,13 +725,36 @@ static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const 
   // i.e. about 1.3 level tables in flight on the chip instead of 2.6 -- the 2 MB tables of the hashed levels then stay in
   // the 4 MB L2 of each XCD (91 -> 85 us on 200 k points; 3 or 2 workgroups per CU: 98 us)
   const int lds_kb = options().hash_fwd_lds_kb;
-  const int lds = (lds_kb < 0 ? 0 : (lds_kb > 64 ? 64 : lds_kb)) * 1024;
+  int lds = (lds_kb < 0 ? 0 : (lds_kb > 64 ? 64 : lds_kb)) * 1024;
+  // bwd_workspace: this forward also counts the corners per (level, slice) into the binned backward's workspace (header and
+  // counts are zeroed here), so that nerf_hash_encode_bwd_ws_store_precounted can skip its count pass
+  unsigned* hist_count = nullptr;
+  LevelBins lb{};
+  if (bwd_workspace != nullptr) {
+    NERF_REQUIRE(bwd_workspace_bytes >= bin_workspace_bytes(n, n_levels), "nerf_hash_encode_fwd_hist: workspace of %zu bytes, need %zu",
+                 bwd_workspace_bytes, bin_workspace_bytes(n, n_levels));
+    unsigned max_slices = 0;
+    for (int i = 0; i < n_levels; ++i) {
+      const unsigned slices = (size_host[i] + kSlice - 1) / kSlice;
+      NERF_REQUIRE(slices <= kMaxSlices, "nerf_hash_encode_fwd_hist: level %d has %u slices (max %u)", i, slices, kMaxSlices);
+      max_slices = slices > max_slices ? slices : max_slices;
+      lb.bin0[i + 1] = lb.bin0[i] + slices;
+    }
+    NERF_REQUIRE(lb.bin0[n_levels] <= (unsigned)kMaxBins, "nerf_hash_encode_fwd_hist: %u bins (max %d)", lb.bin0[n_levels], kMaxBins);
+    const BinWorkspace w = carve(bwd_workspace, n, n_levels);
+    if (hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * lb.bin0[n_levels], as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_hash_encode_fwd_hist: memset failed");
+    hist_count = w.count;
+    if (lds < (int)(max_slices * sizeof(unsigned))) lds = (int)(max_slices * sizeof(unsigned));
+  }
   if (table_f16 != nullptr)
     hipLaunchKernelGGL(hash_fwd_kernel<half2_t>, dim3((int)blocks, n_levels), dim3(256), lds, as_stream(stream), pts, n, n_pad,
-                       static_cast<const half2_t*>(table_f16), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out, nat_f16);
+                       static_cast<const half2_t*>(table_f16), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out, nat_f16,
+                       hist_count, lb);
   else
     hipLaunchKernelGGL(hash_fwd_kernel<float2>, dim3((int)blocks, n_levels), dim3(256), lds, as_stream(stream), pts, n, n_pad,
-                       reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out, nat_f16);
+                       reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out, nat_f16,
+                       hist_count, lb);
   return check_launch("nerf_hash_encode_fwd");
 }
 
@@ -698,11 +762,11 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
                          int level0, int level1, nerf_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0,
-                         bool overwrite = false) {
+                         bool overwrite = false, bool precounted = false) {
   NERF_REQUIRE(level0 >= 0 && level0 <= level1 && level1 <= n_levels, "nerf_hash_encode_bwd: levels [%d, %d) of %d", level0, level1, n_levels);
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
-  NERF_REQUIRE(pts && d_feat && d_table && scale_host && res_host && size_host && offset_host && dense_host,
+  NERF_REQUIRE(pts && (d_feat || precounted) && d_table && scale_host && res_host && size_host && offset_host && dense_host,
                "nerf_hash_encode_bwd: NULL pointer");
   HashLevels L;
   int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
@@ -733,12 +797,15 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
       NERF_REQUIRE((size_t)n * 8 * (size_t)n_levels < 0xffffffffull, "nerf_hash_encode_bwd_ws: n=%lld too large for 32-bit record offsets", (long long)n);
       const BinWorkspace w = carve(workspace, n, n_levels);
       const unsigned n_bins = plan.bin0[plan.count];
-      if (hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * n_bins, as_stream(stream)) != hipSuccess)   // header + counts
+      if (!precounted && hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * n_bins, as_stream(stream)) != hipSuccess)   // header + counts
         return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws: memset failed");
       int64_t bx = (n + 511) / 512;
       const int64_t bx_count = bx > 256 ? 256 : bx, bx_scatter = bx > 128 ? 128 : bx;
-      const bool point_major = n_bins <= kPmBins;
-      if (point_major) {
+      const bool point_major = precounted || n_bins <= kPmBins;
+      if (precounted) {
+        // counts by the forward (nerf_hash_encode_fwd_f16_hist), largest |gradient| and level-major gradients by the
+        // decoder's backward (nerf_imlp_bwd_lm): nothing to do here
+      } else if (point_major) {
         int64_t bpm = (n + 255) / 256;
         if (bpm > 1024) bpm = 1024;
         hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm), dim3(256), 0, as_stream(stream), pts, n, L, plan, d_feat, w.count,
@@ -754,16 +821,18 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
       for (int i = 0; i < plan.count; ++i) (plan.bin0[i + 1] - plan.bin0[i] <= kStagedBins ? any_staged : any_direct) = true;
       if (any_staged)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted ? 1 : 0);
       if (any_direct)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted ? 1 : 0);
       size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
       if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
       hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,
                          d_table, table_entries);
     }
   }
+  if (precounted && !binned)
+    return fail(NERF_EINVAL, "nerf_hash_encode_bwd_ws_store_precounted: the binned form is not available for this table shape / option set");
   if (overwrite && !binned && level0 < level1) {
     // the atomic forms accumulate: give them the zeroed range the overwrite contract promises
     const size_t e0 = offset_host[level0], e1 = offset_host[level1 - 1] + size_host[level1 - 1];
@@ -838,6 +907,15 @@ extern "C" int nerf_hash_encode_bwd_ws_store(const float* pts, int64_t n, int n_
   }
   return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table,
                        first_level, end_level, stream, workspace, workspace_bytes, true);
+}
+
+extern "C" int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                                        const unsigned* res_host, const unsigned* size_host,
+                                                        const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                                        float* d_table, void* workspace, size_t workspace_bytes, nerf_stream_t stream) {
+  NERF_REQUIRE(n > 0 && workspace != nullptr, "nerf_hash_encode_bwd_ws_store_precounted: n=%lld, workspace %p", (long long)n, workspace);
+  return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, nullptr, d_table, 0, n_levels,
+                       stream, workspace, workspace_bytes, true, true);
 }
 
 extern "C" int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const float* table, int n_levels,

@@ -91,6 +91,8 @@ struct IArgs {
   const float* d_rgb; const float* d_sigma;
   __bf16* dzs1; __bf16* dzs2; __bf16* dzc1; __bf16* dzc2; __bf16* dsmall;
   float* d_feat;            // [n,32] fp32
+  float2* grad_lm;          // instead of d_feat: level-major gradients [16][n] float2 (the binned hash backward's input)
+  unsigned* amax_bits;      // with grad_lm: running maximum of |d_feat| as fp32 bits (the scatter's fixed-point scale)
 };
 
 template <int STEP, int KS, class Epi>
@@ -186,6 +188,7 @@ __global__ void __launch_bounds__(kIThreads) imlp_bwd_kernel(const IArgs a) {
   __syncthreads();
   const char* wbase = smem + lane * 16 - kIFwdFrags * 1024;   // istep().frag0 counts from the forward stream
   const int64_t n_tiles = a.n_pad / kITile;
+  float amax = 0.0f;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t wt = tile * 4 + wave, n = wt * 32 + col;
     const bool live = n < a.n;
@@ -223,14 +226,31 @@ __global__ void __launch_bounds__(kIThreads) imlp_bwd_kernel(const IArgs a) {
     });
     { bf16x8 in[1] = {g16[0]}; istep_run<8, 1>(wbase, in, grad_epi(gs1, a.dzs1, mask.x)); }
     istep_run<9, 4>(wbase, gs1, [&](auto, f32x16 acc) {
-      if (live) {
+      if (!live) return;
+      if (a.grad_lm != nullptr) {
+        // registers 4g..4g+3 = features 8g + 4 half + (0..3) = levels 4g + 2 half and + 1: two float2 per group, each store
+        // instruction covers 32 consecutive points of one level (256 contiguous bytes)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-          *reinterpret_cast<f32x4*>(a.d_feat + n * 32 + 8 * g + 4 * half) = v;
+          const int lvl = 4 * g + 2 * half;
+          a.grad_lm[(int64_t)lvl * a.n + n] = make_float2(acc[4 * g], acc[4 * g + 1]);
+          a.grad_lm[(int64_t)(lvl + 1) * a.n + n] = make_float2(acc[4 * g + 2], acc[4 * g + 3]);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(acc[r]));
+        return;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(a.d_feat + n * 32 + 8 * g + 4 * half) = v;
       }
     });
+  }
+  if (a.amax_bits != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0 && amax > 0.0f && amax <= 3.0e38f) atomicMax(a.amax_bits, __builtin_bit_cast(unsigned, amax));
   }
 }
 
@@ -324,16 +344,35 @@ extern "C" int nerf_imlp_fwd_encoded(const void* packed, void* workspace, const 
   return check_launch("nerf_imlp_fwd_encoded");
 }
 
+static int imlp_bwd_impl(const void* packed, void* workspace, const float* rgb, const float* sigma, const float* d_rgb,
+                         const float* d_sigma, int64_t n, float* grads_f32, float* d_feat, float2* grad_lm, unsigned* amax_bits,
+                         nerf_stream_t stream);
+
 extern "C" int nerf_imlp_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma,
                              const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
                              float* d_feat, nerf_stream_t stream) {
+  NERF_REQUIRE(n == 0 || d_feat != nullptr, "nerf_imlp_bwd: d_feat is NULL");
+  return imlp_bwd_impl(packed, workspace, rgb, sigma, d_rgb, d_sigma, n, grads_f32, d_feat, nullptr, nullptr, stream);
+}
+
+extern "C" int nerf_imlp_bwd_lm(const void* packed, void* workspace, const float* rgb, const float* sigma,
+                                const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
+                                void* grad_lm, void* amax_bits, nerf_stream_t stream) {
+  NERF_REQUIRE(n == 0 || (grad_lm != nullptr && amax_bits != nullptr), "nerf_imlp_bwd_lm: NULL output");
+  return imlp_bwd_impl(packed, workspace, rgb, sigma, d_rgb, d_sigma, n, grads_f32, nullptr, static_cast<float2*>(grad_lm),
+                       static_cast<unsigned*>(amax_bits), stream);
+}
+
+static int imlp_bwd_impl(const void* packed, void* workspace, const float* rgb, const float* sigma, const float* d_rgb,
+                         const float* d_sigma, int64_t n, float* grads_f32, float* d_feat, float2* grad_lm, unsigned* amax_bits,
+                         nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && grads_f32, "nerf_imlp_bwd: bad arguments");
   if (hipMemsetAsync(grads_f32, 0, sizeof(float) * kIParams, as_stream(stream)) != hipSuccess)
     return fail(NERF_ELAUNCH, "nerf_imlp_bwd: memset failed");
   if (n == 0) return NERF_OK;
-  NERF_REQUIRE(packed && workspace && rgb && sigma && d_rgb && d_sigma && d_feat, "nerf_imlp_bwd: NULL pointer");
+  NERF_REQUIRE(packed && workspace && rgb && sigma && d_rgb && d_sigma && (d_feat || grad_lm), "nerf_imlp_bwd: NULL pointer");
   IArgs a = iargs(packed, workspace, nullptr, n, const_cast<float*>(rgb), const_cast<float*>(sigma));
-  a.d_rgb = d_rgb; a.d_sigma = d_sigma; a.d_feat = d_feat;
+  a.d_rgb = d_rgb; a.d_sigma = d_sigma; a.d_feat = d_feat; a.grad_lm = grad_lm; a.amax_bits = amax_bits;
   const int grid = grid_for_tiles(a.n_pad / kITile);
   if (grid <= 0) return fail(NERF_ELAUNCH, "nerf_imlp_bwd: cannot query device");
   hipLaunchKernelGGL(imlp_bwd_kernel, dim3(grid), dim3(kIThreads), kIBwdFrags * 1024, as_stream(stream), a);

@@ -252,6 +252,7 @@ class InstantNgpEngine:
         # the fp32 master copy too): written by the optimiser kernel, refreshed here whenever torch code has
         # touched ``self.table`` in place (tensor version counter); cfg half_table: false keeps fp32 gathers
         self.half_table = bool(cfg.get("half_table", True))
+        self.precount = bool(cfg.get("precount", True))
         self.table_h = torch.empty(self.table.numel(), device=self.device, dtype=torch.float16) if self.half_table else None
         self._table_version = None
         self.packed = ops.imlp_pack(self.net)
@@ -282,11 +283,18 @@ class InstantNgpEngine:
             self._table_version = self.table._version
         return self.table_h.view(-1, 2)
 
-    def _field(self, pts: Tensor, dirs: Tensor, train: bool):
+    def _field(self, pts: Tensor, dirs: Tensor, train: bool, hist_ws: Optional[Tensor] = None):
+        """``hist_ws`` (training, fp16 table): the forward also counts the corners per (level, table slice) into the binned
+        hash backward's workspace, so that the backward can skip its count pass"""
         lib = ops._lib.load()
         n = pts.shape[0]
         ws = torch.empty(lib.nerf_imlp_workspace_bytes(n), device=self.device, dtype=torch.uint8)
-        ops.hash_encode_fwd(pts, self._gather_table(), self.levels, self.bound, want_f32=False, out_nat=ws)
+        if hist_ws is not None:
+            ops._lib.check(lib.nerf_hash_encode_fwd_f16_hist(pts.data_ptr(), n, self._gather_table().data_ptr(), self.levels.n_levels,
+                                                             *self.levels.host_args(), float(self.bound), ws.data_ptr(), hist_ws.data_ptr(),
+                                                             hist_ws.numel(), ops._stream()), "nerf_hash_encode_fwd_f16_hist")
+        else:
+            ops.hash_encode_fwd(pts, self._gather_table(), self.levels, self.bound, want_f32=False, out_nat=ws)
         rgb, sigma = torch.empty(n, 3, device=self.device), torch.empty(n, device=self.device)
         ops._lib.check(lib.nerf_imlp_fwd(self.packed.data_ptr(), ws.data_ptr(), dirs.data_ptr(), n, rgb.data_ptr(),
                                          sigma.data_ptr(), 1 if train else 0, ops._stream()), "nerf_imlp_fwd")
@@ -363,7 +371,11 @@ class InstantNgpEngine:
                 for lo, hi in self.level_groups():
                     reduce(table_slice(lo, hi))
         else:
-            rgb, sigma, ws = self._field(pts, dirs, True)
+            # single-rank step on the fp16 table: forward counts the scatter's bins, the decoder's backward hands its feature
+            # gradients over level-major -- the hash backward starts at its plan pass (cfg precount: false = separate count pass)
+            precount = sync_grads_async is None and self.half_table and self.precount
+            hws = self._hash_bwd_workspace(n)
+            rgb, sigma, ws = self._field(pts, dirs, True, hist_ws=hws if precount else None)
             P = lambda t: t.data_ptr()
             # a fresh zeroed loss slot per step out of a ring cleared once per lap (no fill launch per step)
             self._grad_calls = getattr(self, "_grad_calls", -1) + 1
@@ -372,11 +384,21 @@ class InstantNgpEngine:
                 self._loss_ring.zero_()
             loss = self._loss_ring[slot:slot + 1]
             d_rgb, d_sigma, _ = ops.composite_mse_bwd(rgb, sigma, z, rays_d, self.bg, target, loss, slots=slots)
+            if precount:
+                import ctypes
+                amax_p, lm_p = ctypes.c_void_p(), ctypes.c_void_p()
+                ops._lib.check(lib.nerf_hash_encode_bwd_ws_slots(P(hws), n, self.levels.n_levels, ctypes.byref(amax_p), ctypes.byref(lm_p)),
+                               "nerf_hash_encode_bwd_ws_slots")
+                ops._lib.check(lib.nerf_imlp_bwd_lm(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(self.g_net),
+                                                    lm_p, amax_p, ops._stream()), "nerf_imlp_bwd_lm")
+                ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_precounted(P(pts), n, self.levels.n_levels, *self.levels.host_args(),
+                                                                            float(self.bound), P(self.g_table), P(hws), hws.numel(),
+                                                                            ops._stream()), "nerf_hash_encode_bwd_ws_store_precounted")
+                return loss[0].clone()
             d_feat = torch.empty(n, 2 * self.levels.n_levels, device=self.device)
             ops._lib.check(lib.nerf_imlp_bwd(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
                                              P(self.g_net), P(d_feat), ops._stream()), "nerf_imlp_bwd")
             reduce(self.g_net)
-            hws = self._hash_bwd_workspace(n)
             # overwrite form: the table gradient is stored slice by slice -- no 52 MB memset, no read-back
             if sync_grads_async is None:
                 ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, workspace=hws, overwrite=True)

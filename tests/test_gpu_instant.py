@@ -605,3 +605,39 @@ def test_hash_backward_overwrite_form_equals_accumulate_form(ops, case):
     empty = torch.full_like(ref, 3.0)
     ops.hash_encode_bwd(pts[:0], t, 1.5, d_feat[:0], empty, workspace=ws, overwrite=True)
     assert float(empty.abs().max()) == 0.0
+
+
+def test_instant_engine_precounted_backward_equals_separate_count_pass():
+    """The step's default path -- the hash forward counts the scatter's bins (nerf_hash_encode_fwd_f16_hist), the decoder's
+    backward writes level-major gradients and their maximum (nerf_imlp_bwd_lm), the hash backward starts at its plan pass
+    (nerf_hash_encode_bwd_ws_store_precounted) -- against the same engine with `precount: false` (separate count pass over
+    d_feat [n,32]): same loss, same network gradients, same table gradient."""
+    import yaml
+    from conftest import ROOT
+    from project_nerf_amd.engine import InstantNgpEngine
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    R, S = 1536, 48
+    gen = torch.Generator().manual_seed(2)
+    o = torch.randn(R, 3, generator=gen)
+    o = (o / o.norm(dim=-1, keepdim=True) * 4.0311).cuda()
+    d = ((torch.rand(R, 3, generator=gen) - 0.5) * 1.6).cuda() - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    target, u = torch.rand(R, 3, generator=gen).cuda(), torch.rand(R, S, generator=gen).cuda()
+    out = []
+    for precount in (True, False):
+        eng = InstantNgpEngine(dict(cfg, precount=precount), seed=0)
+        eng.table.copy_((torch.rand(eng.table.numel(), generator=torch.Generator().manual_seed(5)) - 0.5).cuda())
+        eng.net[2048:2048 + 64] *= 20.0
+        ops_mod = __import__("project_nerf_amd").ops
+        ops_mod.imlp_pack(eng.net, eng.packed)
+        ax = torch.linspace(-1.5, 1.5, 128)
+        gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+        eng.binary_grid = ((gx ** 2 + gy ** 2 + gz ** 2) < 1.2 ** 2).cuda()
+        eng.g_table.fill_(float("nan"))
+        loss = float(eng.compute_gradients(o, d.contiguous(), target, S, u=u))
+        out.append((loss, eng.g_net.clone(), eng.g_table.clone()))
+    (l1, n1, t1), (l0, n0, t0) = out
+    assert abs(l1 - l0) < 1e-6 * max(l0, 1.0) and bool(torch.isfinite(t1).all())
+    assert float((n1 - n0).abs().max()) <= 1e-5 * float(n0.abs().max())          # float atomics of the tiny wgrad
+    # zero-gradient points take part in the precounted form (they own eight all-zero records): the sums are the same
+    assert float((t1 - t0).abs().max()) <= 2e-6 * float(t0.abs().max())
