@@ -252,7 +252,11 @@ class InstantNgpEngine:
         # the fp32 master copy too): written by the optimiser kernel, refreshed here whenever torch code has
         # touched ``self.table`` in place (tensor version counter); cfg half_table: false keeps fp32 gathers
         self.half_table = bool(cfg.get("half_table", True))
-        self.precount = bool(cfg.get("precount", True))
+        # precount: the hash forward counts the scatter's bins and the decoder's backward writes level-major gradients, so the
+        # hash backward starts at its plan pass.  Built as the round-2 review asked and measured SLOWER on the same box
+        # (tools/ab_instant_precount.py: 0.699 against 0.651 ms per step -- eight LDS atomics per point and level in the
+        # latency-bound forward cost more than the 0.05 ms count pass they replace): off by default
+        self.precount = bool(cfg.get("precount", False))
         self.table_h = torch.empty(self.table.numel(), device=self.device, dtype=torch.float16) if self.half_table else None
         self._table_version = None
         self.packed = ops.imlp_pack(self.net)
@@ -371,8 +375,8 @@ class InstantNgpEngine:
                 for lo, hi in self.level_groups():
                     reduce(table_slice(lo, hi))
         else:
-            # single-rank step on the fp16 table: forward counts the scatter's bins, the decoder's backward hands its feature
-            # gradients over level-major -- the hash backward starts at its plan pass (cfg precount: false = separate count pass)
+            # opt-in (cfg precount: true; single rank, fp16 table): forward counts the scatter's bins, the decoder's backward
+            # hands its feature gradients over level-major -- the hash backward starts at its plan pass
             precount = sync_grads_async is None and self.half_table and self.precount
             hws = self._hash_bwd_workspace(n)
             rgb, sigma, ws = self._field(pts, dirs, True, hist_ws=hws if precount else None)

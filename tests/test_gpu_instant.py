@@ -608,10 +608,10 @@ def test_hash_backward_overwrite_form_equals_accumulate_form(ops, case):
 
 
 def test_instant_engine_precounted_backward_equals_separate_count_pass():
-    """The step's default path -- the hash forward counts the scatter's bins (nerf_hash_encode_fwd_f16_hist), the decoder's
-    backward writes level-major gradients and their maximum (nerf_imlp_bwd_lm), the hash backward starts at its plan pass
-    (nerf_hash_encode_bwd_ws_store_precounted) -- against the same engine with `precount: false` (separate count pass over
-    d_feat [n,32]): same loss, same network gradients, same table gradient."""
+    """The opt-in `precount: true` path -- the hash forward counts the scatter's bins (nerf_hash_encode_fwd_f16_hist), the
+    decoder's backward writes level-major gradients and their maximum (nerf_imlp_bwd_lm), the hash backward starts at its plan
+    pass (nerf_hash_encode_bwd_ws_store_precounted) -- against the default (separate count pass over d_feat [n,32]): same
+    loss, same network gradients, same table gradient."""
     import yaml
     from conftest import ROOT
     from project_nerf_amd.engine import InstantNgpEngine
