@@ -587,7 +587,7 @@ def main():
         out["kernels_in_step"] = {p: {"ms": v} for p, v in in_step.items()}
         out["kernels_in_step_note"] = ("HIP events on the launch stream between the phases of the timed step; "
                                        "fwd = mlp_fwd_stream_kernel<true, true>, loss = composite_mse_bwd_kernel, dgrad = mlp_bwd_stream_kernel<true>, "
-                                       "wgrad = memset + mlp_wgrad_kernel + wgrad_reduce_kernel, batch_sampling = train_batch_kernel (pixel draws, rays, targets, jittered depths)")
+                                       "wgrad = mlp_wgrad_kernel<false> + wgrad_reduce_kernel, batch_sampling = train_batch_kernel (pixel draws, rays, targets, jittered depths)")
         # ---- the same kernels launched back to back on their own (warm caches) ----
         o, d, target = ds.sample_batch(R, eng.bg)
         u = torch.rand(R, S, device=device)
@@ -647,10 +647,10 @@ def main():
         roofs = {
             "mlp_fwd_train": mfma_roof("mlp_fwd_stream_kernel<true, true>", "fwd", "mlp_fwd_train", n * FWD_FLOP),
             "mlp_bwd_dgrad": mfma_roof("mlp_bwd_stream_kernel<true>", "dgrad", "mlp_bwd_dgrad", n * DGRAD_FLOP),
-            "mlp_bwd_wgrad": mfma_roof("mlp_wgrad_kernel", "wgrad", "mlp_bwd_wgrad", n * WGRAD_FLOP),
-            "mlp_bwd_wgrad_hbm_view": {"bound": "hbm", "kernel": "mlp_wgrad_kernel", "achieved": wgrad_bytes / in_step["wgrad"] * 1e-6,
+            "mlp_bwd_wgrad": mfma_roof("mlp_wgrad_kernel<false>", "wgrad", "mlp_bwd_wgrad", n * WGRAD_FLOP),
+            "mlp_bwd_wgrad_hbm_view": {"bound": "hbm", "kernel": "mlp_wgrad_kernel<false>", "achieved": wgrad_bytes / in_step["wgrad"] * 1e-6,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": wgrad_bytes / in_step["wgrad"] * 1e-6 / HBM_PEAK_GBS,
-                                       "traffic": traffic("mlp_wgrad_kernel"), "work_per_launch": wgrad_bytes, "launch_ms": in_step["wgrad"],
+                                       "traffic": traffic("mlp_wgrad_kernel<false>"), "work_per_launch": wgrad_bytes, "launch_ms": in_step["wgrad"],
                                        "achieved_back_to_back": wgrad_bytes / k["mlp_bwd_wgrad"] * 1e-6, "launch_ms_back_to_back": k["mlp_bwd_wgrad"],
                                        "note": f"design traffic, not compulsory bytes: reads every bf16 training image once ({WGRAD_ELEMS * 2} B/sample)"},
         }

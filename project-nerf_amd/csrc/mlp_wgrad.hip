@@ -420,6 +420,9 @@ __device__ __forceinline__ void run_job(const WgradArgs& args, const WgradJob jo
   flush_tiles<NT_ACC, NT_NAT, ONES, SPLIT, FP8, NT>(args, job, acc, g, active);
 }
 
+// FP8 = false: bf16 training images (the default); true: the 8-bit opt-in.  Two instantiations, so that a profile of a run
+// that uses both (bench.py times the 8-bit step as a labelled secondary) reports them as two kernels
+template <bool FP8>
 __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   LaneGeo g;
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
     const long long a0 = lo > j0 ? lo - j0 : 0, a1 = (hi < j1 ? hi : j1) - j0;
     const int wt0 = (int)((a0 + job.cost - 1) / job.cost), wt1 = (int)((a1 + job.cost - 1) / job.cost);
     if (wt0 >= wt1) continue;
-    if (args.amax != nullptr) {   // 8-bit images (vanilla decoder, asm-stream family)
+    if constexpr (FP8) {          // 8-bit images (vanilla decoder, asm-stream family, option stash_fp8)
       switch (job.kind) {
         case 0: run_job8<8, 0, true>(args, job, wt0, wt1, smem, g); break;
         case 1: run_job8<8, 2, false>(args, job, wt0, wt1, smem, g); break;
@@ -460,8 +463,7 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
         case 4: run_job<8, 0, true, true, true>(args, job, wt0, wt1, smem, g); break;
         default: run_job<4, 0, true, true, true>(args, job, wt0, wt1, smem, g); break;
       }
-      continue;
-    }
+    } else {
     switch (job.kind) {
       case 0: run_job<8, 0, true, false, false>(args, job, wt0, wt1, smem, g); break;    // 256x256 (+bias)
       case 1: run_job<8, 2, false, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.4
@@ -473,6 +475,7 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
       case 7: run_job<2, 0, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant 64-wide layers
       case 8: run_job<1, 1, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant colour-net layer 1
       default: run_job<2, 0, false, true, false>(args, job, wt0, wt1, smem, g); break;   // instant rgb layer
+    }
     }
   }
 }
@@ -674,7 +677,9 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
 
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
-  if (int rc = ensure_dynamic_lds((const void*)mlp_wgrad_kernel, kWgLds, "nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
+  const bool fp8 = args.amax != nullptr;
+  if (int rc = ensure_dynamic_lds(fp8 ? (const void*)mlp_wgrad_kernel<true> : (const void*)mlp_wgrad_kernel<false>, kWgLds,
+                                  "nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
   long long want = (long long)args.wave_tiles * nj / 4;   // at least ~4 wave tiles per span
   if (options().wgrad_grid > 0 && options().wgrad_grid < n_cu) n_cu = options().wgrad_grid;
   int grid = (int)(want < 1 ? 1 : (want > n_cu ? n_cu : want));
@@ -722,7 +727,8 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
     else hipLaunchKernelGGL(mlp_wgrad_small_kernel<false>, dim3((int)g3), dim3(512), kWgStages * SmallStage::Bytes, stream, args);
     return check_launch("tiny-MLP wgrad");
   }
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid), dim3(512), kWgLds, stream, args);
+  if (fp8) hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(grid), dim3(512), kWgLds, stream, args);
+  else hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(grid), dim3(512), kWgLds, stream, args);
   if (args.slab != nullptr) {
     if (int rc = check_launch("nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(80, args.n_jobs), dim3(256), 0, stream, args);
