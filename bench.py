@@ -312,7 +312,8 @@ def bench_part4(args, device, steps=200):
         pass
 
     def traffic(names):
-        vals = [pmc.get(nm, {}).get("hbm_bytes_per_launch_corrected") for nm in names]
+        # kernels launched at several sizes per step (four grids, three optimiser groups): mean bytes per launch x launches per step
+        vals = [pmc.get(nm, {}).get("hbm_bytes_per_launch_mean") for nm in names]
         return sum(v * c for v, c in zip(vals, names.values())) if vals and all(v is not None for v in vals) else None
     # algorithmic bytes: forward gathers 8 corners x 4 B (fp16 pairs) per level and point; the scatter's read-modify-write 8 corners
     # x 16 B (+ the canonical grid's input gradient: 8 corners x 8 B); the optimiser streams params / grads / moments
