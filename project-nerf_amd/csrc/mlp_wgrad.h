@@ -11,6 +11,7 @@ constexpr int kWgStages = 4;
 constexpr int kWgStageA = 16 * 1024, kWgStageB = 16 * 1024, kWgStageN = 4 * 1024;
 constexpr int kWgStageBytes = kWgStageA + kWgStageB + kWgStageN;   // 36 KiB
 constexpr int kWgLds = kWgStages * kWgStageBytes;                 // 144 KiB
+constexpr int kWgScratch = 256;                                    // behind the ring: cross-wave sums at the end of a span
 constexpr int kMaxTiles = 10;                                      // n-tiles a wave accumulates
 
 struct WgradJob {
@@ -29,6 +30,11 @@ struct WgradJob {
   int acc_valid, acc_col0;
   int nat_valid, nat_col0;
   int bias_off, bias_nat_col;   // bias_nat_col < 0: bias comes from the ones tile
+  // second output of the merged feature + sigma job (a2 != null, bf16 images): the 16-wide natural gradient block whose row
+  // o2_row contracts with the same B image into grads[w2_off .. + acc_valid) and its sum over samples into grads[bias2_off];
+  // the partial tile carries n2 = acc_valid + 1 extra floats behind the bias sums
+  const char* a2;
+  int w2_off, bias2_off, o2_row, n2;
   long long cost0;      // prefix sum of cost (bytes per wave tile * wave tiles) before this job
   int cost;             // bytes per wave tile
   // slab mode (WgradArgs::slab): workgroups part0 .. part0 + n_parts - 1 hold a partial tile of this job, tile

@@ -286,6 +286,205 @@ __device__ __forceinline__ void run_job8(const WgradArgs& args, const WgradJob j
   flush_tiles<NT_ACC, NT_NAT, ONES, false, true, NT>(args, job, acc, g, active);
 }
 
+// LDS-DMA of one 1-KiB piece with a wave-uniform base: lane l copies base[voff_l .. +16) to LDS m0 + 16 l
+__device__ __forceinline__ void dma_1k_s(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+               : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
+// The bf16-image jobs of the vanilla decoder (kinds 0..5), straight-line form.  The generic run_job below decides at run time,
+// every ring iteration, how many pieces a wave copies, from which of the three images, and which s_waitcnt immediate fits: some
+// 500 shader cycles of scalar branches per iteration that all eight waves spend together behind the barrier (skeleton launch
+// without DMA and MFMAs: 0.28 us per iteration, 0.12 ms per step).  Here the piece counts are template constants (PA / PB / PN
+// 1-KiB pieces per wave tile of the A image, the blocked B image and the natural-order B image), every wave's pieces are
+// resolved once per span into (wave-uniform base, LDS offset, stride), the steady state is wait(2 PER) - barrier - PER copies -
+// MFMAs without a branch, and the last three iterations of a span are peeled.
+// SIG: the merged feature + sigma job -- both contract against the SAME h7 image, so sigma_layer's gradient rides on the
+// feature job's stream instead of re-reading 16 KiB per wave tile in a job of its own (one ring iteration and 5 % of the
+// kernel's bytes less per wave tile).  The 16-wide natural gradient block (job.a2) lands in the stage's unused N region; wave
+// w contracts it with column tile w (a tenth accumulator tile); its row o2_row summed over the samples is sigma_layer's bias
+// gradient: the wave whose turn it is (stage number mod 8) adds its operand registers on the vector ALU.
+template <int PA, int PB, int PN, int NT_ACC, int NT_NAT, bool ONES, bool SPLIT, bool SIG = false>
+__device__ __forceinline__ void run_job16(const WgradArgs& args, const WgradJob job, int wt0, int wt1, char* smem, const LaneGeo g) {
+  static_assert(!SIG || (PN == 0 && !SPLIT && NT_ACC == 8), "the merged job uses the N region and one column tile per wave");
+  constexpr int NT = SPLIT ? 2 : NT_ACC + NT_NAT + (ONES ? 1 : 0);
+  constexpr int PIECES = PA + PB + PN + (SIG ? 1 : 0), FULL = PIECES / 8, REM = PIECES % 8, PER = FULL + (REM ? 1 : 0);
+  const int wave = g.wave, lane = g.lane;
+  const bool active = SPLIT ? (wave <= NT_ACC) : (wave < PA / 2);
+  const bool compute = active && !(args.debug & 1), copy = !(args.debug & 2);
+  const bool extra = wave < REM;        // waves 0 .. REM-1 copy one piece more than the others
+  f32x16 acc[NT], acc_sig;
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_sig[r] = 0.0f;
+  float sig_bias = 0.0f;
+
+  // this wave's pieces: (wave-uniform source, LDS offset in the stage, bytes per wave tile of that image)
+  const char* base[PER];
+  unsigned dst[PER];
+  int stride[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int pc = wave + 8 * i;
+    pc = pc < PIECES ? pc : PIECES - 1;
+    if (pc < PA) {
+      stride[i] = PA * 1024;
+      base[i] = job.a + pc * 1024;
+      dst[i] = pc * 1024;
+    } else if (pc < PA + PB) {
+      stride[i] = PB * 1024;
+      base[i] = job.b_acc + (pc - PA) * 1024;
+      dst[i] = kWgStageA + (pc - PA) * 1024;
+    } else if (SIG && pc == PIECES - 1) {
+      stride[i] = 1024;
+      base[i] = job.a2;
+      dst[i] = kWgStageA + kWgStageB;
+    } else {
+      stride[i] = PN * 1024;
+      base[i] = job.b_nat + (pc - PA - PB) * 1024;
+      dst[i] = kWgStageA + kWgStageB + (pc - PA - PB) * 1024;
+    }
+    base[i] += (size_t)wt0 * stride[i];
+  }
+  const unsigned smem_lds = lds_addr(smem), voff = lane * 16;
+  auto issue = [&](int wt) {            // stages are issued in order: base[] walks with them
+    const unsigned stage = smem_lds + (wt & (kWgStages - 1)) * kWgStageBytes;
+#pragma unroll
+    for (int i = 0; i < FULL; ++i) {
+      dma_1k_s(base[i], voff, stage + dst[i]);
+      base[i] += stride[i];
+    }
+    if constexpr (REM != 0) {
+      if (extra) {
+        dma_1k_s(base[FULL], voff, stage + dst[FULL]);
+        base[FULL] += stride[FULL];
+      }
+    }
+  };
+  auto wait_stages = [&](auto stages) {   // all but the `stages` newest stages of this wave have landed
+    constexpr int S = decltype(stages)::value;
+    if constexpr (REM != 0) {
+      if (extra) wait_vm<S * (FULL + 1)>();
+      else wait_vm<S * FULL>();
+    } else wait_vm<S * FULL>();
+  };
+
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  auto mfmas = [&](int wt) {
+    const char* stage = smem + (wt & (kWgStages - 1)) * kWgStageBytes;
+    const char* pa = SPLIT ? stage + g.off_nat - 1024 * g.fhalf : stage + wave * 2048 + g.off_acc;
+    const char* pb = stage + kWgStageA + g.off_acc + (SPLIT ? (wave < NT_ACC ? wave : 0) * 2048 : 0);
+    const char* pn = stage + kWgStageA + kWgStageB + g.off_nat;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af = SPLIT ? tr_frag<128>(pa + 512 * s) : tr_frag<256>(pa + 1024 * s);
+      if (SPLIT && g.fhalf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) af[e] = (__bf16)0.0f;
+      }
+      if constexpr (SPLIT) {
+        if (wave < NT_ACC) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tr_frag<256>(pb + 1024 * s), acc[0], 0, 0, 0);
+        if (ONES && wave == NT_ACC % 8) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, acc[1], 0, 0, 0);
+      } else {
+        // all fragment reads of the k-step first, then the MFMAs: hipcc otherwise recycles one
+        // fragment register (read -> wait -> mfma), exposing the LDS latency per MFMA
+        bf16x8 bf[NT_ACC + NT_NAT + 1];
+#pragma unroll
+        for (int k = 0; k < NT_ACC; ++k) bf[k] = tr_frag<256>(pb + k * 2048 + 1024 * s);
+#pragma unroll
+        for (int k = 0; k < NT_NAT; ++k) bf[NT_ACC + k] = tr_frag<128>(pn + k * 2048 + 512 * s);
+        bf[NT_ACC + NT_NAT] = ones;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[k], acc[k], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (1 + NT_ACC + NT_NAT), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SIG) {
+          // after the k-step's own MFMAs, in the registers they freed (the kernel sits on the 256-register limit)
+          bf16x8 a2 = tr_frag<128>(pn - 1024 * g.fhalf + 512 * s);      // natural 16-wide block: the upper feature half reads as zeros
+          if (g.fhalf) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a2[e] = (__bf16)0.0f;
+          }
+          const bf16x8 b2 = tr_frag<256>(pb + wave * 2048 + 1024 * s);  // column tile `wave` of h7 once more (register arrays cannot be indexed by the wave)
+          acc_sig = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc_sig, 0, 0, 0);
+          if ((wt & 7) == wave) {      // lane r (r < 16) of each half holds 8 consecutive samples of gradient column r
+            const s16x8 bits = __builtin_bit_cast(s16x8, a2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sig_bias += __builtin_bit_cast(float, (unsigned)(unsigned short)bits[e] << 16);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+
+  __builtin_amdgcn_s_barrier();   // previous span's readers are done with the ring
+  if (copy) {
+    if (wt0 + 0 < wt1) issue(wt0 + 0);
+    if (wt0 + 1 < wt1) issue(wt0 + 1);
+    if (wt0 + 2 < wt1) issue(wt0 + 2);
+  }
+  int wt = wt0;
+  for (; wt + 3 < wt1; ++wt) {    // steady state: stages wt+1 and wt+2 stay in flight, the slot of stage wt-1 is refilled
+    wait_stages(std::integral_constant<int, 2>{});
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (copy) issue(wt + 3);
+    if (compute) mfmas(wt);
+  }
+  for (; wt < wt1; ++wt) {        // the span's last three stages: nothing left to issue
+    const int left = wt1 - 1 - wt;
+    if (left >= 2) wait_stages(std::integral_constant<int, 2>{});
+    else if (left == 1) wait_stages(std::integral_constant<int, 1>{});
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (compute) mfmas(wt);
+  }
+  flush_tiles<NT_ACC, NT_NAT, ONES, SPLIT, false, NT>(args, job, acc, g, active);
+  if constexpr (SIG) {
+    // row o2_row of the tenth tile = d sigma_layer.weight[wave*32 + c32]; the bias sum: lanes o2_row and 32 + o2_row of every
+    // wave hold partial sums over that wave's stages -> scratch behind the ring -> wave 0 adds the eight in order
+    float* red = reinterpret_cast<float*>(smem + kWgLds);
+    const float both = sig_bias + __shfl(sig_bias, (lane + 32) & 63);
+    if (lane == job.o2_row) red[wave] = both;
+    __builtin_amdgcn_s_barrier();
+    if (!(args.debug & 4)) {
+      const int c32 = lane & 31, hrow = lane >> 5;
+      float w = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if ((r & 3) + 8 * (r >> 2) + 4 * hrow == job.o2_row) w = acc_sig[r];
+      const bool mine = ((job.o2_row >> 2) & 1) == hrow;      // C layout: row = (r&3) + 8(r>>2) + 4 hrow
+      float bias = 0.0f;
+      if (wave == 0 && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bias += red[k];
+      }
+      if (args.slab != nullptr) {
+        float* tile = args.slab + job.slab_off + (long long)((int)blockIdx.x - job.part0) * job.p_stride + job.o_valid * job.w_ld + job.o_valid;
+        if (mine) tile[wave * 32 + c32] = w;
+        if (wave == 0 && lane == 0) tile[job.acc_valid] = bias;
+      } else {
+        if (mine) atomicAdd(args.grads + job.w2_off + wave * 32 + c32, w);
+        if (wave == 0 && lane == 0) atomicAdd(args.grads + job.bias2_off, bias);
+      }
+    }
+    __builtin_amdgcn_s_barrier();   // the scratch is free for the next span
+  }
+}
+
 // One job span [wt0, wt1) of one layer.  OWNER mode (SPLIT = false): wave w owns output rows
 // 32w.. x all NT = NT_ACC + NT_NAT + ONES column tiles.  SPLIT mode (single 16-row natural A
 // block, dsmall): wave w owns column tile w (w < NT_ACC) and wave NT_ACC % 8 the ones tile.
@@ -465,12 +664,13 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
       }
     } else {
     switch (job.kind) {
-      case 0: run_job<8, 0, true, false, false>(args, job, wt0, wt1, smem, g); break;    // 256x256 (+bias)
-      case 1: run_job<8, 2, false, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.4
-      case 2: run_job<0, 2, false, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.0
-      case 3: run_job<8, 1, false, false, false>(args, job, wt0, wt1, smem, g); break;   // view_layer
-      case 4: run_job<8, 0, true, true, false>(args, job, wt0, wt1, smem, g); break;     // sigma_layer
-      case 5: run_job<4, 0, true, true, false>(args, job, wt0, wt1, smem, g); break;     // rgb_layer
+      case 0: run_job16<16, 16, 0, 8, 0, true, false>(args, job, wt0, wt1, smem, g); break;    // 256x256 (+bias)
+      case 1: run_job16<16, 16, 4, 8, 2, false, false>(args, job, wt0, wt1, smem, g); break;   // pts_layers.4
+      case 2: run_job16<16, 0, 4, 0, 2, false, false>(args, job, wt0, wt1, smem, g); break;    // pts_layers.0
+      case 3: run_job16<8, 16, 2, 8, 1, false, false>(args, job, wt0, wt1, smem, g); break;    // view_layer
+      case 4: run_job16<1, 16, 0, 8, 0, true, true>(args, job, wt0, wt1, smem, g); break;      // sigma_layer
+      case 5: run_job16<1, 8, 0, 4, 0, true, true>(args, job, wt0, wt1, smem, g); break;       // rgb_layer
+      case 13: run_job16<16, 16, 0, 8, 0, true, false, true>(args, job, wt0, wt1, smem, g); break;   // feature_layer + sigma_layer
       case 6: run_job<0, 1, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant sigma-net layer 1
       case 7: run_job<2, 0, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant 64-wide layers
       case 8: run_job<1, 1, false, false, false>(args, job, wt0, wt1, smem, g); break;   // instant colour-net layer 1
@@ -527,7 +727,7 @@ __global__ void __launch_bounds__(512) mlp_wgrad_small_kernel(const WgradArgs ar
 // slab mode: grads[parameter] = sum over the job's partial tiles, in tile order (the same sum every run)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradArgs args) {
   const WgradJob& job = args.jobs[blockIdx.y];
-  const int n_w = job.o_valid * job.w_ld, n_all = n_w + job.o_valid;
+  const int n_w = job.o_valid * job.w_ld, n_b = n_w + job.o_valid, n_all = n_b + job.n2;
   const float* tile = args.slab + job.slab_off;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += gridDim.x * blockDim.x) {
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
@@ -541,7 +741,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradArgs args)
     for (; t < job.n_parts; ++t) s0 += tile[(long long)t * job.p_stride + i];
     const float sum = (s0 + s1) + (s2 + s3);
     if (i < n_w) args.grads[job.w_off + i] = sum;
-    else args.grads[job.bias_off + (i - n_w)] = sum;
+    else if (i < n_b) args.grads[job.bias_off + (i - n_w)] = sum;
+    else if (i < n_all - 1) args.grads[job.w2_off + (i - n_b)] = sum;      // merged job: second output behind the bias sums
+    else args.grads[job.bias2_off] = sum;
   }
 }
 
@@ -596,9 +798,12 @@ int nerf_launch_wgrad(const char* stash, const StashLayout& sl, const char* work
     j.a = work + bl.dfeat; j.a_bytes = 16384; j.mt_a = 8;
     j.b_acc = st_h(7); j.b_acc_bytes = 16384; j.nt_acc = 8; j.ones = 1; j.bias_nat_col = -1;
     j.w_off = kWFeat; j.w_ld = 256; j.o_valid = 256; j.acc_valid = 256; j.bias_off = kBFeat; j.kind = 0;
+    if (!sl.fp8) {   // bf16 images: sigma_layer (dsmall[:,3] x h7) rides on this job's stream of h7
+      j.a2 = work + bl.dsmall; j.w2_off = kWSigma; j.bias2_off = kBSigma; j.o2_row = 3; j.n2 = 257; j.kind = 13;
+    }
     add(j);
   }
-  {  // sigma_layer: dsmall[:,3] x h7
+  if (sl.fp8) {  // sigma_layer: dsmall[:,3] x h7
     WgradJob j{};
     j.a = work + bl.dsmall; j.a_bytes = 1024; j.a_nat = 1; j.mt_a = 1; j.split_n = 1;
     j.b_acc = st_h(7); j.b_acc_bytes = 16384; j.nt_acc = 8; j.ones = 1; j.bias_nat_col = -1;
@@ -641,7 +846,7 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   const int overhead = options().wgrad_overhead;
   for (int j = 0; j < nj; ++j) {
     WgradJob& jb = args.jobs[j];
-    const int bytes = jb.a_bytes + jb.b_acc_bytes + jb.b_nat_bytes;
+    const int bytes = jb.a_bytes + jb.b_acc_bytes + jb.b_nat_bytes + (jb.a2 ? 1024 : 0);
     jb.cost = bytes + overhead;
     if (args.amax != nullptr) {
       // 8-bit images: a stage costs max(DMA time, MFMA time) + a fixed share, in shader cycles.  DMA: the
@@ -678,7 +883,7 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   int n_cu = 0;
   if (int rc = device_cu_count(&n_cu); rc != NERF_OK) return rc;
   const bool fp8 = args.amax != nullptr;
-  if (int rc = ensure_dynamic_lds(fp8 ? (const void*)mlp_wgrad_kernel<true> : (const void*)mlp_wgrad_kernel<false>, kWgLds,
+  if (int rc = ensure_dynamic_lds(fp8 ? (const void*)mlp_wgrad_kernel<true> : (const void*)mlp_wgrad_kernel<false>, kWgLds + kWgScratch,
                                   "nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
   long long want = (long long)args.wave_tiles * nj / 4;   // at least ~4 wave tiles per span
   if (options().wgrad_grid > 0 && options().wgrad_grid < n_cu) n_cu = options().wgrad_grid;
@@ -705,7 +910,7 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
       ok = count > 0 && count == last - first + 1;          // contiguous (a tiny launch can leave holes: atomics then)
       jb.part0 = first;
       jb.n_parts = count;
-      jb.p_stride = (jb.o_valid * jb.w_ld + jb.o_valid + 63) / 64 * 64;
+      jb.p_stride = (jb.o_valid * jb.w_ld + jb.o_valid + jb.n2 + 63) / 64 * 64;
       jb.slab_off = off;
       off += (long long)count * jb.p_stride;
     }
@@ -717,7 +922,7 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   bool small = args.amax == nullptr && args.slab == nullptr && !options().wgrad_big_only, p4 = false;
   for (int j = 0; j < args.n_jobs; ++j) {
     const WgradJob& jb = args.jobs[j];
-    p4 = p4 || jb.kind >= 10;
+    p4 = p4 || (jb.kind >= 10 && jb.kind <= 12);
     small = small && jb.kind >= 6 && jb.a_bytes <= SmallStage::A && jb.b_acc_bytes <= SmallStage::B && jb.b_nat_bytes <= SmallStageP4::N;
   }
   if (p4 && !small) return fail(NERF_EINVAL, "wgrad: Part 4 job kinds run on the small-stage kernel only");
@@ -727,8 +932,8 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
     else hipLaunchKernelGGL(mlp_wgrad_small_kernel<false>, dim3((int)g3), dim3(512), kWgStages * SmallStage::Bytes, stream, args);
     return check_launch("tiny-MLP wgrad");
   }
-  if (fp8) hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(grid), dim3(512), kWgLds, stream, args);
-  else hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(grid), dim3(512), kWgLds, stream, args);
+  if (fp8) hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(grid), dim3(512), kWgLds + kWgScratch, stream, args);
+  else hipLaunchKernelGGL(mlp_wgrad_kernel<false>, dim3(grid), dim3(512), kWgLds + kWgScratch, stream, args);
   if (args.slab != nullptr) {
     if (int rc = check_launch("nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(80, args.n_jobs), dim3(256), 0, stream, args);

@@ -15,13 +15,13 @@ grads = torch.empty(ops.MLP_PARAM_COUNT, device="cuda")
 lib = ops._lib.load(); st = torch.cuda.current_stream().cuda_stream
 lib.nerf_mlp_bwd_dgrad(packed.data_ptr(), stash.data_ptr(), rgb.data_ptr(), sigma.data_ptr(), torch.randn_like(rgb).data_ptr(), torch.randn_like(sigma).data_ptr(), n, ws.data_ptr(), st)
 def t(it=20):
-    for _ in range(3): lib.nerf_mlp_bwd_wgrad(stash.data_ptr(), ws.data_ptr(), n, grads.data_ptr(), st)
+    for _ in range(3): ops._lib.check(lib.nerf_mlp_bwd_wgrad(stash.data_ptr(), ws.data_ptr(), n, grads.data_ptr(), st), "wgrad")
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(it): lib.nerf_mlp_bwd_wgrad(stash.data_ptr(), ws.data_ptr(), n, grads.data_ptr(), st)
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
 gb = (stash.numel() + ws.numel()) * 1e-9
-for dbg in (0, 1, 2, 3):
+for dbg in (0, 1, 2, 3, 7):
     ops._lib.set_option("wgrad_debug", dbg)
     ms = t()
     print(f"debug={dbg}: {ms:.3f} ms  {gb/ms*1e3:.0f} GB/s", flush=True)
