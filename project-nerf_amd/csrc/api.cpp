@@ -36,6 +36,7 @@ static const OptionSlot kSlots[] = {
     {"chain_grid", "NERF_CHAIN_GRID", &Options::chain_grid},
     {"wgrad_grid", "NERF_WGRAD_GRID", &Options::wgrad_grid},
     {"hash_fwd_lds_kb", "NERF_HASH_FWD_LDS_KB", &Options::hash_fwd_lds_kb},
+    {"hash_xcd", "NERF_HASH_XCD", &Options::hash_xcd},
 };
 
 Options& options() {

@@ -39,6 +39,7 @@ struct Options {
   int stash_fp8 = 0;             // 1: 8-bit training images (e4m3 / e5m2) in the asm-stream family instead of bf16
   int chain_grid = 0;            // > 0: cap the chain kernels' workgroup count (timing below the power limit; CU partition with wgrad_grid)
   int wgrad_grid = 0;            // > 0: cap the decoder weight-gradient kernel's workgroup count (two half-batches in flight)
+  int hash_xcd = 1;              // 1: hash-grid gather kernels launch XCD-aware (levels x and x + 8 on XCD x); 0: level-major 2-D launch (A/B)
   int hash_fwd_lds_kb = 36;      // dynamic LDS per hash-forward workgroup (occupancy throttle, see nerf_hash_encode_fwd); 0: none
 };
 Options& options();

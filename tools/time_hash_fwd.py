@@ -22,9 +22,11 @@ def tm(f, it=50):
     e0.record()
     for _ in range(it): f()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it * 1e3
-for kb in [int(x) for x in os.environ.get("LDS_KB", "0").split(",")]:
+for xcd in (1, 0):
+ lib.nerf_set_option(b"hash_xcd", xcd)
+ for kb in [int(x) for x in os.environ.get("LDS_KB", "0,36").split(",")]:
   lib.nerf_set_option(b"hash_fwd_lds_kb", kb)
   a = tm(lambda: ops.hash_encode_fwd(pts, table_h, L, 1.5, want_f32=False, out_nat=ws))
   b = tm(lambda: ops.hash_encode_fwd(pts, table, L, 1.5, want_f32=False, out_nat=ws))
   c = tm(lambda: ops.hash_encode_fwd(pts, table_h, L, 1.5, want_f32=True, out_nat=None))
-  print(f"lds {kb:3d} KB  n = {n}: fp16 table -> operand image {a:.1f} us | fp32 table -> operand image {b:.1f} us | fp16 table -> fp32 rows {c:.1f} us", flush=True)
+  print(f"xcd-aware {xcd} lds {kb:3d} KB  n = {n}: fp16 table -> operand image {a:.1f} us | fp32 table -> operand image {b:.1f} us | fp16 table -> fp32 rows {c:.1f} us", flush=True)
