@@ -25,6 +25,8 @@ static const OptionSlot kSlots[] = {
     {"wgrad_bw_x16", "NERF_WGRAD_BW", &Options::wgrad_bw_x16},
     {"wgrad_fixed", "NERF_WGRAD_FIXED", &Options::wgrad_fixed},
     {"wgrad_debug", "NERF_WGRAD_DEBUG", &Options::wgrad_debug},
+    {"wgrad_small_span", "NERF_WGRAD_SMALL_SPAN", &Options::wgrad_small_span},
+    {"wgrad_small_cap", "NERF_WGRAD_SMALL_CAP", &Options::wgrad_small_cap},
     {"wgrad_only", "NERF_WGRAD_ONLY", &Options::wgrad_only},
     {"hash_bwd_only_level", "NERF_HASH_BWD_ONLY_LEVEL", &Options::hash_bwd_only_level},
     {"hash_bwd_atomic", "NERF_HASH_BWD_ATOMIC", &Options::hash_bwd_atomic},

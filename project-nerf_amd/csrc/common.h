@@ -29,6 +29,8 @@ struct Options {
   int wgrad_bw_x16 = 192;        // span cost model, 8-bit images: DMA bytes per 16 shader cycles and CU
   int wgrad_fixed = 2000;        // ... and the fixed cycles per ring iteration
   int wgrad_debug = 0;           // skeleton timing: 1 no compute, 2 no DMA, 4 no flush
+  int wgrad_small_span = 32;     // tiny-MLP wgrad kernel: least wave tiles per workgroup span
+  int wgrad_small_cap = 3;       // ... and most workgroups per CU
   int wgrad_only = -1;           // keep one job kind
   int hash_bwd_only_level = -1;  // time one level's atomics
   int wgrad_big_only = 0;        // 1: the Instant tiny-MLP weight gradients on the decoder's one-workgroup-per-CU kernel (A/B)

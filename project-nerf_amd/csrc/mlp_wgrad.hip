@@ -927,7 +927,12 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   }
   if (p4 && !small) return fail(NERF_EINVAL, "wgrad: Part 4 job kinds run on the small-stage kernel only");
   if (small) {
-    long long g3 = want < 1 ? 1 : (want > 3LL * n_cu ? 3LL * n_cu : want);
+    // every workgroup ends its span with one float atomic per weight of the job: short spans on many workgroups turn the
+    // launch into an atomic storm on a few thousand addresses (54 k samples on 768 workgroups: 47 us, most of it the flush)
+    const long long span = options().wgrad_small_span > 0 ? options().wgrad_small_span : 4;
+    const long long cap = (long long)(options().wgrad_small_cap > 0 ? options().wgrad_small_cap : 3) * n_cu;
+    const long long want3 = (long long)args.wave_tiles * nj / span;
+    long long g3 = want3 < 1 ? 1 : (want3 > cap ? cap : want3);
     if (p4) hipLaunchKernelGGL(mlp_wgrad_small_kernel<true>, dim3((int)g3), dim3(512), kWgStages * SmallStageP4::Bytes, stream, args);
     else hipLaunchKernelGGL(mlp_wgrad_small_kernel<false>, dim3((int)g3), dim3(512), kWgStages * SmallStage::Bytes, stream, args);
     return check_launch("tiny-MLP wgrad");

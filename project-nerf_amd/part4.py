@@ -119,8 +119,9 @@ def forward_chain(packed, params, tables, levels_d, levels_c, bound, pts, x_def,
 
 
 def backward_chain(packed, params, table_c_f32, levels_d, levels_c, bound, x_in, xc, ws: Workspace, rgb, sigma, d_rgb, d_sigma,
-                   d_dx_extra, g_net, g_tables, hash_ws=None, after_canonical=None, after_grid=None):
-    """Adds the gradients of one batch into ``g_net`` [30145] and ``g_tables`` (4 tensors [E*2]).  ``d_dx_extra`` [n,3] or
+                   d_dx_extra, g_net, g_tables, hash_ws=None, after_canonical=None, after_grid=None, overwrite=False):
+    """Adds the gradients of one batch into ``g_net`` [30145] and ``g_tables`` (4 tensors [E*2]); ``overwrite`` (needs
+    ``hash_ws``): the table gradients are STORED instead (no zeroing by the caller, no read-back -- the engine's data batch).  ``d_dx_extra`` [n,3] or
     None: gradient reaching delta_x directly (displacement regulariser, a caller's loss on delta_x); rgb None: the
     deformation chain alone (regulariser probes).  ``after_*`` callbacks: data-parallel hooks (ranges that are final)."""
     lib = _lib.load()
@@ -131,7 +132,8 @@ def backward_chain(packed, params, table_c_f32, levels_d, levels_c, bound, x_in,
                    "nerf_p4_canon_bwd")
         d_feat_c = ws.d_feat(3)
         d_xc = ops.hash_encode_bwd_input(xc, table_c_f32.view(-1, 2), levels_c, bound, d_feat_c)
-        ops.hash_encode_bwd(xc, levels_c, bound, d_feat_c, g_tables[3], workspace=hash_ws(n, levels_c.n_levels) if hash_ws else None)
+        ops.hash_encode_bwd(xc, levels_c, bound, d_feat_c, g_tables[3], workspace=hash_ws(n, levels_c.n_levels) if hash_ws else None,
+                            overwrite=overwrite)
         if after_grid is not None:
             after_grid(3)
         d_dx = d_xc if d_dx_extra is None else d_xc.add_(d_dx_extra)
@@ -139,7 +141,8 @@ def backward_chain(packed, params, table_c_f32, levels_d, levels_c, bound, x_in,
     if after_canonical is not None:
         after_canonical()
     for k in range(3):
-        ops.hash_encode_bwd(x_in, levels_d, bound, ws.d_feat(k), g_tables[k], workspace=hash_ws(n, levels_d.n_levels) if hash_ws else None)
+        ops.hash_encode_bwd(x_in, levels_d, bound, ws.d_feat(k), g_tables[k], workspace=hash_ws(n, levels_d.n_levels) if hash_ws else None,
+                            overwrite=overwrite)
         if after_grid is not None:
             after_grid(k)
 
@@ -325,12 +328,12 @@ class DualHashEngine:
         n = pts.shape[0]
         bg = self.bg if bg is None else bg
         self.g_net.zero_()
-        self.g_tables.zero_()
         self._scalars.zero_()
         loss, reg = self._scalars[0:1], self._scalars[1:2]
         handles = []
         reduce = (lambda view: handles.append(sync_grads_async(view))) if sync_grads_async is not None else (lambda view: None)
         if n == 0:
+            self.g_tables.zero_()
             loss = ((bg.expand(R, 3) - target) ** 2).mean().reshape(1)
         else:
             lib = _lib.load()
@@ -344,7 +347,7 @@ class DualHashEngine:
                                                       P(d_rgb), P(d_sigma), P(d_extra), ops._stream()), "nerf_composite_mse_reg_bwd")
             g_tabs = [self.g_table(k) for k in range(4)]
             backward_chain(self.packed, self.net, self.table(3), self.levels_d, self.levels_c, self.bound, pts if x_def is None else x_def,
-                           xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch,
+                           xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch, overwrite=True,
                            after_grid=(lambda k: reduce(g_tabs[k])) if (sync_grads_async is not None and probes is None) else None)
         if probes is not None:
             self._probe_regularisers(probes)
