@@ -182,7 +182,7 @@ static int tv_normsq_impl(const float* params, float* grads, int64_t n, float tv
   NERF_REQUIRE(params && grads, "nerf_tv_normsq: NULL pointer");
   const float tv_scale = n > 1 ? tv_weight / (float)(n - 1) : 0.0f;      // d/dp of mean|p[1:] - p[:-1]| * w
   int64_t blocks = (n / 4 + 255) / 256 + 1;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 1024) blocks = 1024;      // measured: 512 +6 %, 256 +50 %, 2048 +15 % (one same-address atomic per workgroup against HBM streams in flight)
   if ((((uintptr_t)params | (uintptr_t)grads) & 15) == 0)
     hipLaunchKernelGGL(nerf::tv_normsq_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
                        tv_scale, grad_scale, normsq_dev);

@@ -39,6 +39,7 @@ static const OptionSlot kSlots[] = {
     {"wgrad_grid", "NERF_WGRAD_GRID", &Options::wgrad_grid},
     {"hash_fwd_lds_kb", "NERF_HASH_FWD_LDS_KB", &Options::hash_fwd_lds_kb},
     {"hash_xcd", "NERF_HASH_XCD", &Options::hash_xcd},
+    {"composite_wgs_per_cu", "NERF_COMPOSITE_WGS", &Options::composite_wgs_per_cu},
 };
 
 Options& options() {

@@ -41,6 +41,8 @@ struct Options {
   int stash_fp8 = 0;             // 1: 8-bit training images (e4m3 / e5m2) in the asm-stream family instead of bf16
   int chain_grid = 0;            // > 0: cap the chain kernels' workgroup count (timing below the power limit; CU partition with wgrad_grid)
   int wgrad_grid = 0;            // > 0: cap the decoder weight-gradient kernel's workgroup count (two half-batches in flight)
+  int composite_wgs_per_cu = 2;  // fused compositing + loss backward: workgroups per CU.  Every workgroup ends with same-address atomics (loss, regulariser,
+                                 // maximum), which retire one after the other in L2: 8 per CU 58 us, 4: 35, 2: 27, 1: 29 (8192 rays x 64, Part 4 step)
   int hash_xcd = 1;              // 1: hash-grid gather kernels launch XCD-aware (levels x and x + 8 on XCD x); 0: level-major 2-D launch (A/B)
   int hash_fwd_lds_kb = 36;      // dynamic LDS per hash-forward workgroup (occupancy throttle, see nerf_hash_encode_fwd); 0: none
 };

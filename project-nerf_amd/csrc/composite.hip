@@ -454,7 +454,7 @@ extern "C" int nerf_composite_mse_bwd(const float* rgb, const float* sigma, cons
   NERF_REQUIRE(rgb && sigma && z && rays_d && target && loss_accum && d_rgb && d_sigma, "nerf_composite_mse_bwd: NULL pointer");
   NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_mse_bwd: bg_rows=%lld", (long long)bg_rows);
   int64_t blocks = (n_rays + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks > 256 * (int64_t)options().composite_wgs_per_cu) blocks = 256 * (int64_t)options().composite_wgs_per_cu;
   const dim3 grid((int)blocks);
   DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
              slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, amax_accum,
@@ -474,7 +474,7 @@ extern "C" int nerf_composite_mse_reg_bwd(const float* rgb, const float* sigma, 
                "nerf_composite_mse_reg_bwd: NULL pointer");
   NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_mse_reg_bwd: bg_rows=%lld", (long long)bg_rows);
   int64_t blocks = (n_rays + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks > 256 * (int64_t)options().composite_wgs_per_cu) blocks = 256 * (int64_t)options().composite_wgs_per_cu;
   const dim3 grid((int)blocks);
   DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
              slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, (float*)nullptr, extra, reg_weight, d_extra,

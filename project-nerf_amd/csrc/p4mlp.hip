@@ -430,8 +430,17 @@ __global__ void __launch_bounds__(kThreads) deform_bwd_kernel(const DeformArgs a
     run<T2t, 4>(wbase, gt2, grad_epi(gt1, a.dzt1, mask.x));
     (void)gt1;
   }
+  // one atomic per workgroup (same-address float atomics retire one after the other in L2)
+  __shared__ float gscale_part[kThreads / 64];
   gscale_local = wave_sum(gscale_local);
-  if (lane == 0 && gscale_local != 0.0f) atomicAdd(a.g_scale, gscale_local);
+  if (lane == 0) gscale_part[threadIdx.x >> 6] = gscale_local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) sum += gscale_part[w];
+    if (sum != 0.0f) atomicAdd(a.g_scale, sum);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ canonical chain
