@@ -8,9 +8,11 @@
 // lane, 4 consecutive features per 8 bytes", the transposing read returns "feature on lane,
 // 4 consecutive samples" = the A/B fragment of a contraction over samples.  Wave w owns
 // output rows 32w..32w+31 x all input columns (fp32 accumulators stay in registers for the
-// whole span), bias gradients fall out of an all-ones column.  Partial sums are flushed with
-// float atomics (two 128-byte segments per wave instruction).
-// HBM-bound: every stashed byte is read exactly once (about 10.4 KB per sample).
+// whole span), bias gradients fall out of an all-ones column.  Every workgroup stores its partial
+// tile with plain stores and wgrad_reduce_kernel sums a job's tiles in order (small launches: float
+// atomics).  HBM-bound: every stashed byte is read exactly once (9.8 KB per sample: sigma_layer's
+// gradient rides on the feature job's stream of h7).  The decoder's bf16 jobs run in run_job16 (piece
+// counts as template constants, straight-line ring loop), everything else in the generic run_job.
 #include <stdlib.h>
 #include "mlp_chain.h"
 #include "mlp_stash.h"
