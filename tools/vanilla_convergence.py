@@ -1,5 +1,6 @@
-"""PSNR-vs-steps of the vanilla engine on the synthetic scene (development aid); argument `bf16` selects the
-compiler-scheduled kernels with bf16 training images, default = asm-stream kernels with 8-bit images."""
+"""PSNR-vs-steps of the vanilla engine on the synthetic scene (development aid).  Default: the asm-stream kernels with bf16
+training images (the bench headline); `fp8`: the same kernels with 8-bit images (option stash_fp8); `legacy`: the
+compiler-scheduled kernels with bf16 images."""
 import os
 import sys, numpy as np, torch, tempfile, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -9,9 +10,12 @@ root = write_synthetic_scene(tempfile.mkdtemp() + "/scene", n_train=20, n_test=2
 ds = BlenderDataset(root, "train", 1, True, 1.0).to("cuda")
 test = BlenderDataset(root, "test", 1, True, 1.0)
 from project_nerf_amd import _lib
-if len(sys.argv) > 1 and sys.argv[1] == "bf16":      # compiler-scheduled family: bf16 training images (A/B reference)
+mode = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+if mode == "legacy":
     _lib.set_option("chain_legacy", 1)
-print("training images:", "bf16 (compiler-scheduled kernels)" if _lib.get_option("chain_legacy") else "8-bit (asm-stream kernels)")
+if mode == "fp8":
+    _lib.set_option("stash_fp8", 1)
+print("training images:", {"legacy": "bf16 (compiler-scheduled kernels)", "fp8": "8-bit (asm-stream kernels)"}.get(mode, "bf16 (asm-stream kernels)"))
 eng = VanillaNerfEngine(seed=0, lr=5e-4)
 torch.manual_seed(0)
 o_t, d_t, tgt = test.get_image_rays(0, "cuda")
