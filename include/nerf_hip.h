@@ -366,6 +366,12 @@ int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const float* table, 
                                const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                                const unsigned* offset_host, const unsigned* dense_host, float bound,
                                const float* d_feat, float* d_pts, nerf_stream_t stream);
+/* the same gradient from the fp16 copy of the table the forward evaluated (nerf_adamw_clip_step_shadow keeps it): the
+ * derivative of the function the forward computed, at half the bytes per gather */
+int nerf_hash_encode_bwd_input_f16(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                   const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                   const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                   const float* d_feat, float* d_pts, nerf_stream_t stream);
 
 
 /* ---- a7: Instant decoder (two bias-free tiny MLPs, bf16 MFMA) -----------------------

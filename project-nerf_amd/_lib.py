@@ -78,6 +78,7 @@ PROTOTYPES = {
     "nerf_hash_encode_bwd_ws_store_precounted": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),
     "nerf_imlp_bwd_lm": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_input": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_hash_encode_bwd_input_f16": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_imlp_packed_bytes": (size_t, []),
     "nerf_imlp_workspace_bytes": (size_t, [i64]),
     "nerf_imlp_hash_operand_offset": (size_t, [i64]),

@@ -181,8 +181,9 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const T
 //   d x01 / d x = 1 / (2 bound) inside the box, 0 where HashRepresentation's clamp is active.
 // One thread per (point, level), level-major like the forward; the 16 levels of a point meet in d_pts through
 // float atomics (three per thread; d_pts is zeroed by the launcher).
+template <class TableT>
 __global__ void __launch_bounds__(256)
-hash_bwd_input_kernel(const float* __restrict__ pts, int64_t n, const float2* __restrict__ table, HashLevels L,
+hash_bwd_input_kernel(const float* __restrict__ pts, int64_t n, const TableT* __restrict__ table, HashLevels L,
                       const float* __restrict__ d_feat, float* __restrict__ d_pts, int n_chunks) {
   const LevelChunk lc = level_chunk(L.n_levels, n_chunks);
   if (lc.lvl >= L.n_levels) return;
@@ -204,7 +205,7 @@ hash_bwd_input_kernel(const float* __restrict__ pts, int64_t n, const float2* __
     float d[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float2 v = table[c.idx[k]];
+      const float2 v = table_entry(table, c.idx[k]);
       const float gv = g0 * v.x + g1 * v.y;
       const float wx = (k & 1) ? frac[0] : 1.0f - frac[0], wy = (k & 2) ? frac[1] : 1.0f - frac[1], wz = (k & 4) ? frac[2] : 1.0f - frac[2];
       d[0] += gv * ((k & 1) ? 1.0f : -1.0f) * wy * wz;
@@ -941,13 +942,13 @@ extern "C" int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_
                        stream, workspace, workspace_bytes, true, true);
 }
 
-extern "C" int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const float* table, int n_levels,
-                                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
-                                          const unsigned* offset_host, const unsigned* dense_host, float bound,
-                                          const float* d_feat, float* d_pts, nerf_stream_t stream) {
+static int hash_bwd_input_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
+                               const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                               const unsigned* offset_host, const unsigned* dense_host, float bound,
+                               const float* d_feat, float* d_pts, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd_input: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
-  NERF_REQUIRE(pts && table && d_feat && d_pts && scale_host && res_host && size_host && offset_host && dense_host,
+  NERF_REQUIRE(pts && (table || table_f16) && d_feat && d_pts && scale_host && res_host && size_host && offset_host && dense_host,
                "nerf_hash_encode_bwd_input: NULL pointer");
   HashLevels L;
   int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
@@ -957,7 +958,28 @@ extern "C" int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const flo
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   const bool xcd = options().hash_xcd != 0;
-  hipLaunchKernelGGL(hash_bwd_input_kernel, level_chunk_grid(n_levels, blocks, xcd), dim3(256), 0, as_stream(stream), pts, n,
-                     reinterpret_cast<const float2*>(table), L, d_feat, d_pts, xcd ? (int)blocks : 0);
+  const dim3 grid = level_chunk_grid(n_levels, blocks, xcd);
+  if (table_f16 != nullptr)
+    hipLaunchKernelGGL(hash_bwd_input_kernel<half2_t>, grid, dim3(256), 0, as_stream(stream), pts, n,
+                       static_cast<const half2_t*>(table_f16), L, d_feat, d_pts, xcd ? (int)blocks : 0);
+  else
+    hipLaunchKernelGGL(hash_bwd_input_kernel<float2>, grid, dim3(256), 0, as_stream(stream), pts, n,
+                       reinterpret_cast<const float2*>(table), L, d_feat, d_pts, xcd ? (int)blocks : 0);
   return check_launch("nerf_hash_encode_bwd_input");
+}
+
+extern "C" int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const float* table, int n_levels,
+                                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                          const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                          const float* d_feat, float* d_pts, nerf_stream_t stream) {
+  return hash_bwd_input_impl(pts, n, table, nullptr, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat,
+                             d_pts, stream);
+}
+
+extern "C" int nerf_hash_encode_bwd_input_f16(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                              const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                              const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                              const float* d_feat, float* d_pts, nerf_stream_t stream) {
+  return hash_bwd_input_impl(pts, n, nullptr, table_f16, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound,
+                             d_feat, d_pts, stream);
 }

@@ -733,12 +733,16 @@ class _HashEncode(torch.autograd.Function):
 
 
 def hash_encode_bwd_input(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor) -> Tensor:
-    """d_pts [n,3]: gradient of the features w.r.t. the encoded positions (dynamic fields)."""
+    """d_pts [n,3]: gradient of the features w.r.t. the encoded positions (dynamic fields); ``table`` fp32 [E,2] or the fp16
+    copy the forward evaluated."""
     lib = _lib.load()
-    pts, table, d_feat = _dev(pts, "pts"), _dev(table, "table"), _dev(d_feat, "d_feat")
+    if not isinstance(table, Tensor) or table.dtype not in (torch.float32, torch.float16):
+        raise TypeError("hash_encode_bwd_input: table must be an fp32 or fp16 tensor")
+    pts, table, d_feat = _dev(pts, "pts"), _dev(table, "table", table.dtype), _dev(d_feat, "d_feat")
     d_pts = torch.empty_like(pts)
-    _lib.check(lib.nerf_hash_encode_bwd_input(_p(pts), pts.shape[0], _p(table), levels.n_levels, *levels.host_args(), float(bound),
-                                              _p(d_feat), _p(d_pts), _stream()), "nerf_hash_encode_bwd_input")
+    fn = lib.nerf_hash_encode_bwd_input_f16 if table.dtype == torch.float16 else lib.nerf_hash_encode_bwd_input
+    _lib.check(fn(_p(pts), pts.shape[0], _p(table), levels.n_levels, *levels.host_args(), float(bound), _p(d_feat), _p(d_pts), _stream()),
+               "nerf_hash_encode_bwd_input")
     return d_pts
 
 

@@ -118,7 +118,7 @@ def forward_chain(packed, params, tables, levels_d, levels_c, bound, pts, x_def,
     return rgb, sigma, dx, xc
 
 
-def backward_chain(packed, params, table_c_f32, levels_d, levels_c, bound, x_in, xc, ws: Workspace, rgb, sigma, d_rgb, d_sigma,
+def backward_chain(packed, params, table_c, levels_d, levels_c, bound, x_in, xc, ws: Workspace, rgb, sigma, d_rgb, d_sigma,
                    d_dx_extra, g_net, g_tables, hash_ws=None, after_canonical=None, after_grid=None, overwrite=False):
     """Adds the gradients of one batch into ``g_net`` [30145] and ``g_tables`` (4 tensors [E*2]); ``overwrite`` (needs
     ``hash_ws``): the table gradients are STORED instead (no zeroing by the caller, no read-back -- the engine's data batch).  ``d_dx_extra`` [n,3] or
@@ -131,7 +131,7 @@ def backward_chain(packed, params, table_c_f32, levels_d, levels_c, bound, x_in,
         _lib.check(lib.nerf_p4_canon_bwd(P(packed), P(ws.buf), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(g_net), ops._stream()),
                    "nerf_p4_canon_bwd")
         d_feat_c = ws.d_feat(3)
-        d_xc = ops.hash_encode_bwd_input(xc, table_c_f32.view(-1, 2), levels_c, bound, d_feat_c)
+        d_xc = ops.hash_encode_bwd_input(xc, table_c.view(-1, 2), levels_c, bound, d_feat_c)
         ops.hash_encode_bwd(xc, levels_c, bound, d_feat_c, g_tables[3], workspace=hash_ws(n, levels_c.n_levels) if hash_ws else None,
                             overwrite=overwrite)
         if after_grid is not None:
@@ -346,7 +346,7 @@ class DualHashEngine:
                                                       P(dx), self.reg_weight / (3 * R), R, n_samples, None, None, P(loss), P(reg),
                                                       P(d_rgb), P(d_sigma), P(d_extra), ops._stream()), "nerf_composite_mse_reg_bwd")
             g_tabs = [self.g_table(k) for k in range(4)]
-            backward_chain(self.packed, self.net, self.table(3), self.levels_d, self.levels_c, self.bound, pts if x_def is None else x_def,
+            backward_chain(self.packed, self.net, self.table(3, half=True), self.levels_d, self.levels_c, self.bound, pts if x_def is None else x_def,
                            xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch, overwrite=True,
                            after_grid=(lambda k: reduce(g_tabs[k])) if (sync_grads_async is not None and probes is None) else None)
         if probes is not None:

@@ -67,6 +67,11 @@ def test_hash_input_gradient_vs_oracle_autograd():
     (ops.hash_encode(tg, xg, t, 1.5) * d_feat.cuda()).sum().backward()
     np.testing.assert_allclose(xg.grad.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
     assert float(tg.grad.abs().sum()) > 0
+    # the fp16 copy of the table (what the engines' forward evaluates): the same arithmetic on the rounded entries
+    half = table.half()
+    d_half = ops.hash_encode_bwd_input(pts.cuda(), half.cuda(), t, 1.5, d_feat.cuda())
+    d_round = ops.hash_encode_bwd_input(pts.cuda(), half.float().cuda(), t, 1.5, d_feat.cuda())
+    np.testing.assert_allclose(d_half.cpu().numpy(), d_round.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))   # float atomics: order
 
 
 def test_part4_forward_vs_reference_golden(model):
