@@ -326,7 +326,7 @@ def bench_part4(args, device, steps=200):
         "backward": {"kernel": "p4 chains bwd + mlp_wgrad_small_kernel<true> x2 + hash_bwd_input_kernel + hash_bin_* x4", "work_per_launch": scatter,
                      "ms": k["chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters"],
                      "traffic": traffic({"hash_bin_count_pm_kernel": 4, "hash_bin_plan_kernel": 4, "hash_bin_scatter_kernel<true>": 4,
-                                         "hash_bin_reduce_kernel": 4, "hash_bwd_input_kernel": 1, "p4::canon_bwd_kernel": 1,
+                                         "hash_bin_reduce_kernel": 4, "hash_bwd_input_kernel<fp16 table>": 1, "p4::canon_bwd_kernel": 1,
                                          "p4::deform_bwd_kernel": 1, "mlp_wgrad_small_kernel<true>": 2})},
         "tv_clip_adamw": {"kernel": "tv_normsq_kernel<true> x5 + adamw_clip_kernel<true> x3", "work_per_launch": n_par * 42,
                           "ms": k["tv + clip + adamw (28.5 M parameters)"],

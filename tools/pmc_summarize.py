@@ -56,8 +56,8 @@ def _short(name):
     if m is None:
         return name.split("(")[0]
     base = m.group(1)
-    if base == "hash_fwd_kernel":                        # template argument is a vector type: nested brackets
-        return "hash_fwd_kernel<fp16 table>" if ("_Float16" in name.split("(")[0] or "DF16_" in name.split("(")[0]) else "hash_fwd_kernel<fp32 table>"
+    if base in ("hash_fwd_kernel", "hash_bwd_input_kernel"):     # template argument is a vector type: nested brackets
+        return base + ("<fp16 table>" if ("_Float16" in name.split("(")[0] or "DF16_" in name.split("(")[0]) else "<fp32 table>")
     t = re.match(r"<[^()]*>", name[m.end():])
     return base + (t.group(0) if t else "")
 
