@@ -17,7 +17,9 @@ Tensor = torch.Tensor
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """raw HIP stream of torch's current stream on the current device.  torch.cuda.current_stream() costs ~8 us of Python per
+    call (device-index plumbing, availability checks) and a step makes dozens: the C accessor torch itself uses instead"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _dev(t: Tensor, name: str, dtype=torch.float32) -> Tensor:
@@ -582,7 +584,11 @@ class HashLevelTable:
         self.dense = _np.asarray(dense, dtype=_np.uint32)
 
     def host_args(self):
-        return tuple(a.ctypes.data_as(_ct.c_void_p) for a in (self.scale, self.res, self.size, self.offset, self.dense))
+        """the five level arrays as ctypes pointers (built once: the arrays are never reallocated)"""
+        args = getattr(self, "_host_args", None)
+        if args is None:
+            args = self._host_args = tuple(a.ctypes.data_as(_ct.c_void_p) for a in (self.scale, self.res, self.size, self.offset, self.dense))
+        return args
 
 
 def hash_encode_fwd(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: float,
