@@ -98,6 +98,41 @@ inline dim3 level_chunk_grid(int n_levels, int64_t blocks, bool xcd_aware) {
   return xcd_aware ? dim3((unsigned)(8 * ((n_levels + 7) / 8) * blocks)) : dim3((unsigned)blocks, (unsigned)n_levels);
 }
 
+// The eight entries of a cell, gathered with as few cache-line requests as the addresses allow.  Corners 2j and 2j+1 differ in x
+// only: on a dense level their entries are neighbours (e, e + 1), on a hashed level with an even cell x they are e and e ^ 1
+// (the hash XORs x in unmultiplied) -- either way one 8-byte (fp16 table) / 16-byte (fp32) load at min(e0, e1) returns both.
+// Otherwise (hashed level, odd x: the carry changes higher bits) the second corner takes its own load.  The gather kernels are
+// bound by the texture path's line rate (one 64-byte line per lane and request on the hashed levels), not by bytes.
+struct half2x2 { half2_t a, b; };
+__device__ __forceinline__ void table_pair(const float2* t, unsigned lo, float2& v0, float2& v1) {
+  float4 q;
+  __builtin_memcpy(&q, reinterpret_cast<const char*>(t + lo), 16);      // 8-byte aligned: two dwordx2 or one dwordx4
+  v0 = make_float2(q.x, q.y);
+  v1 = make_float2(q.z, q.w);
+}
+__device__ __forceinline__ void table_pair(const half2_t* t, unsigned lo, float2& v0, float2& v1) {
+  half2x2 q;
+  __builtin_memcpy(&q, reinterpret_cast<const char*>(t + lo), 8);       // 4-byte aligned dwordx2
+  v0 = make_float2((float)q.a[0], (float)q.a[1]);
+  v1 = make_float2((float)q.b[0], (float)q.b[1]);
+}
+template <class TableT>
+__device__ __forceinline__ void gather_cell(const TableT* __restrict__ table, const Corner& c, float2 (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned e0 = c.idx[2 * j], e1 = c.idx[2 * j + 1], lo = e0 < e1 ? e0 : e1;
+    if ((e0 > e1 ? e0 - e1 : e1 - e0) == 1u) {
+      float2 p0, p1;
+      table_pair(table, lo, p0, p1);                       // entries lo and lo + 1 = the two corners
+      v[2 * j] = e0 == lo ? p0 : p1;
+      v[2 * j + 1] = e0 == lo ? p1 : p0;
+    } else {
+      v[2 * j] = table_entry(table, e0);
+      v[2 * j + 1] = table_entry(table, e1);
+    }
+  }
+}
+
 template <class TableT>
 __global__ void __launch_bounds__(256)
 hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const TableT* __restrict__ table, HashLevels L,
@@ -130,11 +165,12 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const T
       for (int k = 0; k < 8; ++k) atomicAdd(&hist_lds[(c.idx[k] - lvl_offset) >> kSliceLog2], 1u);
     }
     float f0 = 0.0f, f1 = 0.0f;
+    float2 v[8];
+    gather_cell(table, c, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float2 v = table_entry(table, c.idx[k]);
-      f0 += c.w[k] * v.x;
-      f1 += c.w[k] * v.y;
+    for (int k = 0; k < 8; ++k) {                           // the sums run over the corners in the reference's order
+      f0 += c.w[k] * v[k].x;
+      f1 += c.w[k] * v[k].y;
       if (idx_out != nullptr && p < n) idx_out[g * 8 + k] = c.idx[k];
     }
     if (out_f32 != nullptr && p < n) {
@@ -203,9 +239,11 @@ hash_bwd_input_kernel(const float* __restrict__ pts, int64_t n, const TableT* __
       frac[a] = sub_rn(pos, floorf(pos));
     }
     float d[3] = {0.0f, 0.0f, 0.0f};
+    float2 tv[8];
+    gather_cell(table, c, tv);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float2 v = table_entry(table, c.idx[k]);
+      const float2 v = tv[k];
       const float gv = g0 * v.x + g1 * v.y;
       const float wx = (k & 1) ? frac[0] : 1.0f - frac[0], wy = (k & 2) ? frac[1] : 1.0f - frac[1], wz = (k & 4) ? frac[2] : 1.0f - frac[2];
       d[0] += gv * ((k & 1) ? 1.0f : -1.0f) * wy * wz;
