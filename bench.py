@@ -299,8 +299,8 @@ def bench_part4(args, device, steps=200):
                                                                                                 ws.nat(i), fp16=True) for i in range(4)], 20),
         "hash_fwd + fused chains fwd": event_ms(fwd, 20),
         "chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters": event_ms(
-            lambda: p4.backward_chain(eng.packed, eng.net, eng.table(3), eng.levels_d, eng.levels_c, eng.bound, pts, xc, ws, rgb, sigma, d_rgb, d_sigma,
-                                      d_dx.clone(), eng.g_net, g_tabs, hash_ws=eng._hash_scratch), 20),
+            lambda: p4.backward_chain(eng.packed, eng.net, eng.table(3, half=True), eng.levels_d, eng.levels_c, eng.bound, pts, xc, ws, rgb, sigma,
+                                      d_rgb, d_sigma, d_dx.clone(), eng.g_net, g_tabs, hash_ws=eng._hash_scratch, overwrite=True), 20),   # as the engine's step calls it
         "tv + clip + adamw (28.5 M parameters)": event_ms(eng.apply_gradients, 20),
     }
     n_par = eng.tables.numel() + eng.net.numel()
