@@ -350,6 +350,11 @@ struct BinItem {
 // contributions: the accumulate form), float atomics (the bin was cut into several items), plain STORE of the whole slice
 // (the overwrite form: d_table needs no zeroing and is not read back)
 constexpr unsigned kFlushRmw = 0, kFlushAtomic = 1, kFlushStore = 2;
+// items of the dense (coarse) levels: consecutive samples of a ray sit in the same cell, so a bin's records come in runs of equal
+// slots (16 at the coarsest level) -- read lane-adjacent, a wave's 64 adds pile up on a few LDS addresses (level 0 alone: 51 us of
+// the reduce launch's 70).  For these items every lane takes EIGHT CONSECUTIVE records, sums equal neighbours in registers
+// (integers: the same sums) and adds once per run; a run then meets at most three lanes of an instruction.
+constexpr unsigned kItemRuns = 1u << 16, kItemLiveMask = 0x3fffu;
 // one corner contribution, 8 bytes: bits [0,12) slot in the slice, [12,38) and [38,64) the two feature gradients as
 // 26-bit signed fixed point at the call's scale (fixed_shift: the largest |d_feat| of the call keeps 25 bits, i.e. a
 // resolution of 3e-8 of it -- finer than one fp32 ulp of that largest term; tinycudann accumulates these in fp16)
@@ -512,7 +517,7 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
         item.entry0 = entry0;
         item.begin = r0 + j * kChunk;
         item.end = r0 + min(c, (j + 1) * kChunk);
-        item.atomic = (it > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2);
+        item.atomic = (it > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) | (L.dense[plan.first + li] ? kItemRuns : 0u);
         items[i0 + j] = item;
       }
     }
@@ -648,6 +653,30 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
     __syncthreads();
     // kUnroll independent record loads in flight per lane: the loop is latency-bound otherwise (49 records per lane)
     constexpr int kUnroll = 8;
+    if (item.atomic & kItemRuns) {
+      for (unsigned r0 = item.begin + kUnroll * threadIdx.x; r0 < item.end; r0 += kUnroll * blockDim.x) {
+        BinRecord rec[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) rec[u] = records[r0 + u < item.end ? r0 + u : item.end - 1];
+        unsigned cur = record_slot(rec[0]);
+        long long s0 = record_g0(rec[0]), s1 = record_g1(rec[0]);
+#pragma unroll
+        for (int u = 1; u < kUnroll; ++u) {
+          if (r0 + u >= item.end) break;
+          const unsigned slot = record_slot(rec[u]);
+          if (slot != cur) {
+            if (s0 != 0) atomicAdd(&acc[2 * cur + 0], (unsigned long long)s0);
+            if (s1 != 0) atomicAdd(&acc[2 * cur + 1], (unsigned long long)s1);
+            cur = slot;
+            s0 = s1 = 0;
+          }
+          s0 += record_g0(rec[u]);
+          s1 += record_g1(rec[u]);
+        }
+        if (s0 != 0) atomicAdd(&acc[2 * cur + 0], (unsigned long long)s0);
+        if (s1 != 0) atomicAdd(&acc[2 * cur + 1], (unsigned long long)s1);
+      }
+    } else
     for (unsigned r0 = item.begin + threadIdx.x; r0 < item.end; r0 += kUnroll * blockDim.x) {
       BinRecord rec[kUnroll];
 #pragma unroll
@@ -665,7 +694,7 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
     }
     __syncthreads();
     float2* dst = reinterpret_cast<float2*>(d_table) + item.entry0;
-    const unsigned live = min(item.atomic >> 2, table_entries - item.entry0), mode = item.atomic & 3u;
+    const unsigned live = min((item.atomic >> 2) & kItemLiveMask, table_entries - item.entry0), mode = item.atomic & 3u;
     if (mode == kFlushStore) {
       for (unsigned i = threadIdx.x; i < live; i += blockDim.x)
         dst[i] = make_float2(__ll2float_rn((long long)acc[2 * i]) * inv_scale, __ll2float_rn((long long)acc[2 * i + 1]) * inv_scale);
