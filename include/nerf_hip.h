@@ -464,6 +464,10 @@ int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight
  * zeroes the scalar once per step and hands it to every group's nerf_adamw_clip_step */
 int nerf_tv_normsq_accum(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
                          float* normsq_dev, nerf_stream_t stream);
+/* the same pass over 1..4 equally long tables stored back to back (n elements in all; Part 4's three deformation grids in one
+ * launch): every table has its own total variation (tv_weight / (n / n_tables - 1) per neighbour pair, no pair across a seam) */
+int nerf_tv_normsq_accum_tables(const float* params, float* grads, int64_t n, int n_tables, float tv_weight, float grad_scale,
+                                float* normsq_dev, nerf_stream_t stream);
 int nerf_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                          int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                          const float* normsq_dev, float max_norm, float grad_scale, nerf_stream_t stream);

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "nerf_adam_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, c_ptr]),
     "nerf_tv_normsq": (i32, [c_ptr, c_ptr, i64, f32, f32, c_ptr, c_ptr]),
     "nerf_tv_normsq_accum": (i32, [c_ptr, c_ptr, i64, f32, f32, c_ptr, c_ptr]),
+    "nerf_tv_normsq_accum_tables": (i32, [c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, c_ptr]),
     "nerf_composite_mse_reg_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, f32, c_ptr, f32, i64, i32, c_ptr, c_ptr,
                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_p4_param_count": (i64, []),

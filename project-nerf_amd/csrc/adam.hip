@@ -103,7 +103,10 @@ __device__ __forceinline__ float tv_term(float prev, float cur, float next, bool
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 tv_normsq_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t n, float tv_scale, float grad_scale,
-                 float* __restrict__ normsq) {
+                 float* __restrict__ normsq, int64_t seg) {
+  // seg: the vector is up to four tables of seg elements back to back (Part 4's three deformation grids in one launch): the
+  // total variation does not couple the last element of a table with the first of the next
+  auto starts = [seg](int64_t e) { return e == 0 || e == seg || e == 2 * seg || e == 3 * seg; };
   // grad_scale (1/world after a summing all-reduce) applies to the DATA gradient only: the TV term is
   // a function of the replicated parameters and must not be divided by the world size
   const bool rewrite = tv_scale != 0.0f || grad_scale != 1.0f;
@@ -116,19 +119,22 @@ tv_normsq_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t n, 
     if (tv_scale != 0.0f) {
       const f4 pp = reinterpret_cast<const f4*>(p)[i];
       const int64_t e0 = 4 * i;
-      const float before = e0 > 0 ? p[e0 - 1] : 0.0f, after = e0 + 4 < n ? p[e0 + 4] : 0.0f;
-      gg[0] += tv_scale * tv_term(before, pp[0], pp[1], e0 > 0, true);
+      const bool has_prev = !starts(e0), has_next = e0 + 4 < n && !starts(e0 + 4);     // seg is a multiple of 4 on this path
+      const float before = has_prev ? p[e0 - 1] : 0.0f, after = has_next ? p[e0 + 4] : 0.0f;
+      gg[0] += tv_scale * tv_term(before, pp[0], pp[1], has_prev, true);
       gg[1] += tv_scale * tv_term(pp[0], pp[1], pp[2], true, true);
       gg[2] += tv_scale * tv_term(pp[1], pp[2], pp[3], true, true);
-      gg[3] += tv_scale * tv_term(pp[2], pp[3], after, true, e0 + 4 < n);
+      gg[3] += tv_scale * tv_term(pp[2], pp[3], after, true, has_next);
     }
     if (rewrite) reinterpret_cast<f4*>(g)[i] = gg;
     local += gg[0] * gg[0] + gg[1] * gg[1] + gg[2] * gg[2] + gg[3] * gg[3];
   }
   for (int64_t i = 4 * n4 + tid; i < n; i += stride) {
     float gi = g[i] * grad_scale;
-    if (tv_scale != 0.0f)
-      gi += tv_scale * tv_term(i > 0 ? p[i - 1] : 0.0f, p[i], i + 1 < n ? p[i + 1] : 0.0f, i > 0, i + 1 < n);
+    if (tv_scale != 0.0f) {
+      const bool has_prev = !starts(i), has_next = i + 1 < n && !starts(i + 1);
+      gi += tv_scale * tv_term(has_prev ? p[i - 1] : 0.0f, p[i], has_next ? p[i + 1] : 0.0f, has_prev, has_next);
+    }
     if (rewrite) g[i] = gi;
     local += gi * gi;
   }
@@ -161,7 +167,7 @@ __global__ void __launch_bounds__(256) f32_to_f16_kernel(const float* __restrict
 }  // namespace nerf
 
 static int tv_normsq_impl(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
-                          float* normsq_dev, bool zero_first, nerf_stream_t stream);
+                          float* normsq_dev, bool zero_first, nerf_stream_t stream, int n_tables = 1);
 
 extern "C" int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
                               float* normsq_dev, nerf_stream_t stream) {
@@ -173,22 +179,29 @@ extern "C" int nerf_tv_normsq_accum(const float* params, float* grads, int64_t n
   return tv_normsq_impl(params, grads, n, tv_weight, grad_scale, normsq_dev, false, stream);
 }
 
+extern "C" int nerf_tv_normsq_accum_tables(const float* params, float* grads, int64_t n, int n_tables, float tv_weight,
+                                           float grad_scale, float* normsq_dev, nerf_stream_t stream) {
+  return tv_normsq_impl(params, grads, n, tv_weight, grad_scale, normsq_dev, false, stream, n_tables);
+}
+
 static int tv_normsq_impl(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
-                          float* normsq_dev, bool zero_first, nerf_stream_t stream) {
-  NERF_REQUIRE(n >= 0 && normsq_dev, "nerf_tv_normsq: bad arguments");
+                          float* normsq_dev, bool zero_first, nerf_stream_t stream, int n_tables) {
+  NERF_REQUIRE(n >= 0 && normsq_dev && n_tables >= 1 && n_tables <= 4 && n % n_tables == 0, "nerf_tv_normsq: bad arguments");
+  const int64_t seg = n / n_tables;
+  NERF_REQUIRE(n_tables == 1 || seg % 4 == 0, "nerf_tv_normsq_accum_tables: %lld elements per table (a multiple of 4)", (long long)seg);
   if (zero_first && hipMemsetAsync(normsq_dev, 0, sizeof(float), nerf::as_stream(stream)) != hipSuccess)
     return nerf::fail(NERF_ELAUNCH, "nerf_tv_normsq: memset failed");
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads, "nerf_tv_normsq: NULL pointer");
-  const float tv_scale = n > 1 ? tv_weight / (float)(n - 1) : 0.0f;      // d/dp of mean|p[1:] - p[:-1]| * w
+  const float tv_scale = seg > 1 ? tv_weight / (float)(seg - 1) : 0.0f;      // d/dp of mean|p[1:] - p[:-1]| * w, per table
   int64_t blocks = (n / 4 + 255) / 256 + 1;
   if (blocks > 1024) blocks = 1024;      // measured: 512 +6 %, 256 +50 %, 2048 +15 % (one same-address atomic per workgroup against HBM streams in flight)
   if ((((uintptr_t)params | (uintptr_t)grads) & 15) == 0)
     hipLaunchKernelGGL(nerf::tv_normsq_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
-                       tv_scale, grad_scale, normsq_dev);
+                       tv_scale, grad_scale, normsq_dev, seg);
   else
     hipLaunchKernelGGL(nerf::tv_normsq_kernel<false>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
-                       tv_scale, grad_scale, normsq_dev);
+                       tv_scale, grad_scale, normsq_dev, seg);
   return nerf::check_launch("nerf_tv_normsq");
 }
 

@@ -423,10 +423,12 @@ class DualHashEngine:
         scale = 1.0 / self.world_size
         normsq = self._scalars[2:3]
         normsq.zero_()
-        for k in range(4):
-            tv = self.tv_canon if k == 3 else self.tv_disp
-            _lib.check(lib.nerf_tv_normsq_accum(P(self.table(k)), P(self.g_table(k)), self.table_sizes[k], tv, scale, P(normsq), st),
-                       "nerf_tv_normsq_accum")
+        # the three deformation grids (equal sizes, back to back in the flat buffer) in one launch, each with its own total variation
+        n_def = self.table_sizes[0]
+        _lib.check(lib.nerf_tv_normsq_accum_tables(P(self.table(0)), P(self.g_table(0)), 3 * n_def, 3, self.tv_disp, scale, P(normsq), st),
+                   "nerf_tv_normsq_accum_tables")
+        _lib.check(lib.nerf_tv_normsq_accum(P(self.table(3)), P(self.g_table(3)), self.table_sizes[3], self.tv_canon, scale, P(normsq), st),
+                   "nerf_tv_normsq_accum")
         _lib.check(lib.nerf_tv_normsq_accum(P(self.net), P(self.g_net), N_PARAMS, 0.0, scale, P(normsq), st), "nerf_tv_normsq_accum")
         lr_t, lr_n, lr_s = self.lr(2.0), self.lr(1.0), self.lr(5.0)      # the rates of THIS step: scheduler.step() follows optimizer.step()
         self.step_count += 1

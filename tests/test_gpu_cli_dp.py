@@ -95,7 +95,9 @@ def test_two_rank_cli_run_follows_the_single_rank_trajectory(mode, scene, tmp_pa
     # first eight steps are held tightly (measured: equal to 3e-5) and the rest of the run loosely.
     # Single steps of the late Part 4 run swing by 10-30 % between two launches of the SAME command (summation order is not
     # reproducible), so the late check is on the mean of the last quarter of the run, with a wide bound per step.
-    early = 4 if mode == "part4" else 1
+    # (three logged steps = six training steps: the first occupancy-grid update at step 8 turns a last-bit difference of the
+    # weights into a different set of active samples as soon as one voxel sits on the threshold)
+    early = 3 if mode == "part4" else 1
     for k, (a, b) in enumerate(zip(l1, l2)):
         bound = 2e-3 if k < early else (0.6 if mode == "part4" else 2e-2)
         assert abs(a - b) <= bound * max(a, 1e-3), (k, l1, l2)

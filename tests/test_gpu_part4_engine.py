@@ -312,3 +312,34 @@ def test_engine_trains_and_updates_its_grid(tmp_path):
     assert float(eng.net[30144]) != pytest.approx(0.1)          # displacement_scale moved (its own 5x group)
     img = eng.render_image(*ds.get_image_rays(0, "cuda")[:2], times[0], S)
     assert img.shape == (size, size, 3) and bool(torch.isfinite(img).all())
+
+
+@pytest.mark.gpu
+def test_tv_normsq_over_tables_equals_one_call_per_table():
+    """nerf_tv_normsq_accum_tables: three equally long tables back to back in one launch = three launches -- every table has its
+    own total variation (no neighbour pair across a seam) and the squared norm accumulates over all of them."""
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import _lib
+    lib = _lib.load()
+    P = lambda t: t.data_ptr()
+    gen = torch.Generator().manual_seed(5)
+    n_tab, seg = 3, 4 * 1237
+    p = torch.randn(n_tab * seg, generator=gen).cuda()
+    g0 = torch.randn(n_tab * seg, generator=gen).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    one, many = g0.clone(), g0.clone()
+    nsq_one, nsq_many = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    _lib.check(lib.nerf_tv_normsq_accum_tables(P(p), P(one), n_tab * seg, n_tab, 0.37, 0.5, P(nsq_one), st), "tables")
+    for k in range(n_tab):
+        _lib.check(lib.nerf_tv_normsq_accum(P(p[k * seg:]), P(many[k * seg:]), seg, 0.37, 0.5, P(nsq_many), st), "single")
+    assert torch.equal(one, many)
+    assert abs(float(nsq_one) - float(nsq_many)) <= 1e-5 * float(nsq_many)
+    # and against the definition: d/dp of 0.37 * mean |p[1:] - p[:-1]| per table, on the halved data gradient
+    ref = []
+    for k in range(n_tab):
+        q = p[k * seg:(k + 1) * seg].detach().clone().requires_grad_(True)
+        (0.37 * (q[1:] - q[:-1]).abs().mean()).backward()
+        ref.append(0.5 * g0[k * seg:(k + 1) * seg] + q.grad)
+    assert float((one - torch.cat(ref)).abs().max()) <= 1e-6
+    with pytest.raises(_lib.NerfHipError):
+        _lib.check(lib.nerf_tv_normsq_accum_tables(P(p), P(one), n_tab * seg, 5, 0.37, 0.5, P(nsq_one), st), "five tables")
