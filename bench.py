@@ -330,7 +330,7 @@ def bench_part4(args, device, steps=200):
                                          "p4::deform_bwd_kernel": 1, "mlp_wgrad_small_kernel<true>": 2})},
         "tv_clip_adamw": {"kernel": "tv_normsq_kernel<true> x5 + adamw_clip_kernel<true> x3", "work_per_launch": n_par * 42,
                           "ms": k["tv + clip + adamw (28.5 M parameters)"],
-                          "traffic": traffic({"tv_normsq_kernel<true>": 5, "adamw_clip_kernel<true>": 3})},
+                          "traffic": traffic({"tv_normsq_kernel<true>": 3, "adamw_clip_kernel<true>": 3})},
     }
     for v in roof.values():
         v.update({"bound": "hbm", "achieved": v["work_per_launch"] / v["ms"] * 1e-6, "peak": HBM_PEAK_GBS, "unit": "GB/s"})
