@@ -295,8 +295,9 @@ def bench_part4(args, device, steps=200):
     g_tabs = [eng.g_table(i) for i in range(4)]
     Ld, Lc = eng.levels_d.n_levels, eng.levels_c.n_levels
     k = {
-        "hash_fwd (3 deformation grids + canonical)": event_ms(lambda: [ops.hash_encode_fwd_nat(pts, tabs[i], eng.levels_d if i < 3 else eng.levels_c, eng.bound,
-                                                                                                ws.nat(i), fp16=True) for i in range(4)], 20),
+        "hash_fwd (3 deformation grids + canonical)": event_ms(lambda: (
+            ops.hash_encode_fwd_nat_tables(pts, tabs[:3], eng.levels_d, eng.bound, [ws.nat(i) for i in range(3)], fp16=True),      # as the step calls it
+            ops.hash_encode_fwd_nat(pts, tabs[3], eng.levels_c, eng.bound, ws.nat(3), fp16=True)), 20),
         "hash_fwd + fused chains fwd": event_ms(fwd, 20),
         "chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters": event_ms(
             lambda: p4.backward_chain(eng.packed, eng.net, eng.table(3, half=True), eng.levels_d, eng.levels_c, eng.bound, pts, xc, ws, rgb, sigma,
@@ -322,7 +323,7 @@ def bench_part4(args, device, steps=200):
     scatter = n * (3 * Ld + Lc) * 8 * 16 + n * Lc * 8 * 8
     roof = {
         "hash_fwd": {"kernel": "hash_fwd_kernel<fp16 table> x4", "work_per_launch": gather + n * (12 + 4 * 64),
-                     "ms": k["hash_fwd (3 deformation grids + canonical)"], "traffic": traffic({"hash_fwd_kernel<fp16 table>": 4})},
+                     "ms": k["hash_fwd (3 deformation grids + canonical)"], "traffic": traffic({"hash_fwd_kernel<fp16 table>": 2})},      # the three deformation grids in one launch + the canonical grid
         "backward": {"kernel": "p4 chains bwd + mlp_wgrad_small_kernel<true> x2 + hash_bwd_input_kernel + hash_bin_* x4", "work_per_launch": scatter,
                      "ms": k["chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters"],
                      "traffic": traffic({"hash_bin_count_pm_kernel": 4, "hash_bin_plan_kernel": 4, "hash_bin_scatter_kernel<true>": 4,

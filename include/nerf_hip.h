@@ -312,6 +312,12 @@ int nerf_hash_encode_fwd_nat(const float* pts, int64_t n, const float* table_f32
                              const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                              const unsigned* offset_host, const unsigned* dense_host, float bound,
                              void* out_nat, int nat_dtype, nerf_stream_t stream);
+/* n_tables grids of ONE level structure evaluated at the same points in one launch (Part 4's three deformation grids):
+ * table g starts table_stride entries (of two fp16) after table g - 1, its operand image out_stride_bytes after the previous one */
+int nerf_hash_encode_fwd_nat_tables(const float* pts, int64_t n, const void* tables_f16, int n_tables, int64_t table_stride,
+                                    int n_levels, const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                    const unsigned* offset_host, const unsigned* dense_host, float bound, void* out_nat,
+                                    int64_t out_stride_bytes, int nat_dtype, nerf_stream_t stream);
 int nerf_f32_to_f16(const float* src, void* dst_f16, int64_t n, nerf_stream_t stream);
 int nerf_hash_encode_bwd(const float* pts, int64_t n, int n_levels, const float* scale_host,
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "nerf_hash_encode_fwd": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_fwd_f16": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_fwd_nat": (i32, [c_ptr, i64, c_ptr, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, i32, c_ptr]),
+    "nerf_hash_encode_fwd_nat_tables": (i32, [c_ptr, i64, c_ptr, i32, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, i64, i32, c_ptr]),
     "nerf_f32_to_f16": (i32, [c_ptr, c_ptr, i64, c_ptr]),
     "nerf_hash_encode_bwd": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_levels": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, i32, i32, c_ptr]),

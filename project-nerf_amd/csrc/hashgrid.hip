@@ -133,11 +133,13 @@ __device__ __forceinline__ void gather_cell(const TableT* __restrict__ table, co
   }
 }
 
+struct TableSet { int n; long long table_stride, out_stride; };     // n tables, entries between them, operand-image elements between their outputs
+
 template <class TableT>
 __global__ void __launch_bounds__(256)
 hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const TableT* __restrict__ table, HashLevels L,
                 float* __restrict__ out_f32, __bf16* __restrict__ out_nat, unsigned* __restrict__ idx_out, int nat_f16,
-                unsigned* __restrict__ hist_count, LevelBins lb, int n_chunks) {
+                unsigned* __restrict__ hist_count, LevelBins lb, int n_chunks, TableSet ts) {
   // hist_count (training, optional): corners per (level, slice) of the points p < n -- the first pass of the binned
   // backward (hash_bin_count_*), done here where the corner indices already exist; LDS histogram per workgroup (the dynamic
   // LDS allocation, >= 4 bytes per slice of the level), one global add per non-empty bin and workgroup
@@ -148,9 +150,13 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const T
   // ray, so a wave's gathers at the coarse and middle levels fall into few cache lines (point-major,
   // 16 lanes of a wave hit 16 different level tables)
   const int64_t rows = out_nat != nullptr ? n_pad : n;
-  const LevelChunk lc = level_chunk(L.n_levels, n_chunks);
-  if (lc.lvl >= L.n_levels) return;
-  const int lvl = lc.lvl;
+  // ts.n tables of the same level structure evaluated at the same points in one launch (Part 4's three deformation grids):
+  // virtual level v = table * n_levels + level; table g reads ts.table_stride entries further and writes its own operand image
+  const LevelChunk lc = level_chunk(L.n_levels * ts.n, n_chunks);
+  if (lc.lvl >= L.n_levels * ts.n) return;
+  const int lvl = lc.lvl % L.n_levels;
+  table += (int64_t)(lc.lvl / L.n_levels) * ts.table_stride;
+  if (out_nat != nullptr) out_nat += (int64_t)(lc.lvl / L.n_levels) * ts.out_stride;
   const unsigned hist_bins = hist_count != nullptr ? lb.bin0[lvl + 1] - lb.bin0[lvl] : 0u, lvl_offset = L.offset[lvl];
   if (hist_count != nullptr) {
     for (unsigned i = threadIdx.x; i < hist_bins; i += blockDim.x) hist_lds[i] = 0;
@@ -746,7 +752,7 @@ static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const 
                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                          const unsigned* offset_host, const unsigned* dense_host, float bound,
                          float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream, int nat_f16 = 0,
-                         void* bwd_workspace = nullptr, size_t bwd_workspace_bytes = 0);
+                         void* bwd_workspace = nullptr, size_t bwd_workspace_bytes = 0, TableSet ts = TableSet{1, 0, 0});
 
 extern "C" int nerf_hash_encode_fwd(const float* pts, int64_t n, const float* table, int n_levels,
                                     const float* scale_host, const unsigned* res_host, const unsigned* size_host,
@@ -776,6 +782,18 @@ extern "C" int nerf_hash_encode_fwd_nat(const float* pts, int64_t n, const float
                        nullptr, out_nat, nullptr, stream, nat_dtype);
 }
 
+extern "C" int nerf_hash_encode_fwd_nat_tables(const float* pts, int64_t n, const void* tables_f16, int n_tables, int64_t table_stride,
+                                               int n_levels, const float* scale_host, const unsigned* res_host,
+                                               const unsigned* size_host, const unsigned* offset_host, const unsigned* dense_host,
+                                               float bound, void* out_nat, int64_t out_stride_bytes, int nat_dtype, nerf_stream_t stream) {
+  NERF_REQUIRE(n_tables >= 1 && n_tables <= 8 && table_stride >= 0 && out_stride_bytes >= 0 && out_stride_bytes % 2 == 0,
+               "nerf_hash_encode_fwd_nat_tables: n_tables=%d", n_tables);
+  NERF_REQUIRE(nat_dtype == 0 || nat_dtype == 1, "nerf_hash_encode_fwd_nat_tables: nat_dtype=%d (0 bf16, 1 fp16)", nat_dtype);
+  NERF_REQUIRE(n == 0 || (tables_f16 != nullptr && out_nat != nullptr), "nerf_hash_encode_fwd_nat_tables: NULL pointer");
+  return hash_fwd_impl(pts, n, nullptr, tables_f16, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound,
+                       nullptr, out_nat, nullptr, stream, nat_dtype, nullptr, 0, TableSet{n_tables, table_stride, out_stride_bytes / 2});
+}
+
 extern "C" int nerf_hash_encode_fwd_f16_hist(const float* pts, int64_t n, const void* table_f16, int n_levels,
                                              const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                                              const unsigned* offset_host, const unsigned* dense_host, float bound,
@@ -797,7 +815,7 @@ static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const 
                          const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                          const unsigned* offset_host, const unsigned* dense_host, float bound,
                          float* out_f32, void* out_nat_bf16, unsigned* idx_out, nerf_stream_t stream, int nat_f16,
-                         void* bwd_workspace, size_t bwd_workspace_bytes) {
+                         void* bwd_workspace, size_t bwd_workspace_bytes, TableSet ts) {
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_fwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(pts && (table || table_f16) && scale_host && res_host && size_host && offset_host && dense_host,
@@ -836,16 +854,18 @@ static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const 
     if (lds < (int)(max_slices * sizeof(unsigned))) lds = (int)(max_slices * sizeof(unsigned));
   }
   const bool xcd = options().hash_xcd != 0;
-  const dim3 grid = level_chunk_grid(n_levels, blocks, xcd);
+  NERF_REQUIRE(ts.n >= 1 && (ts.n == 1 || (out_f32 == nullptr && idx_out == nullptr && bwd_workspace == nullptr && out_nat_bf16 != nullptr)),
+               "nerf_hash_encode_fwd_nat_tables: several tables write operand images only");
+  const dim3 grid = level_chunk_grid(n_levels * ts.n, blocks, xcd);
   const int n_chunks = xcd ? (int)blocks : 0;
   if (table_f16 != nullptr)
     hipLaunchKernelGGL(hash_fwd_kernel<half2_t>, grid, dim3(256), lds, as_stream(stream), pts, n, n_pad,
                        static_cast<const half2_t*>(table_f16), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out, nat_f16,
-                       hist_count, lb, n_chunks);
+                       hist_count, lb, n_chunks, ts);
   else
     hipLaunchKernelGGL(hash_fwd_kernel<float2>, grid, dim3(256), lds, as_stream(stream), pts, n, n_pad,
                        reinterpret_cast<const float2*>(table), L, out_f32, static_cast<__bf16*>(out_nat_bf16), idx_out, nat_f16,
-                       hist_count, lb, n_chunks);
+                       hist_count, lb, n_chunks, ts);
   return check_launch("nerf_hash_encode_fwd");
 }
 

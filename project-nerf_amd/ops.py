@@ -625,6 +625,25 @@ def hash_encode_fwd_nat(pts: Tensor, table: Tensor, levels: HashLevelTable, boun
                "nerf_hash_encode_fwd_nat")
 
 
+def hash_encode_fwd_nat_tables(pts: Tensor, tables, levels: HashLevelTable, bound: float, outs, fp16: bool) -> bool:
+    """The operand images of several fp16 tables of ONE level structure at the same points in one launch, when the tables
+    and the images are equally spaced in memory (views of one flat buffer); False: not the case, nothing was launched."""
+    if len(tables) < 2 or any(t.dtype != torch.float16 or not t.is_contiguous() for t in tables):
+        return False
+    t_step = tables[1].data_ptr() - tables[0].data_ptr()
+    o_step = outs[1].data_ptr() - outs[0].data_ptr()
+    if t_step <= 0 or o_step <= 0 or t_step % 4 or o_step % 2:
+        return False
+    for k in range(1, len(tables)):
+        if tables[k].data_ptr() - tables[0].data_ptr() != k * t_step or outs[k].data_ptr() - outs[0].data_ptr() != k * o_step:
+            return False
+    pts = _dev(pts, "pts")
+    _lib.check(_lib.load().nerf_hash_encode_fwd_nat_tables(_p(pts), pts.shape[0], _p(tables[0]), len(tables), t_step // 4, levels.n_levels,
+                                                           *levels.host_args(), float(bound), _p(outs[0]), o_step, 1 if fp16 else 0,
+                                                           _stream()), "nerf_hash_encode_fwd_nat_tables")
+    return True
+
+
 def f32_to_f16(src: Tensor, dst: Optional[Tensor] = None) -> Tensor:
     """fp16 copy of a flat fp32 parameter vector (the shadow table of the hash forward)"""
     src = _dev(src, "src")

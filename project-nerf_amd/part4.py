@@ -104,8 +104,10 @@ def forward_chain(packed, params, tables, levels_d, levels_c, bound, pts, x_def,
     n = pts.shape[0]
     dev = pts.device
     x_in = pts if x_def is None else x_def
-    for k in range(3):
-        ops.hash_encode_fwd_nat(x_in, tables[k], levels_d, bound, ws.nat(k), fp16=True)
+    # the engine's three deformation tables are views of one flat fp16 buffer: one launch; separate tensors: one launch each
+    if not ops.hash_encode_fwd_nat_tables(x_in, tables[:3], levels_d, bound, [ws.nat(k) for k in range(3)], fp16=True):
+        for k in range(3):
+            ops.hash_encode_fwd_nat(x_in, tables[k], levels_d, bound, ws.nat(k), fp16=True)
     dx, xc = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
     _lib.check(lib.nerf_p4_deform_fwd(P(packed), P(params), P(ws.buf), P(pts), P(t_def), P(blend), n, P(dx), P(xc), 1 if train else 0,
                                       ops._stream()), "nerf_p4_deform_fwd")
