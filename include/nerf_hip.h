@@ -349,6 +349,16 @@ int nerf_hash_encode_bwd_ws_store(const float* pts, int64_t n, int n_levels, con
                                   const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
                                   int first_level, int end_level, void* workspace, size_t workspace_bytes,
                                   nerf_stream_t stream);
+/* The overwrite form for n_tables tables of ONE level structure, scattered to from the same points, in one pass of launches
+ * (Part 4's three deformation grids): table t starts table_stride ENTRIES after table t - 1 in d_table, its feature gradients
+ * [n, 2 n_levels] dfeat_stride FLOATS after the previous table's in d_feat; n_levels * n_tables <= 48;
+ * workspace >= nerf_hash_encode_bwd_tables_workspace_bytes(n, n_levels, n_tables). */
+size_t nerf_hash_encode_bwd_tables_workspace_bytes(int64_t n, int n_levels, int n_tables);
+int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n, int n_tables, int64_t table_stride, int n_levels,
+                                         const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                         const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                         const float* d_feat, int64_t dfeat_stride, float* d_table, void* workspace,
+                                         size_t workspace_bytes, nerf_stream_t stream);
 /* The count pass of the binned backward done where the information already exists (Instant-NGP step, all levels):
  *   nerf_hash_encode_fwd_f16_hist  the forward also counts the corners per (level, table slice) into `bwd_workspace`
  *                                  (>= nerf_hash_encode_bwd_workspace_bytes(n, L); its header and counts are zeroed here);

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "nerf_hash_encode_bwd_workspace_bytes": (size_t, [i64, i32]),
     "nerf_hash_encode_bwd_ws": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, i32, i32, c_ptr, size_t, c_ptr]),
     "nerf_hash_encode_bwd_ws_store": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, i32, i32, c_ptr, size_t, c_ptr]),
+    "nerf_hash_encode_bwd_tables_workspace_bytes": (size_t, [i64, i32, i32]),
+    "nerf_hash_encode_bwd_ws_store_tables": (i32, [c_ptr, i64, i32, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, i64, c_ptr, c_ptr, size_t, c_ptr]),
     "nerf_hash_encode_fwd_f16_hist": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),
     "nerf_hash_encode_bwd_ws_slots": (i32, [c_ptr, i64, i32, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr)]),
     "nerf_hash_encode_bwd_ws_store_precounted": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),

@@ -341,9 +341,16 @@ constexpr unsigned kMaxSlices = 4096;          // per level (LDS histogram); lar
 constexpr int kMaxBins = 65536;
 constexpr int kFixedBits = 25;                 // magnitude bits of a term (26-bit signed field of the packed record)
 
+// Several tables of one level structure, scattered to from the same points, share one pass (Part 4's three deformation grids):
+// VIRTUAL level v = table * n_levels + level; table t's entries start t * table_stride entries further in d_table, its feature
+// gradients t * dfeat_stride floats further in d_feat.  One table: n_tables = 1, v = level.
+constexpr int kMaxPlanLevels = 48;
 struct BinPlan {
-  int first, count;                            // levels [first, first + count)
-  unsigned bin0[kMaxLevels + 1];               // first bin of level first + i; bin0[count] = number of bins
+  int first, count;                            // virtual levels [first, first + count)
+  int n_tables;
+  unsigned table_stride;
+  long long dfeat_stride;
+  unsigned bin0[kMaxPlanLevels + 1];           // first bin of virtual level first + i; bin0[count] = number of bins
 };
 
 struct BinHeader {                             // start of the workspace
@@ -457,13 +464,13 @@ hash_bin_count_pm_kernel(const float* __restrict__ pts, int64_t n, HashLevels L,
   float amax = 0.0f;
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
     const float px = pts[p * 3 + 0], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
-    const float2* row = reinterpret_cast<const float2*>(d_feat + p * (2 * L.n_levels)) + plan.first;
     for (int li = 0; li < plan.count; ++li) {
-      const float2 g = row[li];
+      const int vl = plan.first + li, tbl = vl / L.n_levels;
+      const float2 g = *reinterpret_cast<const float2*>(d_feat + tbl * plan.dfeat_stride + p * (2 * L.n_levels) + 2 * (vl - tbl * L.n_levels));
       grad_lm[(int64_t)li * n + p] = g;
       if (g.x == 0.0f && g.y == 0.0f) continue;
       amax = fmaxf(amax, fmaxf(fabsf(g.x), fabsf(g.y)));
-      const int lvl = plan.first + li;
+      const int lvl = vl - tbl * L.n_levels;
       const Corner c = corners_of(L, lvl, px, py, pz);
       const unsigned offset = L.offset[lvl], b0 = plan.bin0[li];
 #pragma unroll
@@ -516,14 +523,15 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
       int li = 0;
       while (li + 1 < plan.count && plan.bin0[li + 1] <= b) ++li;
       const unsigned first = (b - plan.bin0[li]) << kSliceLog2;
-      const unsigned entry0 = L.offset[plan.first + li] + first;
-      const unsigned live = min(kSlice, L.size[plan.first + li] - first);      // the level's last slice may be partial
+      const int tbl = (plan.first + li) / L.n_levels, lvl = plan.first + li - tbl * L.n_levels;
+      const unsigned entry0 = tbl * plan.table_stride + L.offset[lvl] + first;
+      const unsigned live = min(kSlice, L.size[lvl] - first);      // the level's last slice may be partial
       for (unsigned j = 0; j < it; ++j) {
         BinItem item;
         item.entry0 = entry0;
         item.begin = r0 + j * kChunk;
         item.end = r0 + min(c, (j + 1) * kChunk);
-        item.atomic = (it > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) | (L.dense[plan.first + li] ? kItemRuns : 0u);
+        item.atomic = (it > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) | (L.dense[lvl] ? kItemRuns : 0u);
         items[i0 + j] = item;
       }
     }
@@ -555,16 +563,17 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
   __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
   __shared__ BinRecord stage[STAGED ? 4096 : 1];
   __shared__ unsigned dest[STAGED ? 4096 : 1];
-  const int lvl = plan.first + blockIdx.y;
+  const int tbl = (plan.first + (int)blockIdx.y) / L.n_levels, lvl = plan.first + (int)blockIdx.y - tbl * L.n_levels;
   const unsigned bins = plan.bin0[blockIdx.y + 1] - plan.bin0[blockIdx.y], offset = L.offset[lvl];
   if (STAGED != (bins <= kStagedBins)) return;                 // the other instantiation owns this level
+  d_feat += tbl * plan.dfeat_stride;
   if (zero_table != nullptr) {
     // overwrite form: a bin that was cut into several items is flushed with atomics by the reduce pass (a later launch),
     // so its slice is zeroed here -- the coarse dense levels in steady state, 1.8 MB of a 52 MB table
     for (unsigned b = blockIdx.x; b < bins; b += gridDim.x) {
       if (count[plan.bin0[blockIdx.y] + b] <= kChunk) continue;
       const unsigned first = b << kSliceLog2, live = min(kSlice, L.size[lvl] - first);
-      float2* dst = reinterpret_cast<float2*>(zero_table) + offset + first;
+      float2* dst = reinterpret_cast<float2*>(zero_table) + (size_t)tbl * plan.table_stride + offset + first;
       for (unsigned i = threadIdx.x; i < live; i += blockDim.x) dst[i] = make_float2(0.0f, 0.0f);
     }
   }
@@ -893,6 +902,9 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
   if (binned) {
     plan.first = first_big;
     plan.count = level1 - first_big;
+    plan.n_tables = 1;
+    plan.table_stride = 0;
+    plan.dfeat_stride = 0;
     plan.bin0[0] = 0;
     unsigned table_entries = 0;
     for (int i = 0; i < n_levels; ++i) table_entries = offset_host[i] + size_host[i] > table_entries ? offset_host[i] + size_host[i] : table_entries;
@@ -1018,6 +1030,79 @@ extern "C" int nerf_hash_encode_bwd_ws_store(const float* pts, int64_t n, int n_
   }
   return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table,
                        first_level, end_level, stream, workspace, workspace_bytes, true);
+}
+
+extern "C" size_t nerf_hash_encode_bwd_tables_workspace_bytes(int64_t n, int n_levels, int n_tables) {
+  if (n <= 0 || n_levels < 1 || n_levels > kMaxLevels || n_tables < 1 || n_levels * n_tables > kMaxPlanLevels) return 0;
+  return bin_workspace_bytes(n, n_levels * n_tables);
+}
+
+// The overwrite-form scatter for n_tables tables of ONE level structure from the same points in one pass of count / plan /
+// scatter / reduce launches (Part 4's three deformation grids: three passes of four small launches otherwise).
+extern "C" int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n, int n_tables, int64_t table_stride, int n_levels,
+                                                    const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                                    const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                                    const float* d_feat, int64_t dfeat_stride, float* d_table, void* workspace,
+                                                    size_t workspace_bytes, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && n_tables >= 1 && n_levels >= 1 && n_levels * n_tables <= kMaxPlanLevels && table_stride >= 0 && dfeat_stride >= 0,
+               "nerf_hash_encode_bwd_ws_store_tables: n=%lld, %d tables of %d levels (at most %d virtual levels)", (long long)n, n_tables,
+               n_levels, kMaxPlanLevels);
+  NERF_REQUIRE(d_table && size_host && offset_host, "nerf_hash_encode_bwd_ws_store_tables: NULL pointer");
+  unsigned entries = 0;
+  for (int i = 0; i < n_levels; ++i) entries = offset_host[i] + size_host[i] > entries ? offset_host[i] + size_host[i] : entries;
+  NERF_REQUIRE(n_tables == 1 || (uint64_t)table_stride >= entries, "nerf_hash_encode_bwd_ws_store_tables: table_stride %lld < %u entries",
+               (long long)table_stride, entries);
+  NERF_REQUIRE(((uint64_t)(n_tables - 1) * (uint64_t)table_stride + entries) < 0xffffffffull, "nerf_hash_encode_bwd_ws_store_tables: tables too large");
+  if (n == 0) {                                      // nothing to scatter: every table is still OVERWRITTEN (with zeros)
+    for (int t = 0; t < n_tables; ++t)
+      if (hipMemsetAsync(d_table + 2 * (size_t)t * table_stride, 0, sizeof(float) * 2 * entries, as_stream(stream)) != hipSuccess)
+        return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws_store_tables: memset failed");
+    return NERF_OK;
+  }
+  NERF_REQUIRE(pts && d_feat && workspace && scale_host && res_host && dense_host, "nerf_hash_encode_bwd_ws_store_tables: NULL pointer");
+  HashLevels L;
+  if (int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound); rc != NERF_OK) return rc;
+  BinPlan plan;
+  plan.first = 0;
+  plan.count = n_levels * n_tables;
+  plan.n_tables = n_tables;
+  plan.table_stride = (unsigned)table_stride;
+  plan.dfeat_stride = dfeat_stride;
+  plan.bin0[0] = 0;
+  bool any_staged = false, any_direct = false;
+  for (int v = 0; v < plan.count; ++v) {
+    const unsigned slices = (size_host[v % n_levels] + kSlice - 1) / kSlice;
+    NERF_REQUIRE(slices <= kMaxSlices, "nerf_hash_encode_bwd_ws_store_tables: level %d has %u slices (max %u)", v % n_levels, slices, kMaxSlices);
+    plan.bin0[v + 1] = plan.bin0[v] + slices;
+    (slices <= kStagedBins ? any_staged : any_direct) = true;
+  }
+  const unsigned n_bins = plan.bin0[plan.count];
+  NERF_REQUIRE(n_bins <= kPmBins, "nerf_hash_encode_bwd_ws_store_tables: %u bins (this form holds all histograms in LDS: max %u)", n_bins, kPmBins);
+  NERF_REQUIRE(workspace_bytes >= bin_workspace_bytes(n, plan.count), "nerf_hash_encode_bwd_ws_store_tables: workspace of %zu bytes, need %zu",
+               workspace_bytes, bin_workspace_bytes(n, plan.count));
+  NERF_REQUIRE((size_t)n * 8 * (size_t)plan.count < 0xffffffffull, "nerf_hash_encode_bwd_ws_store_tables: n=%lld too large for 32-bit record offsets",
+               (long long)n);
+  const BinWorkspace w = carve(workspace, n, plan.count);
+  if (hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * n_bins, as_stream(stream)) != hipSuccess)
+    return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws_store_tables: memset failed");
+  int64_t bpm = (n + 255) / 256;
+  if (bpm > 1024) bpm = 1024;
+  hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm), dim3(256), 0, as_stream(stream), pts, n, L, plan, d_feat, w.count, w.header,
+                     w.grad_lm);
+  hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header, 1);
+  int64_t bx = (n + 511) / 512;
+  const int64_t bx_scatter = bx > 128 ? 128 : bx;
+  if (any_staged)
+    hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
+                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0);
+  if (any_direct)
+    hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
+                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0);
+  size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records, d_table,
+                     (unsigned)((uint64_t)(n_tables - 1) * (uint64_t)table_stride + entries));
+  return check_launch("nerf_hash_encode_bwd_ws_store_tables");
 }
 
 extern "C" int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_t n, int n_levels, const float* scale_host,

@@ -687,6 +687,32 @@ def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: T
                    "nerf_hash_encode_bwd_ws")
 
 
+def hash_encode_bwd_tables(pts: Tensor, levels: HashLevelTable, bound: float, d_feats, d_tables, workspace_of) -> bool:
+    """The overwrite-form scatter of several tables of ONE level structure from the same points in one pass of launches, when
+    the tables' gradients and their feature gradients are equally spaced in memory (views of flat buffers).  ``workspace_of(n,
+    n_levels, n_tables)`` returns the uint8 workspace.  False: not the case, nothing was launched."""
+    k = len(d_tables)
+    if k < 2 or any(t.dtype != torch.float32 or not t.is_contiguous() for t in list(d_tables) + list(d_feats)):
+        return False
+    t_step = d_tables[1].data_ptr() - d_tables[0].data_ptr()
+    f_step = d_feats[1].data_ptr() - d_feats[0].data_ptr()
+    if t_step <= 0 or f_step <= 0 or t_step % 8 or f_step % 4 or t_step // 8 < levels.entries:
+        return False
+    for i in range(1, k):
+        if d_tables[i].data_ptr() - d_tables[0].data_ptr() != i * t_step or d_feats[i].data_ptr() - d_feats[0].data_ptr() != i * f_step:
+            return False
+    lib = _lib.load()
+    if k * levels.n_levels > 48:
+        return False
+    pts = _dev(pts, "pts")
+    n = pts.shape[0]
+    ws = workspace_of(n, levels.n_levels, k)
+    _lib.check(lib.nerf_hash_encode_bwd_ws_store_tables(_p(pts), n, k, t_step // 8, levels.n_levels, *levels.host_args(), float(bound),
+                                                        _p(d_feats[0]), f_step // 4, _p(d_tables[0]), _p(ws), ws.numel(), _stream()),
+               "nerf_hash_encode_bwd_ws_store_tables")
+    return True
+
+
 IMLP_PARAM_COUNT = 11264
 IMLP_SIGMA_PARAMS = 3072
 

@@ -121,9 +121,10 @@ def forward_chain(packed, params, tables, levels_d, levels_c, bound, pts, x_def,
 
 
 def backward_chain(packed, params, table_c, levels_d, levels_c, bound, x_in, xc, ws: Workspace, rgb, sigma, d_rgb, d_sigma,
-                   d_dx_extra, g_net, g_tables, hash_ws=None, after_canonical=None, after_grid=None, overwrite=False):
+                   d_dx_extra, g_net, g_tables, hash_ws=None, after_canonical=None, after_grid=None, overwrite=False, tables_ws=None):
     """Adds the gradients of one batch into ``g_net`` [30145] and ``g_tables`` (4 tensors [E*2]); ``overwrite`` (needs
-    ``hash_ws``): the table gradients are STORED instead (no zeroing by the caller, no read-back -- the engine's data batch).  ``d_dx_extra`` [n,3] or
+    ``hash_ws``): the table gradients are STORED instead (no zeroing by the caller, no read-back -- the engine's data batch);
+    ``tables_ws(n, n_levels, n_tables)``: workspace for scattering to the three deformation grids in one pass.  ``d_dx_extra`` [n,3] or
     None: gradient reaching delta_x directly (displacement regulariser, a caller's loss on delta_x); rgb None: the
     deformation chain alone (regulariser probes).  ``after_*`` callbacks: data-parallel hooks (ranges that are final)."""
     lib = _lib.load()
@@ -142,6 +143,13 @@ def backward_chain(packed, params, table_c, levels_d, levels_c, bound, x_in, xc,
     _lib.check(lib.nerf_p4_deform_bwd(P(packed), P(params), P(ws.buf), P(d_dx.contiguous()), n, P(g_net), ops._stream()), "nerf_p4_deform_bwd")
     if after_canonical is not None:
         after_canonical()
+    # the engine's overwrite form: the three deformation grids (views of one flat gradient buffer) in one pass of launches
+    if overwrite and tables_ws is not None and ops.hash_encode_bwd_tables(x_in, levels_d, bound, [ws.d_feat(k) for k in range(3)], g_tables[:3],
+                                                                          tables_ws):
+        if after_grid is not None:
+            for k in range(3):
+                after_grid(k)
+        return
     for k in range(3):
         ops.hash_encode_bwd(x_in, levels_d, bound, ws.d_feat(k), g_tables[k], workspace=hash_ws(n, levels_d.n_levels) if hash_ws else None,
                             overwrite=overwrite)
@@ -256,6 +264,7 @@ class DualHashEngine:
         self._scalars = torch.zeros(4, device=self.device)          # loss, regulariser, squared gradient norm, spare
         self._ws: Dict[int, Workspace] = {}
         self._hash_ws = None
+        self._hash_ws_tables = None
         self._counter = 0
         self.repack()
 
@@ -303,6 +312,13 @@ class DualHashEngine:
         ws.n = n
         return ws
 
+    def _hash_scratch_tables(self, n: int, n_levels: int, n_tables: int) -> Tensor:
+        need = _lib.load().nerf_hash_encode_bwd_tables_workspace_bytes(n, n_levels, n_tables)
+        if self._hash_ws_tables is None or self._hash_ws_tables.numel() < need:
+            self._hash_ws_tables = None
+            self._hash_ws_tables = torch.empty(int(need * 1.25), dtype=torch.uint8, device=self.device)
+        return self._hash_ws_tables
+
     def _hash_scratch(self, n: int, n_levels: int) -> Tensor:
         need = ops.hash_encode_bwd_workspace_bytes(n, n_levels)
         if self._hash_ws is None or self._hash_ws.numel() < need:
@@ -349,7 +365,7 @@ class DualHashEngine:
                                                       P(d_rgb), P(d_sigma), P(d_extra), ops._stream()), "nerf_composite_mse_reg_bwd")
             g_tabs = [self.g_table(k) for k in range(4)]
             backward_chain(self.packed, self.net, self.table(3, half=True), self.levels_d, self.levels_c, self.bound, pts if x_def is None else x_def,
-                           xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch, overwrite=True,
+                           xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch, overwrite=True, tables_ws=self._hash_scratch_tables,
                            after_grid=(lambda k: reduce(g_tabs[k])) if (sync_grads_async is not None and probes is None) else None)
         if probes is not None:
             self._probe_regularisers(probes)

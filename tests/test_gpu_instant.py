@@ -641,3 +641,43 @@ def test_instant_engine_precounted_backward_equals_separate_count_pass():
     assert float((n1 - n0).abs().max()) <= 1e-5 * float(n0.abs().max())          # float atomics of the tiny wgrad
     # zero-gradient points take part in the precounted form (they own eight all-zero records): the sums are the same
     assert float((t1 - t0).abs().max()) <= 2e-6 * float(t0.abs().max())
+
+
+@pytest.mark.gpu
+def test_hash_backward_tables_form_equals_one_pass_per_table(ops, n=9000):
+    """nerf_hash_encode_bwd_ws_store_tables: three tables of one level structure (Part 4's deformation grids: L12, T 2^16) scattered
+    to from the same points in ONE count / plan / scatter / reduce pass = three single-table overwrite passes; the forward's
+    multi-table launch (nerf_hash_encode_fwd_nat_tables) = three single launches."""
+    t = ops.HashLevelTable(12, 16, 16, 1.5)
+    gen = torch.Generator().manual_seed(21)
+    pts = ((torch.rand(max(n, 1), 3, generator=gen) - 0.5) * 3.0)[:n].cuda()
+    E = t.entries
+    d_feat = torch.randn(3, n, 24, generator=gen).cuda()                  # equally spaced feature gradients
+    flat = torch.full((3 * E * 2,), float("nan"), device="cuda")          # equally spaced table gradients, whatever they held
+    views = [flat[k * 2 * E:(k + 1) * 2 * E] for k in range(3)]
+    lib = ops._lib.load()
+    ws_of = lambda n_, L_, k_: torch.empty(max(lib.nerf_hash_encode_bwd_tables_workspace_bytes(n_, L_, k_), 256), dtype=torch.uint8, device="cuda")
+    assert ops.hash_encode_bwd_tables(pts, t, 1.5, [d_feat[k] for k in range(3)], views, ws_of)
+    ref = torch.full((3, E, 2), float("nan"), device="cuda")
+    ws = torch.empty(max(ops.hash_encode_bwd_workspace_bytes(n, 12), 256), dtype=torch.uint8, device="cuda")
+    for k in range(3):
+        ops.hash_encode_bwd(pts, t, 1.5, d_feat[k], ref[k], workspace=ws, overwrite=True)
+    assert bool(torch.isfinite(flat).all())
+    scale = max(float(ref.abs().max()), 1e-30)
+    assert float((flat.view(3, E, 2) - ref).abs().max()) <= 1e-6 * scale
+    # unequal spacing: refused, nothing launched
+    assert not ops.hash_encode_bwd_tables(pts, t, 1.5, [d_feat[0], d_feat[2], d_feat[1]], views, ws_of)
+    # no points at all (C entry point): every table is still overwritten, with zeros
+    flat.fill_(3.0)
+    ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_tables(None, 0, 3, E, 12, *t.host_args(), 1.5, None, 0, flat.data_ptr(), None, 0,
+                                                            torch.cuda.current_stream().cuda_stream), "tables, n = 0")
+    assert float(flat.abs().max()) == 0.0
+    # forward: three fp16 tables in one launch
+    tabs = (torch.rand(3 * E, 2, generator=gen) - 0.5).cuda().half()
+    n_pad = (n + 127) // 128 * 128
+    img = torch.zeros(3, n_pad * 32, dtype=torch.float16, device="cuda")
+    one = torch.zeros_like(img)
+    assert ops.hash_encode_fwd_nat_tables(pts, [tabs[k * E:(k + 1) * E] for k in range(3)], t, 1.5, [img[k] for k in range(3)], fp16=True)
+    for k in range(3):
+        ops.hash_encode_fwd_nat(pts, tabs[k * E:(k + 1) * E], t, 1.5, one[k], fp16=True)
+    assert torch.equal(img, one)
