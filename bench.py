@@ -301,7 +301,8 @@ def bench_part4(args, device, steps=200):
         "hash_fwd + fused chains fwd": event_ms(fwd, 20),
         "chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters": event_ms(
             lambda: p4.backward_chain(eng.packed, eng.net, eng.table(3, half=True), eng.levels_d, eng.levels_c, eng.bound, pts, xc, ws, rgb, sigma,
-                                      d_rgb, d_sigma, d_dx.clone(), eng.g_net, g_tabs, hash_ws=eng._hash_scratch, overwrite=True), 20),   # as the engine's step calls it
+                                      d_rgb, d_sigma, d_dx.clone(), eng.g_net, g_tabs, hash_ws=eng._hash_scratch, overwrite=True,
+                                      tables_ws=eng._hash_scratch_tables), 20),   # as the engine's step calls it
         "tv + clip + adamw (28.5 M parameters)": event_ms(eng.apply_gradients, 20),
     }
     n_par = eng.tables.numel() + eng.net.numel()
@@ -324,10 +325,10 @@ def bench_part4(args, device, steps=200):
     roof = {
         "hash_fwd": {"kernel": "hash_fwd_kernel<fp16 table> x4", "work_per_launch": gather + n * (12 + 4 * 64),
                      "ms": k["hash_fwd (3 deformation grids + canonical)"], "traffic": traffic({"hash_fwd_kernel<fp16 table>": 2})},      # the three deformation grids in one launch + the canonical grid
-        "backward": {"kernel": "p4 chains bwd + mlp_wgrad_small_kernel<true> x2 + hash_bwd_input_kernel + hash_bin_* x4", "work_per_launch": scatter,
+        "backward": {"kernel": "p4 chains bwd + mlp_wgrad_small_kernel<true> x2 + hash_bwd_input_kernel + hash_bin_* x2 (deformation grids in one pass, canonical grid)", "work_per_launch": scatter,
                      "ms": k["chains bwd + tiny-MLP wgrad + hash input gradient + 4 scatters"],
-                     "traffic": traffic({"hash_bin_count_pm_kernel": 4, "hash_bin_plan_kernel": 4, "hash_bin_scatter_kernel<true>": 4,
-                                         "hash_bin_reduce_kernel": 4, "hash_bwd_input_kernel<fp16 table>": 1, "p4::canon_bwd_kernel": 1,
+                     "traffic": traffic({"hash_bin_count_pm_kernel": 2, "hash_bin_plan_kernel": 2, "hash_bin_scatter_kernel<true>": 2,
+                                         "hash_bin_reduce_kernel": 2, "hash_bwd_input_kernel<fp16 table>": 1, "p4::canon_bwd_kernel": 1,
                                          "p4::deform_bwd_kernel": 1, "mlp_wgrad_small_kernel<true>": 2})},
         "tv_clip_adamw": {"kernel": "tv_normsq_kernel<true> x5 + adamw_clip_kernel<true> x3", "work_per_launch": n_par * 42,
                           "ms": k["tv + clip + adamw (28.5 M parameters)"],
