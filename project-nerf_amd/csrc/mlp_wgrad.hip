@@ -311,7 +311,7 @@ __device__ __forceinline__ void wait_vm() {
 // kernel's bytes less per wave tile).  The 16-wide natural gradient block (job.a2) lands in the stage's unused N region; wave
 // w contracts it with column tile w (a tenth accumulator tile); its row o2_row summed over the samples is sigma_layer's bias
 // gradient: the wave whose turn it is (stage number mod 8) adds its operand registers on the vector ALU.
-template <int PA, int PB, int PN, int NT_ACC, int NT_NAT, bool ONES, bool SPLIT, bool SIG = false>
+template <int PA, int PB, int PN, int NT_ACC, int NT_NAT, bool ONES, bool SPLIT, bool SIG = false, class Stage = BigStage>
 __device__ __forceinline__ void run_job16(const WgradArgs& args, const WgradJob job, int wt0, int wt1, char* smem, const LaneGeo g) {
   static_assert(!SIG || (PN == 0 && !SPLIT && NT_ACC == 8), "the merged job uses the N region and one column tile per wave");
   constexpr int NT = SPLIT ? 2 : NT_ACC + NT_NAT + (ONES ? 1 : 0);
@@ -344,21 +344,21 @@ __device__ __forceinline__ void run_job16(const WgradArgs& args, const WgradJob 
     } else if (pc < PA + PB) {
       stride[i] = PB * 1024;
       base[i] = job.b_acc + (pc - PA) * 1024;
-      dst[i] = kWgStageA + (pc - PA) * 1024;
+      dst[i] = Stage::A + (pc - PA) * 1024;
     } else if (SIG && pc == PIECES - 1) {
       stride[i] = 1024;
       base[i] = job.a2;
-      dst[i] = kWgStageA + kWgStageB;
+      dst[i] = Stage::A + Stage::B;
     } else {
       stride[i] = PN * 1024;
       base[i] = job.b_nat + (pc - PA - PB) * 1024;
-      dst[i] = kWgStageA + kWgStageB + (pc - PA - PB) * 1024;
+      dst[i] = Stage::A + Stage::B + (pc - PA - PB) * 1024;
     }
     base[i] += (size_t)wt0 * stride[i];
   }
   const unsigned smem_lds = lds_addr(smem), voff = lane * 16;
   auto issue = [&](int wt) {            // stages are issued in order: base[] walks with them
-    const unsigned stage = smem_lds + (wt & (kWgStages - 1)) * kWgStageBytes;
+    const unsigned stage = smem_lds + (wt & (kWgStages - 1)) * Stage::Bytes;
 #pragma unroll
     for (int i = 0; i < FULL; ++i) {
       dma_1k_s(base[i], voff, stage + dst[i]);
@@ -383,10 +383,10 @@ __device__ __forceinline__ void run_job16(const WgradArgs& args, const WgradJob 
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   auto mfmas = [&](int wt) {
-    const char* stage = smem + (wt & (kWgStages - 1)) * kWgStageBytes;
+    const char* stage = smem + (wt & (kWgStages - 1)) * Stage::Bytes;
     const char* pa = SPLIT ? stage + g.off_nat - 1024 * g.fhalf : stage + wave * 2048 + g.off_acc;
-    const char* pb = stage + kWgStageA + g.off_acc + (SPLIT ? (wave < NT_ACC ? wave : 0) * 2048 : 0);
-    const char* pn = stage + kWgStageA + kWgStageB + g.off_nat;
+    const char* pb = stage + Stage::A + g.off_acc + (SPLIT ? (wave < NT_ACC ? wave : 0) * 2048 : 0);
+    const char* pn = stage + Stage::A + Stage::B + g.off_nat;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 af = SPLIT ? tr_frag<128>(pa + 512 * s) : tr_frag<256>(pa + 1024 * s);
@@ -458,7 +458,7 @@ __device__ __forceinline__ void run_job16(const WgradArgs& args, const WgradJob 
   if constexpr (SIG) {
     // row o2_row of the tenth tile = d sigma_layer.weight[wave*32 + c32]; the bias sum: lanes o2_row and 32 + o2_row of every
     // wave hold partial sums over that wave's stages -> scratch behind the ring -> wave 0 adds the eight in order
-    float* red = reinterpret_cast<float*>(smem + kWgLds);
+    float* red = reinterpret_cast<float*>(smem + kWgStages * Stage::Bytes);
     const float both = sig_bias + __shfl(sig_bias, (lane + 32) & 63);
     if (lane == job.o2_row) red[wave] = both;
     __builtin_amdgcn_s_barrier();
@@ -687,8 +687,9 @@ __global__ void __launch_bounds__(512, 2) mlp_wgrad_kernel(const WgradArgs args)
 // workgroup fill the waits of the first (the decoder's kernel holds 256 VGPRs and 144 KiB of LDS: one per CU)
 // P4 = false: the Part 2 Instant jobs (kinds 6..9); true: the Part 4 field's jobs (kinds 6..12, p4mlp.hip) -- its own
 // instantiation so that the three-tile jobs' registers do not lower the occupancy of the Instant step's kernel
+// (launch bounds: the Instant jobs fit 80 VGPRs = three workgroups per CU, 46.7 -> 44.3 us; the Part 4 jobs spill there, 48 -> 52 us)
 template <bool P4>
-__global__ void __launch_bounds__(512) mlp_wgrad_small_kernel(const WgradArgs args) {
+__global__ void __launch_bounds__(512, P4 ? 4 : 6) mlp_wgrad_small_kernel(const WgradArgs args) {
   using Stage = std::conditional_t<P4, SmallStageP4, SmallStage>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   LaneGeo g;
@@ -709,19 +710,24 @@ __global__ void __launch_bounds__(512) mlp_wgrad_small_kernel(const WgradArgs ar
     const long long a0 = lo > j0 ? lo - j0 : 0, a1 = (hi < j1 ? hi : j1) - j0;
     const int wt0 = (int)((a0 + job.cost - 1) / job.cost), wt1 = (int)((a1 + job.cost - 1) / job.cost);
     if (wt0 >= wt1) continue;
+    // straight-line ring loop (run_job16): piece counts as template constants; the 1-KiB pieces of a stage are A (PA), blocked B
+    // (PB), natural-order B (PN)
     if constexpr (P4) {
       switch (job.kind) {
-        case 10: run_job<2, 0, true, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;    // time modulation layer 2 (+ bias)
-        case 11: run_job<2, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;   // displacement decoder layer 1
-        case 12: run_job<0, 2, false, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;   // sigma-net layer 1 on [hash | time code]
+        case 10: run_job16<4, 4, 0, 2, 0, true, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;    // time modulation layer 2 (+ bias)
+        case 11: run_job16<4, 4, 2, 2, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;   // displacement decoder layer 1
+        case 12: run_job16<4, 0, 4, 0, 2, false, false, false, Stage>(args, job, wt0, wt1, smem, g); continue;   // sigma-net layer 1 on [hash | time code]
         default: break;
       }
     }
     switch (job.kind) {
-      case 6: run_job<0, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); break;   // sigma-net layer 1
-      case 7: run_job<2, 0, false, false, false, Stage>(args, job, wt0, wt1, smem, g); break;   // 64-wide layers
-      case 8: run_job<1, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); break;   // colour-net layer 1
-      default: run_job<2, 0, false, true, false, Stage>(args, job, wt0, wt1, smem, g); break;   // rgb layer
+      case 6: run_job16<4, 0, 2, 0, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); break;   // sigma-net layer 1
+      case 7:                                                                                           // 64-wide layers: 64 or 16 outputs
+        if (job.mt_a == 2) run_job16<4, 4, 0, 2, 0, false, false, false, Stage>(args, job, wt0, wt1, smem, g);
+        else run_job16<2, 4, 0, 2, 0, false, false, false, Stage>(args, job, wt0, wt1, smem, g);
+        break;
+      case 8: run_job16<4, 2, 2, 1, 1, false, false, false, Stage>(args, job, wt0, wt1, smem, g); break;   // colour-net layer 1
+      default: run_job16<1, 4, 0, 2, 0, false, true, false, Stage>(args, job, wt0, wt1, smem, g); break;   // rgb layer
     }
   }
 }
