@@ -11,7 +11,6 @@ import torch  # noqa: E402
 import yaml  # noqa: E402
 
 from src.core import NeuralField  # noqa: E402
-from project_nerf_amd.dynamic import part4_probe_draws  # noqa: E402
 from project_nerf_amd.part4 import DualHashEngine  # noqa: E402
 
 dev = "cuda"
