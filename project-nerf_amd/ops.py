@@ -184,7 +184,7 @@ def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float
     z = torch.empty(R, n_samples, device=dev)
     slots = torch.empty(n, device=dev, dtype=torch.int32)
     pts, dirs = torch.empty(max(n, 1), 3, device=dev), torch.empty(max(n, 1), 3, device=dev)
-    count = torch.zeros(1, device=dev, dtype=torch.int32)
+    count = torch.empty(1, device=dev, dtype=torch.int32)          # zeroed by the library call itself
     if u is None and jitter is not None:
         _lib.check(lib.nerf_sample_compact_jitter_shard(_p(rays_o), _p(rays_d), int(jitter[0]), int(jitter[1]) & 0xFFFFFF, int(first_ray),
                                                         R, n_samples, near, far, _p(grid), grid.shape[0], float(bound), _p(z), _p(slots),

@@ -241,7 +241,9 @@ class DualHashEngine:
         self.tables_h = torch.empty(total, dtype=torch.float16, device=self.device)
         self.g_tables = torch.zeros(total, device=self.device)
         self.net = torch.zeros(N_PARAMS, device=self.device)
-        self.g_net = torch.zeros(N_PARAMS, device=self.device)
+        # network gradients and the step's four scalars (loss, regulariser, squared gradient norm, spare) in one buffer: one fill per step
+        self._g_net_scalars = torch.zeros(N_PARAMS + 4, device=self.device)
+        self.g_net = self._g_net_scalars[:N_PARAMS]
         self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in (("tables", self.tables), ("net", self.net))}
         self.packed = torch.empty(_lib.load().nerf_p4_packed_bytes(), dtype=torch.uint8, device=self.device)
         self.near, self.far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
@@ -261,7 +263,7 @@ class DualHashEngine:
         self.grid = torch.zeros(res, res, res, device=self.device)
         self.binary_grid = torch.ones(res, res, res, dtype=torch.bool, device=self.device)
         self.step_count = 0
-        self._scalars = torch.zeros(4, device=self.device)          # loss, regulariser, squared gradient norm, spare
+        self._scalars = self._g_net_scalars[N_PARAMS:]
         self._ws: Dict[int, Workspace] = {}
         self._hash_ws = None
         self._hash_ws_tables = None
@@ -345,8 +347,7 @@ class DualHashEngine:
         z, slots, pts, dirs = prepared.get()
         n = pts.shape[0]
         bg = self.bg if bg is None else bg
-        self.g_net.zero_()
-        self._scalars.zero_()
+        self._g_net_scalars.zero_()
         loss, reg = self._scalars[0:1], self._scalars[1:2]
         handles = []
         reduce = (lambda view: handles.append(sync_grads_async(view))) if sync_grads_async is not None else (lambda view: None)
