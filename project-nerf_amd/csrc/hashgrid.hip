@@ -483,19 +483,25 @@ hash_bin_count_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, Bi
 // walks the levels, and leaves a level-major copy of the gradients for the scatter pass.  Needs the histograms of
 // all levels in LDS at once: used when the call has at most kPmBins bins (2048 for L16 / T2^19).
 constexpr unsigned kPmBins = 8192;
+// levels per workgroup row of the point-major count pass: all of them for a large batch (198 k points: 46 us, in rows of four
+// 63 us -- four times the point reads and flushes), four for a small one (54 k points x 36 levels: 37 -> 18 us per launch)
+inline int pm_levels_per_row(int64_t n, int n_levels) { return n >= 131072 ? n_levels : 4; }
 __global__ void __launch_bounds__(256)
 hash_bin_count_pm_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
-                         unsigned* __restrict__ count, BinHeader* __restrict__ header, float2* __restrict__ grad_lm) {
+                         unsigned* __restrict__ count, BinHeader* __restrict__ header, float2* __restrict__ grad_lm, int levels_per_row) {
   __shared__ unsigned hist[kPmBins];
   __shared__ unsigned wg_amax;
-  const unsigned n_bins = plan.bin0[plan.count];
-  for (unsigned i = threadIdx.x; i < n_bins; i += blockDim.x) hist[i] = 0;
+  // blockIdx.y: a chunk of levels_per_row levels -- a lane walking all 16 (36) levels alone is a long dependent chain, and a small
+  // batch (54 k points) leaves less than one wave per SIMD to hide it
+  const int li0 = blockIdx.y * levels_per_row, li1 = min(li0 + levels_per_row, plan.count);
+  const unsigned bin_lo = plan.bin0[li0], bin_hi = plan.bin0[li1];
+  for (unsigned i = bin_lo + threadIdx.x; i < bin_hi; i += blockDim.x) hist[i] = 0;
   if (threadIdx.x == 0) wg_amax = 0;
   __syncthreads();
   float amax = 0.0f;
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
     const float px = pts[p * 3 + 0], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
-    for (int li = 0; li < plan.count; ++li) {
+    for (int li = li0; li < li1; ++li) {
       const int vl = plan.first + li, tbl = vl / L.n_levels;
       const float2 g = *reinterpret_cast<const float2*>(d_feat + tbl * plan.dfeat_stride + p * (2 * L.n_levels) + 2 * (vl - tbl * L.n_levels));
       grad_lm[(int64_t)li * n + p] = g;
@@ -518,7 +524,7 @@ hash_bin_count_pm_kernel(const float* __restrict__ pts, int64_t n, HashLevels L,
   __syncthreads();
   if (threadIdx.x == 0 && wg_amax > __hip_atomic_load(&header->amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(&header->amax_bits, wg_amax);
-  for (unsigned i = threadIdx.x; i < n_bins; i += blockDim.x)
+  for (unsigned i = bin_lo + threadIdx.x; i < bin_hi; i += blockDim.x)
     if (hist[i] != 0) atomicAdd(count + i, hist[i]);
 }
 
@@ -972,8 +978,9 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
       } else if (point_major) {
         int64_t bpm = (n + 255) / 256;
         if (bpm > 1024) bpm = 1024;
-        hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm), dim3(256), 0, as_stream(stream), pts, n, L, plan, d_feat, w.count,
-                           w.header, w.grad_lm);
+        const int per_row = pm_levels_per_row(n, plan.count);
+        hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm, (plan.count + per_row - 1) / per_row), dim3(256), 0, as_stream(stream),
+                           pts, n, L, plan, d_feat, w.count, w.header, w.grad_lm, per_row);
       } else
         hipLaunchKernelGGL(hash_bin_count_kernel, dim3((int)bx_count, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan, d_feat,
                            w.count, w.header);
@@ -1128,8 +1135,9 @@ extern "C" int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n,
     return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws_store_tables: memset failed");
   int64_t bpm = (n + 255) / 256;
   if (bpm > 1024) bpm = 1024;
-  hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm), dim3(256), 0, as_stream(stream), pts, n, L, plan, d_feat, w.count, w.header,
-                     w.grad_lm);
+  const int per_row = pm_levels_per_row(n, plan.count);
+  hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm, (plan.count + per_row - 1) / per_row), dim3(256), 0, as_stream(stream), pts, n,
+                     L, plan, d_feat, w.count, w.header, w.grad_lm, per_row);
   hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header, 1);
   int64_t bx = (n + 511) / 512;
   const int64_t bx_scatter = bx > 128 ? 128 : bx;
