@@ -539,7 +539,7 @@ __device__ __forceinline__ int fixed_shift(unsigned amax_bits) {
 __global__ void __launch_bounds__(1024)
 hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ count, unsigned* __restrict__ cursor,
                      BinItem* __restrict__ items, BinHeader* __restrict__ header, int overwrite) {
-  __shared__ unsigned scan_r[1024], scan_i[1024];
+  __shared__ unsigned scan_r[1024], scan_i[1024], wave_r[16], wave_i[16];
   __shared__ unsigned carry_r, carry_i;
   const unsigned n_bins = plan.bin0[plan.count];
   if (threadIdx.x == 0) carry_r = carry_i = 0;
@@ -549,16 +549,22 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
     const unsigned c = b < n_bins ? count[b] : 0u;
     // overwrite form: every bin gets an item (an empty bin's item stores a slice of zeros)
     const unsigned it = (b < n_bins && overwrite && c == 0) ? 1u : (c + kChunk - 1) / kChunk;
-    scan_r[threadIdx.x] = c;
-    scan_i[threadIdx.x] = it;
-    __syncthreads();
-    for (unsigned d = 1; d < 1024; d <<= 1) {                 // inclusive Hillis-Steele scan of both columns
-      const unsigned ar = threadIdx.x >= d ? scan_r[threadIdx.x - d] : 0u, ai = threadIdx.x >= d ? scan_i[threadIdx.x - d] : 0u;
-      __syncthreads();
-      scan_r[threadIdx.x] += ar;
-      scan_i[threadIdx.x] += ai;
-      __syncthreads();
+    // inclusive scan of both columns: within the wave by shuffles, the sixteen wave totals through LDS (two barriers per round
+    // instead of twenty: the launch sits alone on the pass's critical path)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned sr = c, si = it;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned ur = __shfl_up(sr, d), ui = __shfl_up(si, d);
+      if (lane >= d) { sr += ur; si += ui; }
     }
+    if (lane == 63) { wave_r[wave] = sr; wave_i[wave] = si; }
+    __syncthreads();
+    unsigned before_r = 0, before_i = 0;
+    for (int w = 0; w < wave; ++w) { before_r += wave_r[w]; before_i += wave_i[w]; }
+    scan_r[threadIdx.x] = sr + before_r;
+    scan_i[threadIdx.x] = si + before_i;
+    __syncthreads();
     const unsigned r0 = carry_r + scan_r[threadIdx.x] - c, i0 = carry_i + scan_i[threadIdx.x] - it;
     if (b < n_bins) {
       cursor[b] = r0;
