@@ -601,7 +601,7 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
 // the workspace, so a wave's store covers a few whole lines instead of 64 separate 12-byte pieces.
 constexpr unsigned kStagedBins = 256;
 template <bool STAGED>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, 8)
 hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
                         unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header,
                         const float2* __restrict__ grad_lm, const unsigned* __restrict__ count, float* __restrict__ zero_table,
@@ -610,7 +610,9 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
   __shared__ unsigned cnt[kBins], base[kBins];
   __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
   __shared__ BinRecord stage[STAGED ? 4096 : 1];
-  __shared__ unsigned dest[STAGED ? 4096 : 1];
+  __shared__ unsigned char bin_of[STAGED ? 4096 : 1];       // bin of every staged record (<= kStagedBins = 256 bins): its place in the workspace is
+                                                            // base[bin] + (position in the stage - start[bin]); 4 KiB instead of 16 KiB of places:
+                                                            // 39 KiB of LDS per workgroup, four workgroups per CU instead of three
   const int tbl = (plan.first + (int)blockIdx.y) / L.n_levels, lvl = plan.first + (int)blockIdx.y - tbl * L.n_levels;
   const unsigned bins = plan.bin0[blockIdx.y + 1] - plan.bin0[blockIdx.y], offset = L.offset[lvl];
   if (STAGED != (bins <= kStagedBins)) return;                 // the other instantiation owns this level
@@ -683,12 +685,15 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
         for (int k = 0; k < 8; ++k) {
           const unsigned local = c.idx[k] - offset, b = local >> kSliceLog2, pos = start[b] + slot[k];
           stage[pos] = pack_record(local & (kSlice - 1), c.w[k] * g0, c.w[k] * g1, scale);
-          dest[pos] = base[b] + slot[k];
+          bin_of[pos] = (unsigned char)b;
         }
       }
       __syncthreads();
       const unsigned count = total;
-      for (unsigned q = threadIdx.x; q < count; q += blockDim.x) records[dest[q]] = stage[q];
+      for (unsigned q = threadIdx.x; q < count; q += blockDim.x) {
+        const unsigned b = bin_of[q];
+        records[base[b] + (q - start[b])] = stage[q];
+      }
       __syncthreads();                          // stage, start and base are rewritten by the next round
     } else {
       for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) {
