@@ -427,6 +427,73 @@ def g14_part4():
     del sys.modules["tinycudann"]
 
 
+def trained_spectrum_table(levels, seed):
+    """Hash-table values with the spectrum of a trained field: amplitude 8 / resolution per level (uniform), i.e. every level
+    contributes a bounded d feature / d x -- unlike part4_table's amplitude 0.5 at every level, where a 1e-3 shift of
+    x_canonical lands in unrelated cells of the fine levels and any implementation's rounding is amplified without bound."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.cat([(torch.rand(lv.size * 2, generator=g) - 0.5) * (8.0 / lv.res) for lv in levels])
+
+
+def g14b_part4_trained():
+    """g14's forward + autograd of the reference's NeuralField('part4') (src/core.py:282-352) on tables with a trained
+    spectrum and the reference's DEFAULT displacement scale (0.1, src/decoders.py:296): the vector the fused HIP chains --
+    the path bench.py times for configs[4] -- are compared with directly (rgb, sigma, delta_x and every parameter gradient,
+    the four tables in full)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tinycudann", os.path.join(HERE, "tinycudann_shim.py"))
+    shim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shim)
+    sys.modules["tinycudann"] = shim
+    torch.manual_seed(14)
+    model = NeuralField(dict(PART4_CFG))
+    names = ("canonical_repr", "deform_grid_start", "deform_grid_mid", "deform_grid_end")
+    tables = {}
+    with torch.no_grad():
+        for k, name in enumerate(names):
+            enc = getattr(model, name).encoding
+            enc.params.copy_(trained_spectrum_table(enc.levels, 140 + k))
+            tables["t:" + name] = enc.params.detach().clone()
+        model.decoder.sigma_net.params[:64 * 64].mul_(1.5)
+        model.decoder.sigma_net.params[64 * 64:64 * 64 + 64].mul_(24.0)     # the density row: visible densities
+        model.deform_decoder.deform_net.params.mul_(2.0)
+    assert abs(float(model.deform_decoder.displacement_scale) - 0.1) < 1e-7   # the reference's default
+    sd = {k: v.clone() for k, v in model.state_dict().items() if "encoding.params" not in k and "freq_bands" not in k}
+    gen = torch.Generator().manual_seed(43)
+    n = 512
+    pts = (torch.rand(n, 3, generator=gen) - 0.5) * 3.0
+    pts[:16] = (torch.rand(16, 3, generator=gen) - 0.5) * 3.3              # a few outside the box (clamped lookups)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    times = torch.rand(n, 1, generator=gen)
+    times[:3] = torch.tensor([[0.0], [0.5], [1.0]])
+    model.eval()
+    rgb, sigma, delta = model(pts, dirs, t=times)
+    w_rgb, w_dx = torch.randn(n, 3, generator=gen), torch.randn(n, 3, generator=gen)
+    model.zero_grad()
+    ((rgb * w_rgb).sum() + sigma.sum() + (delta * w_dx).sum()).backward()
+    keep = lambda k: not k.startswith("deformation_grid.")
+    grads = {"g:" + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None and keep(k)}
+    # the same forward + autograd with the stand-in's outputs rounded to fp16, tinycudann's output precision
+    shim.FP16_OUTPUTS = True
+    try:
+        rgb16, sigma16, delta16 = model(pts, dirs, t=times)
+        model.zero_grad()
+        ((rgb16 * w_rgb).sum() + sigma16.sum() + (delta16 * w_dx).sum()).backward()
+        grads16 = {"g16:" + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None and keep(k)}
+    finally:
+        shim.FP16_OUTPUTS = False
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    print(f"  g14b: max |delta_x| {float(delta.abs().max()):.3e}, sigma range {float(sigma.min()):.3e} .. {float(sigma.max()):.3e}, "
+          f"{int((sigma > 0.5).sum())} of {n} with sigma > 0.5")
+    print(f"  g14b, fp16 operator outputs vs fp32: delta_x {float((delta16 - delta).abs().max() / delta.abs().max()):.2e} of max, "
+          f"|d rgb| {float((rgb16 - rgb).abs().max()):.2e}; gradients rel: " +
+          ", ".join(f"{k[2:].split('.')[0]}.{k.split('.')[-2]} {rel(grads16['g16:' + k[2:]], v):.3f}" for k, v in grads.items()))
+    save("g14b_part4_trained", pts=pts, dirs=dirs, times=times, rgb=rgb, sigma=sigma, delta=delta, w_rgb=w_rgb, w_dx=w_dx,
+         rgb16=rgb16, sigma16=sigma16, delta16=delta16,
+         **tables, **{"w:" + k: v for k, v in sd.items()}, **grads, **grads16)
+    del sys.modules["tinycudann"]
+
+
 PART3_CFGS = {
     "nerf": {"mode": "part3", "canonical_type": "nerf", "L_embed": 6, "L_embed_canon": 8, "L_embed_dir": 4, "L_embed_time": 6,
              "hidden_dim": 64, "num_layers": 5, "skip_layer": 3, "view_dim": 32, "deform_hidden_dim": 48, "deform_num_layers": 3},
@@ -532,4 +599,5 @@ if __name__ == "__main__":
     g12_part1()
     g13_instant_glue()
     g14_part4()
+    g14b_part4_trained()
     g15_part3()

@@ -32,6 +32,17 @@ def _pad16(n):
     return (n + 15) // 16 * 16
 
 
+# tinycudann returns fp16 from both operators ("[N, L*F] fp16", "[N, out] fp16").  False (default): the
+# stand-in stays fp32 end to end (the goldens' main vectors).  True: outputs are rounded to fp16 and widened again -- what
+# make_golden.py::g14b uses for its SECOND set of vectors, which shows how far the reference's own Part 4 field moves when
+# only the operators' output precision is tinycudann's (displacements rounded to fp16 land in other fine hash cells).
+FP16_OUTPUTS = False
+
+
+def _out(y):
+    return y.half().float() if FP16_OUTPUTS else y
+
+
 class Encoding(nn.Module):
     def __init__(self, n_input_dims, encoding_config, dtype=None):
         super().__init__()
@@ -43,7 +54,7 @@ class Encoding(nn.Module):
         self.params = nn.Parameter((torch.rand(O.hash_grid_entries(self.levels) * self.n_features) * 2 - 1) * 1e-4)
 
     def forward(self, x01):
-        return O.hash_encode(self.levels, self.params.view(-1, self.n_features), x01)
+        return _out(O.hash_encode(self.levels, self.params.view(-1, self.n_features), x01))
 
 
 class Network(nn.Module):
@@ -79,4 +90,4 @@ class Network(nn.Module):
         if pad:
             x = torch.cat([x, x.new_zeros(x.shape[0], pad)], dim=-1)
         y = O.tiny_mlp(self.weights(), x.float(), out_act=self.out_act)
-        return y[:, :self.n_output_dims]
+        return _out(y[:, :self.n_output_dims])

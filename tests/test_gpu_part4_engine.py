@@ -142,6 +142,97 @@ def test_fused_field_vs_fp32_module_path_on_smooth_tables(smooth_pair):
     assert worst < 0.15, worst                 # fp16 forward / bf16 backward chains against fp32 autograd (measured <= 0.08)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# g14b: the REFERENCE's NeuralField('part4') forward + autograd (src/core.py:282-352 around the stand-in tinycudann) on
+# tables with a trained spectrum at the reference's default displacement scale (0.1): the fused operator -- the path
+# bench.py times for configs[4] -- against it DIRECTLY: rgb, sigma, delta_x and every parameter gradient.
+def build_g14b(fused):
+    from src.core import NeuralField
+    g = golden("g14b_part4_trained")
+    m = NeuralField(dict(PART4_CFG, fused_part4=fused))
+    sd = m.state_dict()
+    for name in ("canonical_repr", "deform_grid_start", "deform_grid_mid", "deform_grid_end"):
+        assert sd[name + ".encoding.params"].shape == g["t:" + name].shape, name
+        sd[name + ".encoding.params"] = T(g["t:" + name])
+    sd["deformation_grid.encoding.params"] = sd["deform_grid_start.encoding.params"]
+    for k, v in g.items():
+        if k.startswith("w:"):
+            assert k[2:] in sd and tuple(sd[k[2:]].shape) == v.shape, k
+            sd[k[2:]] = T(v)
+    m.load_state_dict(sd)
+    assert abs(float(m.deform_decoder.displacement_scale) - 0.1) < 1e-7
+    return m.cuda(), g
+
+
+# Bounds = 1.5x the values measured on MI355X (gpurun_out/r04/t_g14b.log, printed by the test).  Two families of gradients:
+#   * the canonical decoder's networks see only the rounding of their own chain: 0.6 % / 1.1 %;
+#   * everything behind d loss / d x_canonical (time modulation, displacement decoder, the three deformation grids) and the
+#     canonical table itself depend on WHICH fine cells x_canonical = x + delta_x falls into: d features / d x is piecewise
+#     constant per cell, the finest cells are 4.3e-4 wide and the table's spectrum gives every level the same share of that
+#     derivative.  The fused forward chain contracts fp16 operands (tinycudann's precision): delta_x is within 1.9e-3 of its
+#     maximum of the fp32 reference, i.e. 1.8e-4 absolute -- a third of a finest cell -- and those gradients move by 10-26 %.
+#     That is the field's own sensitivity, not the kernels': the golden carries a SECOND set of reference vectors (g16:*) for
+#     which only the stand-in operators' OUTPUTS were rounded to fp16 (delta_x moves by 2.8e-4 of its maximum): the
+#     reference's own gradients then move by 1.0-2.6 % -- the same 90-140x ratio of gradient error to delta_x error.  The
+#     test prints both next to each other.
+G14B_FUSED = dict(delta=3.0e-3, rgb=1.0e-3, sigma=1.0e-2, grads={
+    "decoder.sigma_net.params": 0.0085, "decoder.color_net.params": 0.0165, "canonical_repr.encoding.params": 0.17,
+    "deform_decoder.deform_net.params": 0.16, "deform_decoder.displacement_scale": 0.27, "time_modulation.net.2.bias": 0.17,
+    "time_modulation.net.2.weight": 0.29, "time_modulation.net.0.bias": 0.29, "time_modulation.net.0.weight": 0.36,
+    "deform_grid_start.encoding.params": 0.32, "deform_grid_mid.encoding.params": 0.35, "deform_grid_end.encoding.params": 0.40})
+# the fp32 module path (stand-alone operators, library GEMMs): measured 6.4e-7 / 7.7e-7 / 5.4e-6 and <= 1e-4 on every gradient
+G14B_FP32 = dict(delta=2e-6, rgb=2e-6, sigma=1e-5, grads=2e-4)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_chains", "fp32_module_path"])
+def test_part4_field_vs_reference_golden_trained_spectrum(fused):
+    m, g = build_g14b(fused)
+    assert m._p4_fused == fused
+    bound = G14B_FUSED if fused else G14B_FP32
+    pts, dirs, times = T(g["pts"]).cuda(), T(g["dirs"]).cuda(), T(g["times"]).cuda()
+    m.eval()                                    # as the golden was taken: no coordinate / time noise; autograd stays on
+    m.zero_grad()
+    rgb, sigma, delta = m(pts, dirs, t=times)
+    ((rgb * T(g["w_rgb"]).cuda()).sum() + sigma.sum() + (delta * T(g["w_dx"]).cuda()).sum()).backward()
+    e_d = float(np.abs(delta.detach().cpu().numpy() - g["delta"]).max() / np.abs(g["delta"]).max())
+    e_c = float(np.abs(rgb.detach().cpu().numpy() - g["rgb"]).max())
+    e_s = float((np.abs(sigma.detach().cpu().numpy() - g["sigma"]) / np.maximum(np.abs(g["sigma"]), 1.0)).max())
+    tag = "fused" if fused else "fp32 module path"
+    print(f"[g14b {tag} forward vs reference] delta_x rel-to-max {e_d:.3e}, |d rgb| {e_c:.3e}, rel d sigma {e_s:.3e}   "
+          f"(reference with fp16 operator outputs vs itself in fp32: {float(np.abs(g['delta16'] - g['delta']).max() / np.abs(g['delta']).max()):.3e}, "
+          f"{float(np.abs(g['rgb16'] - g['rgb']).max()):.3e})")
+    assert e_d < bound["delta"] and e_c < bound["rgb"] and e_s < bound["sigma"], (e_d, e_c, e_s)
+    params = dict(m.named_parameters())
+    checked, bad = 0, []
+    for k, v in g.items():
+        if not k.startswith("g:"):
+            continue
+        got, want = params[k[2:]].grad.detach().cpu().reshape(-1), T(v).reshape(-1)
+        r = rel(got, want)
+        cos = float(torch.dot(got, want) / (got.norm() * want.norm() + 1e-30))
+        own = rel(T(g["g16:" + k[2:]]).reshape(-1), want)
+        print(f"[g14b {tag} grads vs reference autograd] {k[2:]:45s} rel {r:.4f} cos {cos:.5f} |g| {float(want.norm()):.3e}   "
+              f"(reference, fp16 operator outputs: rel {own:.4f})")
+        if not r < (bound["grads"][k[2:]] if fused else bound["grads"]):
+            bad.append((k, r))
+        checked += 1
+    assert checked == 12 and not bad, bad
+
+
+def test_engine_forward_vs_reference_golden_trained_spectrum():
+    """DualHashEngine.field (flat parameters, fp16 copy of the tables) on g14b's weights against the reference's outputs"""
+    m, g = build_g14b(True)
+    eng, _ = make_engine(m)
+    with torch.no_grad():
+        rgb, sigma, delta = eng.field(T(g["pts"]).cuda(), T(g["dirs"]).cuda(), T(g["times"]).cuda())
+    e_d = float(np.abs(delta.cpu().numpy() - g["delta"]).max() / np.abs(g["delta"]).max())
+    e_c = float(np.abs(rgb.cpu().numpy() - g["rgb"]).max())
+    e_s = float((np.abs(sigma.cpu().numpy().reshape(-1, 1) - g["sigma"]) / np.maximum(np.abs(g["sigma"]), 1.0)).max())
+    print(f"[g14b engine forward vs reference] delta_x rel-to-max {e_d:.3e}, |d rgb| {e_c:.3e}, rel d sigma {e_s:.3e}")
+    b = G14B_FUSED                              # measured 1.95e-3 / 6.4e-4 / 7.0e-3 (the engine gathers from the fp16 copy of the tables)
+    assert e_d < b["delta"] and e_c < b["rgb"] and e_s < 1.1e-2, (e_d, e_c, e_s)
+
+
 def batch(R, S, seed):
     g = torch.Generator().manual_seed(seed)
     o = torch.randn(R, 3, generator=g)
@@ -160,17 +251,18 @@ def make_engine(m, **over):
     return eng, cfg
 
 
-def test_engine_gradients_equal_module_path_autograd(smooth_pair):
+def _engine_vs_module_autograd(m, cfg_over, R, S, res, bound, tag):
     """One batch through DualHashEngine.compute_gradients against torch autograd of the fp32 module path (render_rays with
-    times + MSE + the displacement regulariser) on the same samples."""
+    times + MSE + the displacement regulariser, reference run.py:1835-1860) on the same samples."""
     from src.renderer import DensityGrid, render_rays
     from project_nerf_amd import ops
-    from project_nerf_amd.part4 import GRIDS, MODULE_SLICES
-    m = smooth_pair[1]
-    eng, cfg = make_engine(m, use_tv_displacement=False, tv_loss_weight=0.0)
-    R, S = 512, 32
+    from project_nerf_amd.part4 import GRIDS, MODULE_SLICES, DualHashEngine
+    cfg = dict(cfg_over, grid_resolution=res, learning_rate=1e-2, train_iters=100, deformation_reg_weight=0.05, use_tv_displacement=False,
+               tv_loss_weight=0.0)
+    eng = DualHashEngine(cfg, seed=3)
+    eng.load_from_model(m)
     o, d, target, t = batch(R, S, 5)
-    ax = torch.linspace(-1.5, 1.5, 32)
+    ax = torch.linspace(-1.5, 1.5, res)
     gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
     eng.binary_grid = ((gx ** 2 + gy ** 2 + gz ** 2) < 1.2 ** 2).cuda()
     torch.manual_seed(7)
@@ -178,8 +270,9 @@ def test_engine_gradients_equal_module_path_autograd(smooth_pair):
     prepared = ops.sample_compact_async(o, d, 2.0, 6.0, S, eng.binary_grid, 1.5, u=u)
     loss = float(eng.compute_gradients(o, d, target, t, S, prepared=(prepared, 1)))
     reg = float(eng._scalars[1])
+    n_active = int(prepared.get()[2].shape[0])
     # the module path on the same batch
-    grid = DensityGrid(32, 1.5, 0.01).cuda()
+    grid = DensityGrid(res, 1.5, 0.01).cuda()
     grid.binary_grid = eng.binary_grid
     m.train()
     m.zero_grad()
@@ -190,18 +283,54 @@ def test_engine_gradients_equal_module_path_autograd(smooth_pair):
     (l_rgb + l_reg).backward()
     m.eval()
     l_rgb, l_reg = l_rgb.detach(), l_reg.detach()
+    print(f"[part4 engine vs module autograd, {tag}] {n_active} active samples of {R * S}; loss {loss:.6f} vs {float(l_rgb):.6f}, "
+          f"regulariser {reg:.3e} vs {float(l_reg):.3e}")
     assert abs(loss - float(l_rgb)) < 2e-2 * float(l_rgb) and abs(reg - float(l_reg)) < 5e-2 * float(l_reg) + 1e-9, (loss, float(l_rgb), reg, float(l_reg))
     sd = dict(m.named_parameters())
     worst = 0.0
     for key, off, cnt in MODULE_SLICES:
         r = rel(eng.g_net[off:off + cnt].cpu(), sd[key].grad.reshape(-1).cpu())
-        print(f"[part4 engine vs module autograd] {key:45s} rel {r:.4f}")
+        print(f"[part4 engine vs module autograd, {tag}] {key:45s} rel {r:.4f}")
         worst = max(worst, r)
     for k, name in enumerate(GRIDS):
         r = rel(eng.g_table(k).cpu(), getattr(m, name).encoding.params.grad.cpu())
-        print(f"[part4 engine vs module autograd] {name:45s} rel {r:.4f}")
+        print(f"[part4 engine vs module autograd, {tag}] {name:45s} rel {r:.4f}")
         worst = max(worst, r)
-    assert worst < 0.12, worst                 # measured: networks <= 0.03, displacement_scale 0.06, grids <= 0.03
+    assert worst < bound, worst
+
+
+def test_engine_gradients_equal_module_path_autograd(smooth_pair):
+    # measured: networks <= 0.03, displacement_scale 0.06, grids <= 0.03
+    _engine_vs_module_autograd(smooth_pair[1], PART4_CFG, 512, 32, 32, 0.12, "T = 2^11 / 2^10, displacement scale 1e-4")
+
+
+def test_engine_gradients_at_the_example_configuration_sizes():
+    """configs/part4.yaml.example's tables (T = 2^20 canonical, 2^16 deformation), batch (8192 rays x 64 samples) and occupancy
+    resolution (64): DualHashEngine.compute_gradients -- the launches bench.py times for BASELINE configs[4] -- against torch
+    autograd of the fp32 module path; trained-spectrum tables, the golden g14b's network weights, default displacement scale."""
+    import yaml
+    from conftest import ROOT
+    import os
+    from src.core import NeuralField
+    ycfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part4.yaml.example")))
+    cfg = {k: ycfg[k] for k in PART4_CFG if k in ycfg}
+    cfg["mode"] = "part4"
+    assert cfg["log2_hashmap_size"] == 20 and cfg["deform_log2_hashmap_size"] == 16
+    g = golden("g14b_part4_trained")
+    m = NeuralField(dict(cfg, fused_part4=False))
+    sd = m.state_dict()
+    for k, name in enumerate(("canonical_repr", "deform_grid_start", "deform_grid_mid", "deform_grid_end")):
+        sd[name + ".encoding.params"] = smooth_table(getattr(m, name).levels, 60 + k)
+    sd["deformation_grid.encoding.params"] = sd["deform_grid_start.encoding.params"]
+    for k, v in g.items():
+        if k.startswith("w:"):
+            sd[k[2:]] = T(v)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    # measured (250,509 active samples): canonical networks 0.2 %, canonical table 9 %, displacement decoder / time modulation
+    # 10-28 %, deformation grids 25-27 % -- the cell-crossing sensitivity g14b's docstring above quantifies on the reference itself
+    # (same level structure, same 4.3e-4 finest cell); with displacement scale 1e-4 the same comparison gives 1-3 % (test above)
+    _engine_vs_module_autograd(m, cfg, ycfg["batch_size"], ycfg["n_samples"], ycfg["grid_resolution"], 0.42, "part4.yaml.example sizes")
 
 
 def test_engine_probe_regularisers_equal_module_path_autograd(plain_model):
