@@ -41,6 +41,39 @@ MFMA_PEAK_TFLOPS = 2500.0    # gfx950 dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
+def kernel_sources_sha16():
+    """fingerprint of the HIP sources the library is built from (the generated headers follow from gen_*.py)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "project-nerf_amd", "csrc", "*"))):
+        name = os.path.basename(path)
+        if os.path.isfile(path) and name.endswith((".hip", ".h", ".cpp", ".py")) and name not in ("mlp_stream_asm.h", "mlp_mtile_asm.h"):
+            h.update(name.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary(name):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary (profiles/<name>; tools/pmc_r04.sh + tools/pmc_summarize.py:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes).  The counters cannot be read inside this
+    process, so the numbers are quoted from that file -- and ONLY while the kernels are the ones they were taken on: the
+    summary records the fingerprint of csrc/ at collection time; if the tree's differs (or the file has none), every
+    `traffic` of the line is null and `traffic_source.stale` says why.  Returns (per-kernel dict or {}, source record)."""
+    path = os.path.join(ROOT, "profiles", name)
+    src = {"file": "profiles/" + name, "kernel_sources_sha16_now": kernel_sources_sha16()}
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except OSError:
+        return {}, dict(src, stale="summary file not found")
+    meta = data.pop("_meta", {})
+    src.update(kernel_sources_sha16_at_collection=meta.get("kernel_sources_sha16"), git_head_at_collection=meta.get("git_head"))
+    if meta.get("kernel_sources_sha16") != src["kernel_sources_sha16_now"]:
+        return {}, dict(src, stale="the kernels' sources have changed since the counters were collected: traffic withheld")
+    return data, dict(src, stale=False)
+
+
 def synth_rays(n, seed, device):
     """Cameras on the NeRF-Synthetic hemisphere (radius 4.0311) looking at the scene."""
     g = torch.Generator().manual_seed(seed)
@@ -202,12 +235,7 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
     }
     # measured HBM bytes per launch from the committed rocprofv3 --pmc summary of `bench.py --workload instant`
     # (tools/pmc_r03.sh: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes); multi-kernel entries sum
-    pmc = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_instant_pmc_summary.json")) as f:
-            pmc = json.load(f)
-    except OSError:
-        pass
+    pmc, pmc_src = pmc_summary("r04_instant_pmc_summary.json")
 
     def traffic(*names):
         vals = [pmc.get(nm, {}).get("hbm_bytes_per_launch_corrected") for nm in names]
@@ -242,7 +270,7 @@ def bench_instant(args, device, iters=1000, size=800, n_train=30, standalone=Fal
         "config": {"workload": "Part 2 Instant-NGP (L16 F2 T2^19 hash grid + tiny MLPs, 128^3 occupancy grid), steady-state train step",
                    "rays_per_gpu": batch, "samples_per_ray": S, "active_ratio": active,
                    "scene": f"analytic scene, {n_train} training frames of {size}x{size} rendered on the GPU ({t_gen:.1f} s, not timed)"},
-        "kernels": {kk: {"ms": v} for kk, v in k.items()}, "active_samples": n, "rooflines": roof,
+        "kernels": {kk: {"ms": v} for kk, v in k.items()}, "active_samples": n, "rooflines": roof, "traffic_source": pmc_src,
         "render_fps": 1.0 / rt, "render_ms_per_frame": rt * 1e3, "render_ms_per_frame_max": max(frame_s) * 1e3, "psnr_curve": curve,
         "reference_headline": "26+ dB in 5 min, 10+ FPS (RTX 4060 Laptop, Lego; README.md:12,136)"}
     if standalone:
@@ -306,12 +334,7 @@ def bench_part4(args, device, steps=200):
         "tv + clip + adamw (28.5 M parameters)": event_ms(eng.apply_gradients, 20),
     }
     n_par = eng.tables.numel() + eng.net.numel()
-    pmc = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_part4_pmc_summary.json")) as f:
-            pmc = json.load(f)
-    except OSError:
-        pass
+    pmc, pmc_src = pmc_summary("r04_part4_pmc_summary.json")
 
     def traffic(names):
         # kernels launched at several sizes per step (four grids, three optimiser groups): mean bytes per launch x launches per step
@@ -342,7 +365,7 @@ def bench_part4(args, device, steps=200):
             "config": {"workload": "Part 4 dual-hash dynamic field train step (configs/part4.yaml.example), DualHashEngine", "rays_per_gpu": R,
                        "samples_per_ray": S, "active_samples": n, "parameters": n_par,
                        "regulariser_probes": "every 16th / 32nd step, through the same kernels"},
-            "kernels": {kk: {"ms": v} for kk, v in k.items()}, "rooflines": roof,
+            "kernels": {kk: {"ms": v} for kk, v in k.items()}, "rooflines": roof, "traffic_source": pmc_src,
             "step_roofline": {"bound": "hbm", "achieved": step_bytes / (dt / steps) * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": step_bytes / (dt / steps) * 1e-9 / HBM_PEAK_GBS, "work_per_step": step_bytes},
             "round2_module_path_ms_per_step": 9.39}
@@ -631,12 +654,8 @@ def main():
         # ---- rooflines: algorithmic work per launch / launch time.  `achieved` and `frac` come from the IN-STEP time
         # (what the rocprofv3 averages of profiles/ reproduce); the back-to-back figure is kept beside it.  PMC traffic
         # from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE doubled, separate passes).
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
-                pmc = json.load(f)
-        except OSError:
-            pass
+        pmc, pmc_src = pmc_summary("r04_pmc_summary.json")
+        out["traffic_source"] = pmc_src
         traffic = lambda name: (pmc.get(name, {}).get("hbm_bytes_per_launch_corrected") if (R, S) == (4096, 64) else None)
 
         def mfma_roof(kernel, phase, iso, work):
@@ -724,7 +743,7 @@ def main():
         try:                      # the side blocks must never cost the run its headline line
             inst = bench_instant(args, device)
             out["instant"] = {key: inst[key] for key in ("value", "unit", "ms_per_step", "render_fps", "render_ms_per_frame", "psnr_curve",
-                                                         "kernels", "rooflines", "active_samples", "config", "reference_headline")}
+                                                         "kernels", "rooflines", "traffic_source", "active_samples", "config", "reference_headline")}
         except Exception as e:    # noqa: BLE001
             out["instant"] = {"error": f"{type(e).__name__}: {e}"}
 

@@ -36,7 +36,11 @@ extern "C" {
 /* 2 (round 2 -> 3): nerf_tv_normsq gained `grad_scale`, the training images of the decoder changed format (see
  * nerf_mlp_fwd).  A host built against another version must refuse to run: compare nerf_abi_version() with the
  * NERF_ABI_VERSION it was compiled against (project-nerf_amd/_lib.py does; INTEGRATION.md shows the check). */
-#define NERF_ABI_VERSION 2
+/* 3 (round 3 -> 4): the squared-norm scalar of nerf_tv_normsq* became a workspace of NERF_NORMSQ_WS_FLOATS floats (the sum over
+ * workgroups is taken in workgroup order: the same bits on every run and every data-parallel replica);
+ * nerf_composite_mse_bwd / nerf_composite_mse_reg_bwd gained `sum_ws`; the imlp / Part 4 workspaces grew (partial tiles);
+ * option "deterministic" and nerf_sample_compact_ordered are new. */
+#define NERF_ABI_VERSION 3
 
 typedef void* nerf_stream_t;
 
@@ -47,8 +51,21 @@ int nerf_abi_version(void);
  * environment ONCE per process (NERF_CHAIN_LEGACY, NERF_FWD_CYCLES, NERF_WGRAD_OVH,
  * NERF_WGRAD_DEBUG, NERF_WGRAD_ONLY, NERF_HASH_BWD_ONLY_LEVEL, NERF_STASH_FP8); afterwards they
  * change only through nerf_set_option.  Names: "chain_legacy", "fwd_cycles", "wgrad_overhead",
- * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "wgrad_atomic", "wgrad_k16", "wgrad_big_only", "stash_fp8", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed", "chain_grid", "wgrad_grid", "hash_fwd_lds_kb".  No hot-path launch reads the
- * environment. */
+ * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "wgrad_atomic", "wgrad_k16", "wgrad_big_only", "stash_fp8", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed", "chain_grid", "wgrad_grid", "hash_fwd_lds_kb",
+ * "hash_xcd", "composite_wgs_per_cu", "deterministic".  No hot-path launch reads the environment.
+ *
+ * "deterministic" (NERF_DETERMINISTIC; default 0).  The reference's gradients are plain sums (loss.backward(), run.py:1941-1944);
+ * several kernels here take such sums in an order that depends on scheduling (float atomics, slots reserved with returning
+ * atomics).  With the option on, every such sum has a fixed order and two runs of the same step produce the same bits:
+ *   - compaction: use nerf_sample_compact_ordered (slots in sample order) instead of nerf_sample_compact*;
+ *   - nerf_imlp_bwd / nerf_p4_canon_bwd / nerf_p4_deform_bwd: weight gradients through partial tiles summed in workgroup order
+ *     (inside the workspace), the displacement-scale gradient through an ordered sum;
+ *   - nerf_hash_encode_bwd_ws*: no bin is cut into several work items (nothing is flushed with float atomics); the forms without a
+ *     workspace return NERF_EINVAL;
+ *   - nerf_hash_encode_bwd_input*: point on the thread, levels summed in order;
+ *   - nerf_composite_mse*_bwd: pass `sum_ws` (the loss and regulariser sums; they do not enter the gradients).
+ * Always ordered, option or not: the vanilla decoder's weight gradients, nerf_tv_normsq*.  Costs 0.1-0.3 ms per Instant / Part 4
+ * step (profiles/). */
 int nerf_set_option(const char* name, int value);
 int nerf_get_option(const char* name, int* value_out);
 
@@ -139,6 +156,17 @@ int nerf_sample_compact_jitter_shard(const float* rays_o, const float* rays_d, u
                                      const uint8_t* binary_grid, int resolution, float bound, float* z_out,
                                      int* slot_of_sample, float* pts_compact, float* dirs_compact,
                                      unsigned* active_count, nerf_stream_t stream);
+
+/* the same compaction with the slots in SAMPLE ORDER (option "deterministic": the single-pass kernels reserve slots with a returning
+ * atomic per 4096 samples, so the order of the compact arrays -- and with it the order of every later sum over samples -- depends
+ * on scheduling).  u != NULL: jitter from u [R,S]; u NULL and draw != 0: drawn as nerf_sample_compact_jitter_shard does from
+ * (seed, counter, first_ray); else the plain depths.  scratch: nerf_sample_compact_ordered_scratch_bytes(n_rays, n_samples) bytes, 4-byte aligned.  Three launches. */
+size_t nerf_sample_compact_ordered_scratch_bytes(int64_t n_rays, int n_samples);
+int nerf_sample_compact_ordered(const float* rays_o, const float* rays_d, const float* u, int draw, uint64_t seed, uint64_t counter,
+                                int64_t first_ray, int64_t n_rays, int n_samples, float near_plane, float far_plane,
+                                const uint8_t* binary_grid, int resolution, float bound, float* z_out, int* slot_of_sample,
+                                float* pts_compact, float* dirs_compact, unsigned* active_count, void* scratch,
+                                size_t scratch_bytes, nerf_stream_t stream);
 
 /* ---- hierarchical (inverse-CDF) fine sampling, opt-in extension --------------------
  * No reference counterpart (the reference has one stratified pass only); follows Mildenhall et al.
@@ -440,11 +468,14 @@ int nerf_render_rays_fwd(const void* packed, const float* rays_o, const float* r
  * loss_weight = 1 / (3 n_rays) gives the reference's mean.  slot_of_sample NULL: dense [R,S] inputs;
  * otherwise compact inputs as in nerf_composite_fwd_indexed.  loss_accum (device fp32) is ADDED to;
  * amax_accum (optional device fp32, max-accumulated; caller zeroes both) receives the vanilla decoder's
- * largest output-layer derivative for nerf_mlp_bwd_dgrad_ex.  pred_out [R,3] optional. */
+ * largest output-layer derivative for nerf_mlp_bwd_dgrad_ex.  pred_out [R,3] optional.
+ * sum_ws: NULL (one float atomic per workgroup into loss_accum / reg_accum) or NERF_SUM_WS_FLOATS floats of scratch: the
+ * workgroups' partial sums are then added in workgroup order (the same bits every run). */
+#define NERF_SUM_WS_FLOATS 8200
 int nerf_composite_mse_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
                            const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
                            float loss_weight, int64_t n_rays, int n_samples, float* pred_out, float* loss_accum,
-                           float* d_rgb, float* d_sigma, float* amax_accum, nerf_stream_t stream);
+                           float* d_rgb, float* d_sigma, float* amax_accum, float* sum_ws, nerf_stream_t stream);
 /* ... with the displacement regulariser of the dynamic fields (Part 3 / 4): `extra` [n,3] (compact, like rgb) is
  * composited with the same weights into extra_map [R,3] (optional) = render_rays' extras['mean_delta_x']
  * (src/renderer.py:363-380), reg_accum += reg_weight * sum_rays |mean_delta_x|^2 (run.py:1838 with reg_weight =
@@ -453,7 +484,7 @@ int nerf_composite_mse_reg_bwd(const float* rgb, const float* sigma, const int* 
                                const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
                                float loss_weight, const float* extra, float reg_weight, int64_t n_rays, int n_samples,
                                float* pred_out, float* extra_map, float* loss_accum, float* reg_accum, float* d_rgb,
-                               float* d_sigma, float* d_extra, nerf_stream_t stream);
+                               float* d_sigma, float* d_extra, float* sum_ws, nerf_stream_t stream);
 
 /* ---- a14: optimiser ---------------------------------------------------------
  * replaces torch.optim.Adam / AdamW .step() (run.py:307,338; run.py:546,629) for
@@ -470,14 +501,18 @@ int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  *   nerf_tv_normsq      : grads = grads * grad_scale + tv_weight * d/dp mean|p[1:] - p[:-1]|  (tv_weight 0:
  *                         no TV term; grad_scale = 1/world after a summing all-reduce: it scales the data
  *                         gradient only, the regulariser is a function of the replicated parameters),
- *                         then *normsq_dev = sum(grads^2)                  (device fp32 scalar)
+ *                         then normsq_dev[0] = sum(grads^2).  normsq_dev: NERF_NORMSQ_WS_FLOATS device floats -- [0] the
+ *                         squared norm, [1] a ticket, [2..] one partial per workgroup: the partials are added in workgroup
+ *                         order by the last workgroup to finish, so every run and every data-parallel replica (identical
+ *                         gradients after the all-reduce) gets the same bits, hence the same clip coefficient
  *   nerf_adamw_clip_step: AdamW with grads scaled by grad_scale * min(1, max_norm / (norm + 1e-6)),
- *                         norm = grad_scale * sqrt(*normsq_dev); normsq_dev NULL or max_norm <= 0: no clip. */
+ *                         norm = grad_scale * sqrt(normsq_dev[0]); normsq_dev NULL or max_norm <= 0: no clip. */
+#define NERF_NORMSQ_WS_FLOATS 1032
 int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
                    float* normsq_dev, nerf_stream_t stream);
-/* the same pass WITHOUT zeroing normsq_dev first: several parameter groups accumulate ONE global squared norm
- * (torch.nn.utils.clip_grad_norm_(model.parameters()) of the Part 3 / 4 loops, run.py:1172, 1943); the caller
- * zeroes the scalar once per step and hands it to every group's nerf_adamw_clip_step */
+/* the same pass WITHOUT zeroing normsq_dev[0..1] first: several parameter groups accumulate ONE global squared norm
+ * (torch.nn.utils.clip_grad_norm_(model.parameters()) of the Part 3 / 4 loops, run.py:1172, 1943) in call order; the caller
+ * zeroes normsq_dev[0] and [1] once per step and hands the workspace to every group's nerf_adamw_clip_step */
 int nerf_tv_normsq_accum(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
                          float* normsq_dev, nerf_stream_t stream);
 /* the same pass over 1..4 equally long tables stored back to back (n elements in all; Part 4's three deformation grids in one

@@ -61,7 +61,7 @@ PROTOTYPES = {
     "nerf_mlp_bwd_wgrad": (i32, [c_ptr, c_ptr, i64, c_ptr, c_ptr]),
     "nerf_mlp_bwd_dgrad_ex": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_composite_mse_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, f32, i64, i32, c_ptr, c_ptr,
-                                     c_ptr, c_ptr, c_ptr, c_ptr]),
+                                     c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_mlp_wgrad_part_split": (i64, []),
     "nerf_mlp_bwd_wgrad_part": (i32, [c_ptr, c_ptr, i64, c_ptr, i32, c_ptr]),
     "nerf_hash_encode_fwd": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -94,7 +94,10 @@ PROTOTYPES = {
     "nerf_tv_normsq_accum": (i32, [c_ptr, c_ptr, i64, f32, f32, c_ptr, c_ptr]),
     "nerf_tv_normsq_accum_tables": (i32, [c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, c_ptr]),
     "nerf_composite_mse_reg_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, f32, c_ptr, f32, i64, i32, c_ptr, c_ptr,
-                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+                                         c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_sample_compact_ordered_scratch_bytes": (size_t, [i64, i32]),
+    "nerf_sample_compact_ordered": (i32, [c_ptr, c_ptr, c_ptr, i32, ctypes.c_uint64, ctypes.c_uint64, i64, i64, i32, f32, f32, c_ptr, i32, f32,
+                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, size_t, c_ptr]),
     "nerf_p4_param_count": (i64, []),
     "nerf_p4_packed_bytes": (size_t, []),
     "nerf_p4_workspace_bytes": (size_t, [i64]),
@@ -109,7 +112,7 @@ PROTOTYPES = {
     "nerf_adamw_clip_step_shadow": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, c_ptr]),
 }
 
-ABI_VERSION = 2      # the NERF_ABI_VERSION of include/nerf_hip.h this table was written against
+ABI_VERSION = 3      # the NERF_ABI_VERSION of include/nerf_hip.h this table was written against
 
 _lib = None
 
@@ -138,6 +141,10 @@ def load():
                            f"{ABI_VERSION} (rebuild with `python project-nerf_amd/build.py`)")
     _lib = lib
     return lib
+
+
+NORMSQ_WS_FLOATS = 1032     # NERF_NORMSQ_WS_FLOATS
+SUM_WS_FLOATS = 8200        # NERF_SUM_WS_FLOATS
 
 
 def set_option(name: str, value: int) -> None:

@@ -40,6 +40,7 @@ static const OptionSlot kSlots[] = {
     {"hash_fwd_lds_kb", "NERF_HASH_FWD_LDS_KB", &Options::hash_fwd_lds_kb},
     {"hash_xcd", "NERF_HASH_XCD", &Options::hash_xcd},
     {"composite_wgs_per_cu", "NERF_COMPOSITE_WGS", &Options::composite_wgs_per_cu},
+    {"deterministic", "NERF_DETERMINISTIC", &Options::deterministic},
 };
 
 Options& options() {

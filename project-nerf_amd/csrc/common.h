@@ -45,6 +45,10 @@ struct Options {
                                  // maximum), which retire one after the other in L2: 8 per CU 58 us, 4: 35, 2: 27, 1: 29 (8192 rays x 64, Part 4 step)
   int hash_xcd = 1;              // 1: hash-grid gather kernels launch XCD-aware (levels x and x + 8 on XCD x); 0: level-major 2-D launch (A/B)
   int hash_fwd_lds_kb = 36;      // dynamic LDS per hash-forward workgroup (occupancy throttle, see nerf_hash_encode_fwd); 0: none
+  int deterministic = 0;         // 1: every sum whose order depends on scheduling takes an ordered form -- compaction slots in sample order,
+                                 // tiny-MLP weight gradients through partial tiles, hash bins never cut, d x from the hash grid level by level,
+                                 // scalar sums (loss, regulariser, displacement-scale gradient) per workgroup and in workgroup order: two runs
+                                 // of the same step give the same bits (reference semantics: a plain sum, run.py:1941-1944)
 };
 Options& options();
 
@@ -159,6 +163,38 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
+}
+
+// ---- ordered sum of V values per workgroup of a 1-D launch (instead of V same-address float atomics per workgroup) ----
+// Every workgroup publishes its values (thread 0 passes them) and takes a ticket; the workgroup that draws the last
+// ticket adds all partials IN WORKGROUP ORDER and accumulates the totals into *out[v] (null: skipped) -- the same bits
+// whatever the order the workgroups finished in.  ws: 1 + V * gridDim.x words, ws[0] (the ticket) zero before the first
+// launch; the last workgroup leaves it zero again.  Every access to ws is a returning device-scope atomic (coherent
+// across the XCDs' L2s without a cache write-back); the ticket is taken only after the partials' atomics have returned.
+// Called by all threads of the workgroup (blockDim.x >= 64).
+constexpr int kOrderedSumMaxBlocks = 4096;
+inline size_t ordered_sum_ws_words(int n_values) { return 1 + (size_t)n_values * kOrderedSumMaxBlocks; }
+template <int V>
+__device__ __forceinline__ void ordered_block_sum(const float (&val)[V], float* const (&out)[V], unsigned* ws) {
+  __shared__ unsigned last_block;
+  const unsigned B = gridDim.x;
+  if (threadIdx.x == 0) {
+    unsigned seen = 0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) seen |= atomicExch(&ws[1 + v * B + blockIdx.x], __float_as_uint(val[v]));
+    asm volatile("" ::"v"(seen) : "memory");      // the exchanges have returned: the partials sit at their coherent home
+    last_block = atomicAdd(&ws[0], 1u) == B - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last_block == 0u || threadIdx.x >= 64) return;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    float s = 0.0f;
+    for (unsigned b = threadIdx.x; b < B; b += 64) s += __uint_as_float(atomicOr(&ws[1 + v * B + b], 0u));
+    s = wave_sum(s);
+    if (threadIdx.x == 0 && out[v] != nullptr) *out[v] += s;
+  }
+  if (threadIdx.x == 0) atomicExch(&ws[0], 0u);
 }
 
 }  // namespace nerf

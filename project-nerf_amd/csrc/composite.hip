@@ -231,7 +231,7 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
                          float* __restrict__ pred_out, float* __restrict__ loss_out, float* __restrict__ d_rgb,
                          float* __restrict__ d_sigma, float* __restrict__ amax_out,
                          const float* __restrict__ extra, float reg_weight, float* __restrict__ d_extra,
-                         float* __restrict__ reg_out, float* __restrict__ extra_map) {
+                         float* __restrict__ reg_out, float* __restrict__ extra_map, unsigned* __restrict__ sum_ws) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int64_t nwave = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -334,9 +334,16 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
   if (lane == 0) { part[threadIdx.x >> 6] = loss_local; part[4 + (threadIdx.x >> 6)] = amax; part[8 + (threadIdx.x >> 6)] = reg_local; }
   __syncthreads();
+  if (sum_ws != nullptr) {                 // the workgroups' partial sums added in workgroup order (the same bits every run)
+    const float val[2] = {(part[0] + part[1]) + (part[2] + part[3]), (part[8] + part[9]) + (part[10] + part[11])};
+    float* const out[2] = {loss_out, reg_out};
+    ordered_block_sum<2>(val, out, sum_ws);
+  }
   if (threadIdx.x == 0) {
-    atomicAdd(loss_out, (part[0] + part[1]) + (part[2] + part[3]));
-    if (reg_out != nullptr) atomicAdd(reg_out, (part[8] + part[9]) + (part[10] + part[11]));
+    if (sum_ws == nullptr) {
+      atomicAdd(loss_out, (part[0] + part[1]) + (part[2] + part[3]));
+      if (reg_out != nullptr) atomicAdd(reg_out, (part[8] + part[9]) + (part[10] + part[11]));
+    }
     if (amax_out != nullptr) {
       const float m = fmaxf(fmaxf(part[4], part[5]), fmaxf(part[6], part[7]));
       if (m == m && m < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, m));
@@ -444,21 +451,37 @@ extern "C" int nerf_composite_bwd_indexed(const float* rgb_compact, const float*
                             slot_of_sample, n_rays, n_samples, d_rgb_compact, d_sigma_compact, nullptr, stream);
 }
 
+// workgroups of the fused compositing + loss backward: composite_wgs_per_cu per CU of THIS device (at least one)
+static int64_t mse_blocks(int64_t n_rays) {
+  int n_cu = 256;
+  (void)device_cu_count(&n_cu);
+  const int per_cu = options().composite_wgs_per_cu < 1 ? 1 : options().composite_wgs_per_cu;
+  int64_t cap = (int64_t)n_cu * per_cu;
+  if (cap > kOrderedSumMaxBlocks) cap = kOrderedSumMaxBlocks;
+  const int64_t blocks = (n_rays + 3) / 4;
+  return blocks < cap ? blocks : cap;
+}
+static int prepare_sum_ws(float* sum_ws, nerf_stream_t stream) {
+  static_assert(NERF_SUM_WS_FLOATS >= 1 + 2 * kOrderedSumMaxBlocks, "two partials per workgroup");
+  if (sum_ws != nullptr && hipMemsetAsync(sum_ws, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
+    return fail(NERF_ELAUNCH, "nerf_composite_mse_bwd: memset failed");
+  return NERF_OK;
+}
+
 extern "C" int nerf_composite_mse_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
                                       const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
                                       float loss_weight, int64_t n_rays, int n_samples, float* pred_out, float* loss_accum,
-                                      float* d_rgb, float* d_sigma, float* amax_accum, nerf_stream_t stream) {
+                                      float* d_rgb, float* d_sigma, float* amax_accum, float* sum_ws, nerf_stream_t stream) {
   NERF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 64 * kMaxPerLane,
                "nerf_composite_mse_bwd: n_rays=%lld n_samples=%d (max %d)", (long long)n_rays, n_samples, 64 * kMaxPerLane);
   if (n_rays == 0) return NERF_OK;
   NERF_REQUIRE(rgb && sigma && z && rays_d && target && loss_accum && d_rgb && d_sigma, "nerf_composite_mse_bwd: NULL pointer");
   NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_mse_bwd: bg_rows=%lld", (long long)bg_rows);
-  int64_t blocks = (n_rays + 3) / 4;
-  if (blocks > 256 * (int64_t)options().composite_wgs_per_cu) blocks = 256 * (int64_t)options().composite_wgs_per_cu;
-  const dim3 grid((int)blocks);
+  const dim3 grid((unsigned)mse_blocks(n_rays));
+  if (int rc = prepare_sum_ws(sum_ws, stream); rc != NERF_OK) return rc;
   DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
              slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, amax_accum,
-             (const float*)nullptr, 0.0f, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+             (const float*)nullptr, 0.0f, (float*)nullptr, (float*)nullptr, (float*)nullptr, reinterpret_cast<unsigned*>(sum_ws));
   return check_launch("nerf_composite_mse_bwd");
 }
 
@@ -466,18 +489,17 @@ extern "C" int nerf_composite_mse_reg_bwd(const float* rgb, const float* sigma, 
                                           const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
                                           float loss_weight, const float* extra, float reg_weight, int64_t n_rays, int n_samples,
                                           float* pred_out, float* extra_map, float* loss_accum, float* reg_accum, float* d_rgb,
-                                          float* d_sigma, float* d_extra, nerf_stream_t stream) {
+                                          float* d_sigma, float* d_extra, float* sum_ws, nerf_stream_t stream) {
   NERF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 64 * kMaxPerLane,
                "nerf_composite_mse_reg_bwd: n_rays=%lld n_samples=%d (max %d)", (long long)n_rays, n_samples, 64 * kMaxPerLane);
   if (n_rays == 0) return NERF_OK;
   NERF_REQUIRE(rgb && sigma && z && rays_d && target && loss_accum && d_rgb && d_sigma && extra && d_extra && reg_accum,
                "nerf_composite_mse_reg_bwd: NULL pointer");
   NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_mse_reg_bwd: bg_rows=%lld", (long long)bg_rows);
-  int64_t blocks = (n_rays + 3) / 4;
-  if (blocks > 256 * (int64_t)options().composite_wgs_per_cu) blocks = 256 * (int64_t)options().composite_wgs_per_cu;
-  const dim3 grid((int)blocks);
+  const dim3 grid((unsigned)mse_blocks(n_rays));
+  if (int rc = prepare_sum_ws(sum_ws, stream); rc != NERF_OK) return rc;
   DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
              slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, (float*)nullptr, extra, reg_weight, d_extra,
-             reg_accum, extra_map);
+             reg_accum, extra_map, reinterpret_cast<unsigned*>(sum_ws));
   return check_launch("nerf_composite_mse_reg_bwd");
 }

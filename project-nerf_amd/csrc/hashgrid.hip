@@ -265,6 +265,52 @@ hash_bwd_input_kernel(const float* __restrict__ pts, int64_t n, const TableT* __
   }
 }
 
+// Option "deterministic": the same gradient with the POINT on the thread, the levels walked in order and summed in registers --
+// one store per coordinate instead of one float atomic per level (whose order across levels depends on scheduling).
+template <class TableT>
+__global__ void __launch_bounds__(256)
+hash_bwd_input_ordered_kernel(const float* __restrict__ pts, int64_t n, const TableT* __restrict__ table, HashLevels L,
+                              const float* __restrict__ d_feat, float* __restrict__ d_pts) {
+  const float two_b = 2.0f * L.bound;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+    const float px = pts[p * 3 + 0], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
+    const float x01[3] = {add_rn(px, L.bound) / two_b, add_rn(py, L.bound) / two_b, add_rn(pz, L.bound) / two_b};
+    float sum[3] = {0.0f, 0.0f, 0.0f};
+    for (int lvl = 0; lvl < L.n_levels; ++lvl) {
+      const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0], g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1];
+      if (g0 == 0.0f && g1 == 0.0f) continue;
+      const Corner c = corners_of(L, lvl, px, py, pz);
+      float frac[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float cl = fminf(fmaxf(x01[a], 0.0f), 1.0f);
+        const float pos = add_rn(mul_rn(cl, L.scale[lvl]), 0.5f);
+        frac[a] = sub_rn(pos, floorf(pos));
+      }
+      float d[3] = {0.0f, 0.0f, 0.0f};
+      float2 tv[8];
+      gather_cell(table, c, tv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float2 v = tv[k];
+        const float gv = g0 * v.x + g1 * v.y;
+        const float wx = (k & 1) ? frac[0] : 1.0f - frac[0], wy = (k & 2) ? frac[1] : 1.0f - frac[1], wz = (k & 4) ? frac[2] : 1.0f - frac[2];
+        d[0] += gv * ((k & 1) ? 1.0f : -1.0f) * wy * wz;
+        d[1] += gv * ((k & 2) ? 1.0f : -1.0f) * wx * wz;
+        d[2] += gv * ((k & 4) ? 1.0f : -1.0f) * wx * wy;
+      }
+      const float s = L.scale[lvl] / two_b;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) sum[a] += d[a] * s;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const bool inside = x01[a] >= 0.0f && x01[a] <= 1.0f;          // torch.clamp passes the gradient on its closed interval
+      d_pts[p * 3 + a] = inside ? sum[a] : 0.0f;
+    }
+  }
+}
+
 constexpr int kLdsEntries = 16384;      // 128 KiB of float2
 template <bool in_lds>
 __global__ void __launch_bounds__(512)
@@ -538,7 +584,9 @@ __device__ __forceinline__ int fixed_shift(unsigned amax_bits) {
 // one workgroup of 1024: bins in rounds of 1024 with a carried total
 __global__ void __launch_bounds__(1024)
 hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ count, unsigned* __restrict__ cursor,
-                     BinItem* __restrict__ items, BinHeader* __restrict__ header, int overwrite) {
+                     BinItem* __restrict__ items, BinHeader* __restrict__ header, int overwrite, unsigned chunk) {
+  // chunk: records per work item -- kChunk, or 0xffffffff (option "deterministic"): a bin is never cut, so no slice is
+  // flushed with float atomics; the coarse dense levels' bins then serialise on one workgroup each
   __shared__ unsigned scan_r[1024], scan_i[1024], wave_r[16], wave_i[16];
   __shared__ unsigned carry_r, carry_i;
   const unsigned n_bins = plan.bin0[plan.count];
@@ -548,7 +596,7 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
     const unsigned b = base + threadIdx.x;
     const unsigned c = b < n_bins ? count[b] : 0u;
     // overwrite form: every bin gets an item (an empty bin's item stores a slice of zeros)
-    const unsigned it = (b < n_bins && overwrite && c == 0) ? 1u : (c + kChunk - 1) / kChunk;
+    const unsigned it = c == 0 ? ((b < n_bins && overwrite) ? 1u : 0u) : (unsigned)(((unsigned long long)c + chunk - 1) / chunk);
     // inclusive scan of both columns: within the wave by shuffles, the sixteen wave totals through LDS (two barriers per round
     // instead of twenty: the launch sits alone on the pass's critical path)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -577,8 +625,8 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
       for (unsigned j = 0; j < it; ++j) {
         BinItem item;
         item.entry0 = entry0;
-        item.begin = r0 + j * kChunk;
-        item.end = r0 + min(c, (j + 1) * kChunk);
+        item.begin = r0 + j * chunk;
+        item.end = r0 + (unsigned)min((unsigned long long)c, (unsigned long long)(j + 1) * chunk);
         item.atomic = (it > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) | (L.dense[lvl] ? kItemRuns : 0u);
         items[i0 + j] = item;
       }
@@ -605,7 +653,7 @@ __global__ void __launch_bounds__(512, 8)
 hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
                         unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header,
                         const float2* __restrict__ grad_lm, const unsigned* __restrict__ count, float* __restrict__ zero_table,
-                        int all_live) {
+                        int all_live, unsigned chunk) {
   constexpr unsigned kBins = STAGED ? kStagedBins : kMaxSlices;
   __shared__ unsigned cnt[kBins], base[kBins];
   __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
@@ -621,7 +669,7 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
     // overwrite form: a bin that was cut into several items is flushed with atomics by the reduce pass (a later launch),
     // so its slice is zeroed here -- the coarse dense levels in steady state, 1.8 MB of a 52 MB table
     for (unsigned b = blockIdx.x; b < bins; b += gridDim.x) {
-      if (count[plan.bin0[blockIdx.y] + b] <= kChunk) continue;
+      if (count[plan.bin0[blockIdx.y] + b] <= chunk) continue;
       const unsigned first = b << kSliceLog2, live = min(kSlice, L.size[lvl] - first);
       float2* dst = reinterpret_cast<float2*>(zero_table) + (size_t)tbl * plan.table_stride + offset + first;
       for (unsigned i = threadIdx.x; i < live; i += blockDim.x) dst[i] = make_float2(0.0f, 0.0f);
@@ -996,23 +1044,27 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
         hipLaunchKernelGGL(hash_bin_count_kernel, dim3((int)bx_count, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan, d_feat,
                            w.count, w.header);
       const float2* grad_lm = point_major ? w.grad_lm : nullptr;
+      const unsigned chunk = options().deterministic ? 0xffffffffu : kChunk;
       hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header,
-                         overwrite ? 1 : 0);
+                         overwrite ? 1 : 0, chunk);
       float* zero_table = overwrite ? d_table : nullptr;
       bool any_staged = false, any_direct = false;
       for (int i = 0; i < plan.count; ++i) (plan.bin0[i + 1] - plan.bin0[i] <= kStagedBins ? any_staged : any_direct) = true;
       if (any_staged)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted ? 1 : 0);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted ? 1 : 0, chunk);
       if (any_direct)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted ? 1 : 0);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted ? 1 : 0, chunk);
       size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
       if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
       hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,
                          d_table, table_entries);
     }
   }
+  if (options().deterministic && !binned && level0 < level1)
+    return fail(NERF_EINVAL, "nerf_hash_encode_bwd: option \"deterministic\" needs the workspace form (nerf_hash_encode_bwd_ws*) -- the "
+                             "other forms end in float atomics");
   if (precounted && !binned)
     return fail(NERF_EINVAL, "nerf_hash_encode_bwd_ws_store_precounted: the binned form is not available for this table shape / option set");
   if (overwrite && !binned && level0 < level1) {
@@ -1149,15 +1201,16 @@ extern "C" int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n,
   const int per_row = pm_levels_per_row(n, plan.count);
   hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm, (plan.count + per_row - 1) / per_row), dim3(256), 0, as_stream(stream), pts, n,
                      L, plan, d_feat, w.count, w.header, w.grad_lm, per_row);
-  hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header, 1);
+  const unsigned chunk = options().deterministic ? 0xffffffffu : kChunk;
+  hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header, 1, chunk);
   int64_t bx = (n + 511) / 512;
   const int64_t bx_scatter = bx > 128 ? 128 : bx;
   if (any_staged)
     hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
-                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0);
+                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0, chunk);
   if (any_direct)
     hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
-                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0);
+                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0, chunk);
   size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records, d_table,
@@ -1185,10 +1238,19 @@ static int hash_bwd_input_impl(const float* pts, int64_t n, const float* table, 
   HashLevels L;
   int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
   if (rc != NERF_OK) return rc;
-  if (hipMemsetAsync(d_pts, 0, sizeof(float) * 3 * (size_t)n, as_stream(stream)) != hipSuccess)
-    return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_input: memset failed");
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  if (options().deterministic) {          // levels summed in order per point: no float atomics
+    if (table_f16 != nullptr)
+      hipLaunchKernelGGL(hash_bwd_input_ordered_kernel<half2_t>, dim3((int)blocks), dim3(256), 0, as_stream(stream), pts, n,
+                         static_cast<const half2_t*>(table_f16), L, d_feat, d_pts);
+    else
+      hipLaunchKernelGGL(hash_bwd_input_ordered_kernel<float2>, dim3((int)blocks), dim3(256), 0, as_stream(stream), pts, n,
+                         reinterpret_cast<const float2*>(table), L, d_feat, d_pts);
+    return check_launch("nerf_hash_encode_bwd_input (ordered)");
+  }
+  if (hipMemsetAsync(d_pts, 0, sizeof(float) * 3 * (size_t)n, as_stream(stream)) != hipSuccess)
+    return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_input: memset failed");
   const bool xcd = options().hash_xcd != 0;
   const dim3 grid = level_chunk_grid(n_levels, blocks, xcd);
   if (table_f16 != nullptr)

@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(kIThreads) imlp_bwd_kernel(const IArgs a) {
 
 struct ILayout {
   int64_t n_pad;
-  size_t hash_nat, hs1, h16, denc, hc1, hc2, mask, dzs1, dzs2, dzc1, dzc2, dsmall, total;
+  size_t hash_nat, hs1, h16, denc, hc1, hc2, mask, dzs1, dzs2, dzc1, dzc2, dsmall, slab, total;
 };
 static ILayout ilayout(int64_t n) {
   ILayout s{};
@@ -275,6 +275,8 @@ static ILayout ilayout(int64_t n) {
   s.dzc1 = o; o += np * 64 * 2;
   s.dzc2 = o; o += np * 64 * 2;
   s.dsmall = o; o += np * 16 * 2;
+  o = (o + 255) / 256 * 256;
+  s.slab = o; o += kSmallSlabBytes;          // partial tiles of the weight-gradient launch (option "deterministic")
   s.total = (o + 255) / 256 * 256;
   return s;
 }
@@ -396,5 +398,7 @@ static int imlp_bwd_impl(const void* packed, void* workspace, const float* rgb, 
   { WgradJob j = job(l.dzc2, 4096, 2, l.hc1, 2, 0, 0, 7); j.w_off = kCW2; j.w_ld = 64; j.o_valid = 64; j.acc_valid = 64; wa.jobs[3] = j; }
   { WgradJob j = job(l.dsmall, 1024, 1, l.hc2, 2, 0, 0, 9); j.a_nat = 1; j.split_n = 1; j.w_off = kCW3; j.w_ld = 64; j.o_valid = 3; j.acc_valid = 64; wa.jobs[4] = j; }
   wa.n_jobs = 5;
+  if (options().deterministic)      // partial tiles summed in workgroup order instead of one float atomic per weight and workgroup
+    return wgrad_launch(wa, n, grads_f32, as_stream(stream), reinterpret_cast<float*>(static_cast<char*>(workspace) + l.slab), kSmallSlabBytes);
   return wgrad_launch(wa, n, grads_f32, as_stream(stream));
 }

@@ -13,6 +13,9 @@ constexpr int kWgStageBytes = kWgStageA + kWgStageB + kWgStageN;   // 36 KiB
 constexpr int kWgLds = kWgStages * kWgStageBytes;                 // 144 KiB
 constexpr int kWgScratch = 256;                                    // behind the ring: cross-wave sums at the end of a span
 constexpr int kMaxTiles = 10;                                      // n-tiles a wave accumulates
+// option "deterministic": partial tiles of the tiny-MLP weight-gradient launches (at most one workgroup per CU then:
+// (256 + kMaxJobs) tiles of at most 6208 floats), part of the imlp / Part 4 workspaces
+constexpr size_t kSmallSlabBytes = 8u << 20;
 
 struct WgradJob {
   const char* a;        // A image
@@ -50,6 +53,7 @@ struct WgradArgs {
   long long total_cost;
   float* grads;
   float* slab;          // non-null: partial tiles go here with plain stores, wgrad_reduce_kernel sums them
+  int slab_accumulate;  // reduce pass: 1 grads += sum of the tiles (tiny-MLP launches), 0 grads = sum
   const float* amax;    // non-null: 8-bit images; *amax = the dgrad launch's largest output-layer derivative
   int k16;              // 1: four 32x32x16 MFMAs per stage instead of one 32x32x64 (8-bit images; A/B)
   int debug;            // development aid (NERF_WGRAD_DEBUG): bit0 skip MFMA/LDS reads, bit1 skip DMA, bit2 skip flush

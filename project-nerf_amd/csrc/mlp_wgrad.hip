@@ -748,10 +748,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgradArgs args)
     }
     for (; t < job.n_parts; ++t) s0 += tile[(long long)t * job.p_stride + i];
     const float sum = (s0 + s1) + (s2 + s3);
-    if (i < n_w) args.grads[job.w_off + i] = sum;
-    else if (i < n_b) args.grads[job.bias_off + (i - n_w)] = sum;
-    else if (i < n_all - 1) args.grads[job.w2_off + (i - n_b)] = sum;      // merged job: second output behind the bias sums
-    else args.grads[job.bias2_off] = sum;
+    // which parameter this element of the tile is; the tiny-MLP launches ADD (one writer per parameter: the same bits every run)
+    float* dst = i < n_w ? args.grads + job.w_off + i
+               : i < n_b ? ((job.ones || job.bias_nat_col >= 0) ? args.grads + job.bias_off + (i - n_w) : nullptr)   // bias-free jobs: no such row
+               : i < n_all - 1 ? args.grads + job.w2_off + (i - n_b)             // merged job: second output behind the bias sums
+                               : args.grads + job.bias2_off;
+    if (dst != nullptr) *dst = args.slab_accumulate ? *dst + sum : sum;
   }
 }
 
@@ -893,11 +895,29 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
   const bool fp8 = args.amax != nullptr;
   if (int rc = ensure_dynamic_lds(fp8 ? (const void*)mlp_wgrad_kernel<true> : (const void*)mlp_wgrad_kernel<false>, kWgLds + kWgScratch,
                                   "nerf_mlp_bwd (wgrad)"); rc != NERF_OK) return rc;
+  // the tiny-MLP jobs (kinds >= 6: Instant, Part 4) run on the small-stage kernel, several workgroups per CU
+  bool small = args.amax == nullptr && !options().wgrad_big_only, p4 = false;
+  for (int j = 0; j < args.n_jobs; ++j) {
+    const WgradJob& jb = args.jobs[j];
+    p4 = p4 || (jb.kind >= 10 && jb.kind <= 12);
+    small = small && jb.kind >= 6 && jb.a_bytes <= SmallStage::A && jb.b_acc_bytes <= SmallStage::B && jb.b_nat_bytes <= SmallStageP4::N;
+  }
+  if (p4 && !small) return fail(NERF_EINVAL, "wgrad: Part 4 job kinds run on the small-stage kernel only");
   long long want = (long long)args.wave_tiles * nj / 4;   // at least ~4 wave tiles per span
   if (options().wgrad_grid > 0 && options().wgrad_grid < n_cu) n_cu = options().wgrad_grid;
   int grid = (int)(want < 1 ? 1 : (want > n_cu ? n_cu : want));
+  if (small) {
+    // every workgroup ends its span with one float atomic per weight of the job: short spans on many workgroups turn the
+    // launch into an atomic storm on a few thousand addresses (54 k samples on 768 workgroups: 47 us, most of it the flush)
+    const long long span = options().wgrad_small_span > 0 ? options().wgrad_small_span : 4;
+    // (partial tiles -- option "deterministic" -- one workgroup per CU: the tiles fit kSmallSlabBytes)
+    const long long cap = (long long)(slab != nullptr ? 1 : (options().wgrad_small_cap > 0 ? options().wgrad_small_cap : 3)) * n_cu;
+    const long long want3 = (long long)args.wave_tiles * nj / span;
+    grid = (int)(want3 < 1 ? 1 : (want3 > cap ? cap : want3));
+  }
   // slab mode: which workgroups hold a partial tile of which job -- the kernel's own span arithmetic, replayed
   args.slab = nullptr;
+  args.slab_accumulate = small ? 1 : 0;       // the tiny-MLP launches ADD to grads (several passes share one gradient vector)
   if (slab != nullptr && args.n_jobs > 0 && args.total_cost > 0) {
     bool ok = true;
     long long off = 0;
@@ -923,26 +943,23 @@ int nerf::wgrad_launch(WgradArgs& args, int64_t n, float* grads, hipStream_t str
       off += (long long)count * jb.p_stride;
     }
     if (ok && (size_t)off * sizeof(float) <= slab_bytes) args.slab = slab;
+    // the tiny jobs leave their matrices' pad columns unwritten (the atomic flush never touches them): zero tiles first
+    if (args.slab != nullptr && small && hipMemsetAsync(slab, 0, (size_t)off * sizeof(float), stream) != hipSuccess)
+      return fail(NERF_ELAUNCH, "tiny-MLP wgrad: memset failed");
+    if (args.slab == nullptr && small) return fail(NERF_EINVAL, "tiny-MLP wgrad (option \"deterministic\"): partial tiles need %zu bytes, %zu given%s",
+                                (size_t)off * sizeof(float), slab_bytes, ok ? "" : " (a job's workgroups are not contiguous)");
   }
   if (args.slab == nullptr && zero_hi > zero_lo &&
       hipMemsetAsync(grads + zero_lo, 0, sizeof(float) * (zero_hi - zero_lo), stream) != hipSuccess)
     return fail(NERF_ELAUNCH, "nerf_mlp_bwd: memset failed");
-  bool small = args.amax == nullptr && args.slab == nullptr && !options().wgrad_big_only, p4 = false;
-  for (int j = 0; j < args.n_jobs; ++j) {
-    const WgradJob& jb = args.jobs[j];
-    p4 = p4 || (jb.kind >= 10 && jb.kind <= 12);
-    small = small && jb.kind >= 6 && jb.a_bytes <= SmallStage::A && jb.b_acc_bytes <= SmallStage::B && jb.b_nat_bytes <= SmallStageP4::N;
-  }
-  if (p4 && !small) return fail(NERF_EINVAL, "wgrad: Part 4 job kinds run on the small-stage kernel only");
   if (small) {
-    // every workgroup ends its span with one float atomic per weight of the job: short spans on many workgroups turn the
-    // launch into an atomic storm on a few thousand addresses (54 k samples on 768 workgroups: 47 us, most of it the flush)
-    const long long span = options().wgrad_small_span > 0 ? options().wgrad_small_span : 4;
-    const long long cap = (long long)(options().wgrad_small_cap > 0 ? options().wgrad_small_cap : 3) * n_cu;
-    const long long want3 = (long long)args.wave_tiles * nj / span;
-    long long g3 = want3 < 1 ? 1 : (want3 > cap ? cap : want3);
-    if (p4) hipLaunchKernelGGL(mlp_wgrad_small_kernel<true>, dim3((int)g3), dim3(512), kWgStages * SmallStageP4::Bytes, stream, args);
-    else hipLaunchKernelGGL(mlp_wgrad_small_kernel<false>, dim3((int)g3), dim3(512), kWgStages * SmallStage::Bytes, stream, args);
+    if (p4) hipLaunchKernelGGL(mlp_wgrad_small_kernel<true>, dim3(grid), dim3(512), kWgStages * SmallStageP4::Bytes, stream, args);
+    else hipLaunchKernelGGL(mlp_wgrad_small_kernel<false>, dim3(grid), dim3(512), kWgStages * SmallStage::Bytes, stream, args);
+    if (args.slab != nullptr) {
+      if (int rc = check_launch("tiny-MLP wgrad"); rc != NERF_OK) return rc;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(16, args.n_jobs), dim3(256), 0, stream, args);
+      return check_launch("tiny-MLP wgrad (reduce)");
+    }
     return check_launch("tiny-MLP wgrad");
   }
   if (fp8) hipLaunchKernelGGL(mlp_wgrad_kernel<true>, dim3(grid), dim3(512), kWgLds + kWgScratch, stream, args);

@@ -241,6 +241,7 @@ struct DeformArgs {
   __bf16* dzt1; __bf16* dzt2; __bf16* dzd1; __bf16* dzd2; __bf16* dsmall;
   float* d_feat[3];        // [n,24] fp32 gradients for the three grids' scatter
   float* g_scale;          // parameter-gradient slot of displacement_scale (accumulated)
+  unsigned* sum_ws;        // non-null (option "deterministic"): workspace of common.h::ordered_block_sum for g_scale
 };
 
 __device__ __forceinline__ void triangle_weights(float t, float (&w)[3]) {
@@ -435,12 +436,16 @@ __global__ void __launch_bounds__(kThreads) deform_bwd_kernel(const DeformArgs a
   gscale_local = wave_sum(gscale_local);
   if (lane == 0) gscale_part[threadIdx.x >> 6] = gscale_local;
   __syncthreads();
+  float sum = 0.0f;
   if (threadIdx.x == 0) {
-    float sum = 0.0f;
 #pragma unroll
     for (int w = 0; w < kThreads / 64; ++w) sum += gscale_part[w];
-    if (sum != 0.0f) atomicAdd(a.g_scale, sum);
   }
+  if (a.sum_ws != nullptr) {               // option "deterministic": the workgroups' sums added in workgroup order
+    const float val[1] = {sum};
+    float* const out[1] = {a.g_scale};
+    ordered_block_sum<1>(val, out, a.sum_ws);
+  } else if (threadIdx.x == 0 && sum != 0.0f) atomicAdd(a.g_scale, sum);
 }
 
 // ------------------------------------------------------------------------------------------------ canonical chain
@@ -636,7 +641,7 @@ prep_kernel(const int* __restrict__ slots, const float* __restrict__ pts, const 
 struct Layout {
   int64_t n_pad;
   size_t feat[3], canon_nat, tc, ht1, tm, df, hd1, hd2, dmask, wts, raw, dzt1, dzt2, dzd1, dzd2, dsmall_d, dfeat[3];
-  size_t sin_nat, hs1, h16, denc, hc1, hc2, cmask, dzs1, dzs2, dzc1, dzc2, dsmall_c, dfeat_c, total;
+  size_t sin_nat, hs1, h16, denc, hc1, hc2, cmask, dzs1, dzs2, dzc1, dzc2, dsmall_c, dfeat_c, sum_ws, slab, total;
 };
 static Layout layout(int64_t n) {
   Layout s{};
@@ -656,6 +661,8 @@ static Layout layout(int64_t n) {
   s.hc1 = take(np * 64 * 2); s.hc2 = take(np * 64 * 2); s.cmask = take((np / kTile) * kThreads * 16);
   s.dzs1 = take(np * 64 * 2); s.dzs2 = take(np * 32 * 2); s.dzc1 = take(np * 64 * 2); s.dzc2 = take(np * 64 * 2);
   s.dsmall_c = take(np * 16 * 2); s.dfeat_c = take(np * 32 * 4);
+  // option "deterministic": ordered sum of the displacement-scale gradient, partial tiles of the weight-gradient launches
+  s.sum_ws = take(ordered_sum_ws_words(1) * sizeof(unsigned)); s.slab = take(kSmallSlabBytes);
   s.total = o;
   return s;
 }
@@ -734,7 +741,8 @@ extern "C" int nerf_p4_sample_inputs(const int* slot_of_sample, const float* pts
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(p4::prep_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), slot_of_sample, pts_compact, ray_times, total,
-                     n_samples, coord_noise_std, time_noise_std, squares_key(seed), counter,
+                     n_samples, coord_noise_std, time_noise_std, squares_key(seed ^ 0x6e6f697365ull), counter,   // its own stream: the depth jitter of
+                                                                                                     // nerf_sample_compact_jitter draws from squares_key(seed)
                      (uint64_t)first_ray * (uint64_t)(n_samples > 0 ? n_samples : 1), x_deform, t_deform);
   return check_launch("nerf_p4_sample_inputs");
 }
@@ -801,6 +809,8 @@ extern "C" int nerf_p4_canon_bwd(const void* packed, void* workspace, const floa
   { WgradJob j = make_job(w, l.dzc2, 4096, 2, l.hc1, 2, 0, 0, 7); j.w_off = kC2; j.w_ld = 64; j.o_valid = 64; j.acc_valid = 64; wa.jobs[3] = j; }
   { WgradJob j = make_job(w, l.dsmall_c, 1024, 1, l.hc2, 2, 0, 0, 9); j.a_nat = 1; j.split_n = 1; j.w_off = kC3; j.w_ld = 64; j.o_valid = 3; j.acc_valid = 64; wa.jobs[4] = j; }
   wa.n_jobs = 5;
+  if (options().deterministic)
+    return wgrad_launch(wa, n, grads_f32, as_stream(stream), reinterpret_cast<float*>(const_cast<char*>(w) + l.slab), kSmallSlabBytes);
   return wgrad_launch(wa, n, grads_f32, as_stream(stream));
 }
 
@@ -816,9 +826,15 @@ extern "C" int nerf_p4_deform_bwd(const void* packed, const float* params_f32, v
   a.d_dx = d_delta_x; a.g_scale = grads_f32 + kScale;
   const int grid = grid_for(a.n_pad / kTile);
   if (grid <= 0) return fail(NERF_ELAUNCH, "nerf_p4_deform_bwd: cannot query device");
+  const bool det = options().deterministic != 0;
+  const Layout l = layout(n);
+  if (det) {
+    NERF_REQUIRE(grid <= kOrderedSumMaxBlocks, "nerf_p4_deform_bwd: %d workgroups (ordered sum: at most %d)", grid, kOrderedSumMaxBlocks);
+    a.sum_ws = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + l.sum_ws);
+    if (hipMemsetAsync(a.sum_ws, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) return fail(NERF_ELAUNCH, "nerf_p4_deform_bwd: memset failed");
+  }
   hipLaunchKernelGGL(p4::deform_bwd_kernel, dim3(grid), dim3(kThreads), kDeformBwdN * 1024, as_stream(stream), a);
   if (int rc = check_launch("nerf_p4_deform_bwd (dgrad)"); rc != NERF_OK) return rc;
-  const Layout l = layout(n);
   const char* w = static_cast<const char*>(workspace);
   WgradArgs wa{};
   { WgradJob j = make_job(w, l.dzt1, 4096, 2, 0, 0, l.tc, 1, 6); j.w_off = kT1W; j.w_ld = 21; j.o_valid = 64; j.nat_valid = kTimeDim;
@@ -830,5 +846,6 @@ extern "C" int nerf_p4_deform_bwd(const void* packed, const float* params_f32, v
   { WgradJob j = make_job(w, l.dzd2, 4096, 2, l.hd1, 2, 0, 0, 7); j.w_off = kD2; j.w_ld = 64; j.o_valid = 64; j.acc_valid = 64; wa.jobs[3] = j; }
   { WgradJob j = make_job(w, l.dsmall_d, 1024, 1, l.hd2, 2, 0, 0, 9); j.a_nat = 1; j.split_n = 1; j.w_off = kD3; j.w_ld = 64; j.o_valid = 3; j.acc_valid = 64; wa.jobs[4] = j; }
   wa.n_jobs = 5;
+  if (det) return wgrad_launch(wa, n, grads_f32, as_stream(stream), reinterpret_cast<float*>(static_cast<char*>(workspace) + l.slab), kSmallSlabBytes);
   return wgrad_launch(wa, n, grads_f32, as_stream(stream));
 }

@@ -222,7 +222,7 @@ def run_dynamic(cfg, args):
         torch.save(save, os.path.join(log_dir, "best_model.pth"))
 
     best = 0.0
-    local = batch // world                                  # this rank's shard [lo, hi) of the step's global batch
+    local = parallel.check_global_batch(batch, world)       # this rank's shard [lo, hi) of the step's global batch
     lo = rank * local
     warm, stop, decay = cfg.get("grid_warmup_iters", 256), cfg.get("grid_stop_ratio", 0.9), cfg.get("grid_decay", 0.95)
     # random-background augmentation (run.py:1043-1044, 1771-1772): a fresh colour per step for target AND render
@@ -245,6 +245,10 @@ def run_dynamic(cfg, args):
         with torch.no_grad():
             eng.grid.copy_(grid.grid)
             eng.binary_grid.copy_(grid.binary_grid)
+        # replicas start from rank 0's values whatever the seeds did (then stay equal: identical all-reduced gradients, ONE
+        # squared norm summed in a fixed order, replicated occupancy-grid updates)
+        parallel.broadcast_([eng.tables, eng.net, eng.grid, eng.binary_grid])
+        eng.repack()
         sync_async = parallel.allreduce_sum_async if world > 1 else None
         pixels = train_set.H * train_set.W
 
@@ -286,9 +290,12 @@ def run_dynamic(cfg, args):
                 if v > best and main_rank:
                     best = v
                     save_best(step, best)
+        if world > 1:
+            say(f">>> replica divergence after {iters} steps: {parallel.replica_divergence([eng.tables, eng.net, eng.binary_grid]):.3e}")
         sync()
     elif not args.eval_only:
         # Part 3: one group (run.py:1016); Part 4: the reference's per-group learning rates (run.py:1684-1738)
+        parallel.broadcast_([p.data for p in model.parameters()] + ([grid.grid, grid.binary_grid] if grid is not None else []))
         opt = torch.optim.AdamW(model.parameters() if part3 else part4_param_groups(model, lr), lr=lr,
                                 weight_decay=cfg.get("weight_decay", 1e-5))
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=cfg.get("eta_min", 1e-4))

@@ -271,7 +271,7 @@ class InstantNgpEngine:
         self.grid = torch.zeros(res, res, res, device=self.device)
         self.binary_grid = torch.ones(res, res, res, dtype=torch.bool, device=self.device)
         self.step_count, self.world_size = 0, world_size
-        self._scratch = torch.empty(1, device=self.device)
+        self._scratch = ops.normsq_ws(self.device)
         self._loss_ring = torch.zeros(1024, device=self.device)
 
     def lr(self) -> float:

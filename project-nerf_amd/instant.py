@@ -108,7 +108,7 @@ def run_instant(cfg, args):
         eng = InstantNgpEngine({**cfg, "scene_bound": cfg.get("scene_bound", 1.5), "grid_threshold": grid.threshold,
                                 "grid_resolution": grid.resolution, "train_iters": iters, "learning_rate": lr}, device=str(device),
                                seed=int(cfg.get("seed", 0) or 0), world_size=world)
-        local = batch // world                               # this rank's shard [lo, hi) of the step's global batch
+        local = parallel.check_global_batch(batch, world)    # this rank's shard [lo, hi) of the step's global batch
         lo, hi = rank * local, (rank + 1) * local
         sync_async = parallel.allreduce_sum_async if world > 1 else None
         wire = torch.bfloat16 if (world > 1 and cfg.get("dp_gradient_wire", "bf16") == "bf16") else None
@@ -121,6 +121,10 @@ def run_instant(cfg, args):
             eng.packed = ops.imlp_pack(eng.net)
             eng.grid.copy_(grid.grid)
             eng.binary_grid.copy_(grid.binary_grid)
+        # replicas start from rank 0's values whatever the seeds did (then stay equal: identical all-reduced gradients, a
+        # squared norm summed in a fixed order, replicated occupancy-grid updates)
+        parallel.broadcast_([eng.table, eng.net, eng.grid, eng.binary_grid])
+        eng.packed = ops.imlp_pack(eng.net)
 
         def sync():
             with torch.no_grad():
@@ -163,8 +167,11 @@ def run_instant(cfg, args):
                     best = v
                     torch.save({"model_state_dict": model.state_dict(), "config": cfg, "step": step, "val_psnr": best,
                                 "density_grid": grid.state_dict()}, os.path.join(log_dir, "best_model.pth"))
+        if world > 1:
+            say(f">>> replica divergence after {iters} steps: {parallel.replica_divergence([eng.table, eng.net, eng.binary_grid]):.3e}")
         sync()
     elif not args.eval_only:
+        parallel.broadcast_([p.data for p in model.parameters()] + ([grid.grid, grid.binary_grid] if grid is not None else []))
         opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=cfg.get("weight_decay", 1e-5))
         sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=cfg.get("eta_min", 1e-4))
         use_tv, tv_w = cfg.get("use_tv_loss", True), float(cfg.get("tv_loss_weight", 1e-6))
@@ -173,7 +180,7 @@ def run_instant(cfg, args):
         val_idx = random.sample(range(len(test_set)), n_val)
         active = 1.0
         model.train()
-        local = batch // world
+        local = parallel.check_global_batch(batch, world)
         for step in range(1, iters + 1):
             o, d, rgba = train_set.sample_random_rays(local * world, device)       # same draw on every rank, own shard kept
             o, d, rgba = (t[rank * local:(rank + 1) * local].contiguous() for t in (o, d, rgba))

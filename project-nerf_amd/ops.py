@@ -126,6 +126,63 @@ def train_batch(images: Tensor, poses: Tensor, focal: float, batch: int, n_sampl
     return o, d, (target if bg is not None else rgba), z
 
 
+# --------------------------------------------------------------------------- deterministic mode
+_DETERMINISTIC = None
+_SUM_WS = {}
+
+
+def set_deterministic(on: bool = True) -> None:
+    """Library option "deterministic" (include/nerf_hip.h): every sum whose order would depend on scheduling takes an
+    ordered form, so two runs of the same training step give the same bits (YAML key ``deterministic: true`` in run.py;
+    environment NERF_DETERMINISTIC=1).  The wrappers below route compaction through nerf_sample_compact_ordered, give the
+    hash scatter a workspace and the fused compositing kernels their ordered-sum scratch."""
+    global _DETERMINISTIC
+    _lib.set_option("deterministic", 1 if on else 0)
+    _DETERMINISTIC = bool(on)
+
+
+def deterministic() -> bool:
+    global _DETERMINISTIC
+    if _DETERMINISTIC is None:
+        _DETERMINISTIC = bool(_lib.get_option("deterministic"))
+    return _DETERMINISTIC
+
+
+def sum_ws(device) -> Optional[Tensor]:
+    """scratch of the ordered loss / regulariser sums of nerf_composite_mse*_bwd (None unless deterministic); one per
+    device: launches that share it must be stream-ordered"""
+    if not deterministic():
+        return None
+    key = torch.device(device)
+    if key not in _SUM_WS:
+        _SUM_WS[key] = torch.zeros(_lib.SUM_WS_FLOATS, device=key)
+    return _SUM_WS[key]
+
+
+def normsq_ws(device) -> Tensor:
+    """workspace of nerf_tv_normsq*: [0] the squared norm, [1] ticket, [2:] one partial per workgroup"""
+    return torch.zeros(_lib.NORMSQ_WS_FLOATS, device=device)
+
+
+def _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, count):
+    """the compaction launch of sample_compact / sample_compact_async: ordered slots when deterministic"""
+    draw = u is None and jitter is not None
+    seed, counter = (int(jitter[0]), int(jitter[1]) & 0xFFFFFF) if draw else (0, 0)
+    if deterministic():
+        scratch = torch.empty(max(lib.nerf_sample_compact_ordered_scratch_bytes(R, n_samples), 4), dtype=torch.uint8, device=rays_o.device)
+        _lib.check(lib.nerf_sample_compact_ordered(_p(rays_o), _p(rays_d), _p(u), 1 if draw else 0, seed, counter, int(first_ray), R, n_samples,
+                                                   near, far, _p(grid), grid.shape[0], float(bound), _p(z), _p(slots), _p(pts), _p(dirs),
+                                                   _p(count), _p(scratch), scratch.numel(), _stream()), "nerf_sample_compact_ordered")
+    elif draw:
+        _lib.check(lib.nerf_sample_compact_jitter_shard(_p(rays_o), _p(rays_d), seed, counter, int(first_ray), R, n_samples, near, far,
+                                                        _p(grid), grid.shape[0], float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count),
+                                                        _stream()), "nerf_sample_compact_jitter")
+    else:
+        _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
+                                           float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),
+                   "nerf_sample_compact")
+
+
 # --------------------------------------------------------------------------- a1-a4 fused
 def sample_compact(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_samples: int,
                    binary_grid: Tensor, bound: float, u: Optional[Tensor] = None):
@@ -144,9 +201,7 @@ def sample_compact(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_sa
     pts = torch.empty(max(n, 1), 3, device=rays_o.device)
     dirs = torch.empty(max(n, 1), 3, device=rays_o.device)
     count = torch.zeros(1, device=rays_o.device, dtype=torch.int32)
-    _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
-                                       float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),
-               "nerf_sample_compact")
+    _compact_launch(lib, rays_o, rays_d, u, None, 0, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, count)
     n_act = int(count.item())
     return z, slots, pts[:n_act], dirs[:n_act]
 
@@ -185,14 +240,7 @@ def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float
     slots = torch.empty(n, device=dev, dtype=torch.int32)
     pts, dirs = torch.empty(max(n, 1), 3, device=dev), torch.empty(max(n, 1), 3, device=dev)
     count = torch.empty(1, device=dev, dtype=torch.int32)          # zeroed by the library call itself
-    if u is None and jitter is not None:
-        _lib.check(lib.nerf_sample_compact_jitter_shard(_p(rays_o), _p(rays_d), int(jitter[0]), int(jitter[1]) & 0xFFFFFF, int(first_ray),
-                                                        R, n_samples, near, far, _p(grid), grid.shape[0], float(bound), _p(z), _p(slots),
-                                                        _p(pts), _p(dirs), _p(count), _stream()), "nerf_sample_compact_jitter")
-    else:
-        _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
-                                           float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),
-                   "nerf_sample_compact")
+    _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, count)
     count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     count_host.copy_(count, non_blocking=True)
     event = torch.cuda.Event()
@@ -346,7 +394,7 @@ def composite_mse_bwd(rgb: Tensor, sigma: Tensor, z: Tensor, rays_d: Tensor, bg:
     pred = torch.empty(R, 3, device=z.device) if want_pred else None
     w = 1.0 / (3 * R) if loss_weight is None else loss_weight
     _lib.check(lib.nerf_composite_mse_bwd(_p(rgb), _p(sigma), _p(slots), _p(z), _p(rays_d), _p(bg), bg_rows, _p(target), w, R, S,
-                                          _p(pred), _p(loss_accum), _p(d_rgb), _p(d_sigma), _p(amax_accum), _stream()),
+                                          _p(pred), _p(loss_accum), _p(d_rgb), _p(d_sigma), _p(amax_accum), _p(sum_ws(z.device)), _stream()),
                "nerf_composite_mse_bwd")
     return d_rgb, d_sigma, pred
 
@@ -674,6 +722,8 @@ def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: T
     lo, hi = level_range if level_range is not None else (0, levels.n_levels)
     if overwrite and workspace is None:
         raise ValueError("hash_encode_bwd: overwrite needs the workspace form")
+    if workspace is None and deterministic():
+        workspace = _hash_bwd_scratch(pts, levels)           # the forms without a workspace end in float atomics
     if workspace is None:
         _lib.check(lib.nerf_hash_encode_bwd_levels(_p(pts), pts.shape[0], levels.n_levels, *levels.host_args(), float(bound),
                                                    _p(d_feat), _p(d_table), lo, hi, _stream()), "nerf_hash_encode_bwd")
@@ -880,7 +930,8 @@ def tv_clip_adamw_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_s
     for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         if _dev(t, nm) is not t:
             raise ValueError(f"{nm} must be contiguous")
-    normsq = scratch if scratch is not None else torch.empty(1, device=params.device)
+    # the squared-norm workspace (NERF_NORMSQ_WS_FLOATS: value, ticket, one partial per workgroup; zeroed by the call)
+    normsq = scratch if (scratch is not None and scratch.numel() >= _lib.NORMSQ_WS_FLOATS) else normsq_ws(params.device)
     _lib.check(lib.nerf_tv_normsq(_p(params), _p(grads), params.numel(), tv_weight, grad_scale, _p(normsq), _stream()),
                "nerf_tv_normsq")
     if shadow_f16 is not None:

@@ -53,18 +53,63 @@ def mean_over_ranks(value: torch.Tensor) -> torch.Tensor:
 
 
 def allreduce_mean_grads_(params) -> None:
-    """module path (torch.optim on nn.Parameters): one summing all-reduce of the flattened gradients, averaged"""
+    """module path (torch.optim on nn.Parameters): one summing all-reduce of the flattened gradients, averaged.  The flat
+    buffer covers EVERY parameter in the given order -- zeros where a rank has no gradient (a shard without active samples, a
+    branch unused on this step) -- so that all ranks issue a collective of the same length, and the result is written back
+    to every parameter so that all ranks step the same set."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if grads:
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= dist.get_world_size()
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    for p in params:
+        g = flat[off:off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+
+
+def broadcast_(tensors, src: int = 0) -> None:
+    """Start-up synchronisation of the replicas: every tensor (parameters, optimiser state, occupancy grid) takes rank
+    ``src``'s values.  Replicas that start equal and apply identical updates (the all-reduced gradient, a squared norm summed
+    in a fixed order) stay bit-equal; this makes the first condition hold whatever the seeds did."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    for t in tensors:
+        if t.dtype == torch.bool:                         # gloo / RCCL have no bool collectives
+            u = t.to(torch.uint8)
+            dist.broadcast(u, src=src)
+            t.copy_(u.to(torch.bool))
+        else:
+            dist.broadcast(t, src=src)
+
+
+def replica_divergence(tensors) -> float:
+    """largest |value on one rank - value on another| over the given replicated tensors (0.0: the replicas are bit-equal);
+    every rank must call it.  Two collectives (MAX, MIN) per tensor: an end-of-run check, not a per-step one."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return 0.0
+    worst = 0.0
+    for t in tensors:
+        hi = t.detach().to(torch.float32 if t.dtype in (torch.bool, torch.uint8, torch.float16) else t.dtype).clone()
+        lo = hi.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        worst = max(worst, float((hi - lo).abs().max()) if hi.numel() else 0.0)
+    return worst
+
+
+def check_global_batch(batch: int, world: int) -> int:
+    """rays per rank of a global batch; the split must be exact (a remainder would silently drop rays)"""
+    if batch % world:
+        raise ValueError(f"batch_size {batch} is not divisible by the {world} data-parallel ranks")
+    return batch // world
 
 
 def render_row_bands(render_fn, rays_o: torch.Tensor, rays_d: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:

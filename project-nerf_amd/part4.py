@@ -54,12 +54,20 @@ def _check_count():
 
 
 class Workspace:
-    """one allocation per point count: hash operand images, every training image, the d-feature arrays"""
+    """hash operand images, every training image, the d-feature arrays of ``n`` points (the kernels derive the layout from n);
+    ``buf``: a caller-owned buffer of at least ``Workspace.bytes(n)`` bytes to lay it out in (the engine's grow-only buffer)"""
 
-    def __init__(self, n: int, device):
+    @staticmethod
+    def bytes(n: int) -> int:
+        return max(_lib.load().nerf_p4_workspace_bytes(n), 256)
+
+    def __init__(self, n: int, device, buf: Optional[Tensor] = None):
         lib = _lib.load()
         self.n = n
-        self.buf = torch.empty(max(lib.nerf_p4_workspace_bytes(n), 256), dtype=torch.uint8, device=device)
+        need = Workspace.bytes(n)
+        if buf is not None and buf.numel() < need:
+            raise ValueError(f"Part 4 workspace: {need} bytes needed for {n} points, {buf.numel()} given")
+        self.buf = buf if buf is not None else torch.empty(need, dtype=torch.uint8, device=device)
         self._off = [lib.nerf_p4_workspace_offset(n, k) for k in range(8)]
 
     def nat(self, k: int) -> Tensor:                     # 0..2 deformation grids, 3 canonical
@@ -264,7 +272,8 @@ class DualHashEngine:
         self.binary_grid = torch.ones(res, res, res, dtype=torch.bool, device=self.device)
         self.step_count = 0
         self._scalars = self._g_net_scalars[N_PARAMS:]
-        self._ws: Dict[int, Workspace] = {}
+        self._normsq_ws = ops.normsq_ws(self.device)
+        self._ws: Dict[str, Tensor] = {}
         self._hash_ws = None
         self._hash_ws_tables = None
         self._counter = 0
@@ -304,15 +313,15 @@ class DualHashEngine:
         base = self.lr0 * mult
         return self.eta_min + (base - self.eta_min) * (1 + math.cos(math.pi * self.step_count / self.t_max)) / 2
 
-    def _workspace(self, n: int) -> Workspace:
-        key = (n + 127) // 128 * 128
-        ws = self._ws.get(key)
-        if ws is None:
-            if len(self._ws) > 8:
-                self._ws.clear()
-            ws = self._ws[key] = Workspace(key, self.device)
-        ws.n = n
-        return ws
+    def _workspace(self, n: int, which: str = "batch") -> Workspace:
+        """the step's workspace laid out in ONE grow-only buffer per use (data batch / regulariser probes): the active-point
+        count changes almost every step, a buffer per count would churn hundreds of MB through the allocator"""
+        need = Workspace.bytes(n)
+        buf = self._ws.get(which)
+        if buf is None or buf.numel() < need:
+            self._ws.pop(which, None)                        # release before growing
+            buf = self._ws[which] = torch.empty(int(need * 1.25), dtype=torch.uint8, device=self.device)
+        return Workspace(n, self.device, buf=buf)
 
     def _hash_scratch_tables(self, n: int, n_levels: int, n_tables: int) -> Tensor:
         need = _lib.load().nerf_hash_encode_bwd_tables_workspace_bytes(n, n_levels, n_tables)
@@ -363,7 +372,8 @@ class DualHashEngine:
             d_rgb, d_sigma, d_extra = torch.empty_like(rgb), torch.empty_like(sigma), torch.empty_like(dx)
             _lib.check(lib.nerf_composite_mse_reg_bwd(P(rgb), P(sigma), P(slots), P(z), P(rays_d), P(bg), 1, P(target), 1.0 / (3 * R),
                                                       P(dx), self.reg_weight / (3 * R), R, n_samples, None, None, P(loss), P(reg),
-                                                      P(d_rgb), P(d_sigma), P(d_extra), ops._stream()), "nerf_composite_mse_reg_bwd")
+                                                      P(d_rgb), P(d_sigma), P(d_extra), P(ops.sum_ws(self.device)), ops._stream()),
+                       "nerf_composite_mse_reg_bwd")
             g_tabs = [self.g_table(k) for k in range(4)]
             backward_chain(self.packed, self.net, self.table(3, half=True), self.levels_d, self.levels_c, self.bound, pts if x_def is None else x_def,
                            xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch, overwrite=True, tables_ws=self._hash_scratch_tables,
@@ -410,7 +420,7 @@ class DualHashEngine:
             return
         X, Tm, W = torch.cat(rows_x).contiguous(), torch.cat(rows_t).contiguous(), torch.cat(rows_w).contiguous()
         n = X.shape[0]
-        ws = Workspace(n, dev)
+        ws = self._workspace(n, "probes")
         _, _, dx, _ = forward_chain(self.packed, self.net, self._tables_for_forward(), self.levels_d, self.levels_c, self.bound,
                                     X, None, Tm, None, ws, True, blend=W)
         g = torch.zeros_like(dx)
@@ -440,8 +450,8 @@ class DualHashEngine:
         lib = _lib.load()
         st = ops._stream()
         scale = 1.0 / self.world_size
-        normsq = self._scalars[2:3]
-        normsq.zero_()
+        normsq = self._normsq_ws                 # [0] the squared norm of ALL groups, [1] ticket, [2:] partials (include/nerf_hip.h)
+        normsq[:2].zero_()
         # the three deformation grids (equal sizes, back to back in the flat buffer) in one launch, each with its own total variation
         n_def = self.table_sizes[0]
         _lib.check(lib.nerf_tv_normsq_accum_tables(P(self.table(0)), P(self.g_table(0)), 3 * n_def, 3, self.tv_disp, scale, P(normsq), st),

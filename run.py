@@ -66,7 +66,8 @@ def run_part2(cfg, args):
     if args.checkpoint:
         model.load_state_dict(torch.load(args.checkpoint, map_location=device)["model_state_dict"])
         say(f">>> Loaded checkpoint: {args.checkpoint}")
-    local_batch = batch_size // world                       # this rank's shard of the global batch
+    local_batch = parallel.check_global_batch(batch_size, world)   # this rank's shard of the global batch
+    parallel.broadcast_([p.data for p in model.parameters()])       # replicas start from rank 0's weights whatever the seeds did
     first_ray = rank * local_batch
     if world > 1:
         say(f">>> data parallel: {world} ranks x {local_batch} rays (global batch {local_batch * world}), RCCL all-reduce of the flat gradient")
@@ -243,7 +244,13 @@ def main():
         # so a data-parallel run is always seeded (`seed:` in the YAML, default 0)
         from project_nerf_amd import parallel
         parallel.init_distributed("cuda")
-        cfg.setdefault("seed", 0)
+        if cfg.get("seed") is None:          # also a YAML `seed: null`
+            cfg["seed"] = 0
+    if cfg.get("deterministic") or os.environ.get("NERF_DETERMINISTIC", "") not in ("", "0"):
+        # every sum whose order would depend on scheduling takes an ordered form: two runs of the same command give the same
+        # bits (include/nerf_hip.h, option "deterministic"; costs 0.1-0.3 ms per Instant / Part 4 step)
+        from project_nerf_amd import ops
+        ops.set_deterministic(True)
     if cfg.get("seed") is not None:        # extension: the reference seeds nothing; a YAML `seed` makes a run repeatable
         torch.manual_seed(int(cfg["seed"]))
         np.random.seed(int(cfg["seed"]))

@@ -457,12 +457,13 @@ def test_tv_normsq_over_tables_equals_one_call_per_table():
     g0 = torch.randn(n_tab * seg, generator=gen).cuda()
     st = torch.cuda.current_stream().cuda_stream
     one, many = g0.clone(), g0.clone()
-    nsq_one, nsq_many = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    from project_nerf_amd import ops
+    nsq_one, nsq_many = ops.normsq_ws("cuda"), ops.normsq_ws("cuda")        # [0] the squared norm, [1] ticket, [2:] partials
     _lib.check(lib.nerf_tv_normsq_accum_tables(P(p), P(one), n_tab * seg, n_tab, 0.37, 0.5, P(nsq_one), st), "tables")
     for k in range(n_tab):
         _lib.check(lib.nerf_tv_normsq_accum(P(p[k * seg:]), P(many[k * seg:]), seg, 0.37, 0.5, P(nsq_many), st), "single")
     assert torch.equal(one, many)
-    assert abs(float(nsq_one) - float(nsq_many)) <= 1e-5 * float(nsq_many)
+    assert abs(float(nsq_one[0]) - float(nsq_many[0])) <= 1e-5 * float(nsq_many[0])
     # and against the definition: d/dp of 0.37 * mean |p[1:] - p[:-1]| per table, on the halved data gradient
     ref = []
     for k in range(n_tab):

@@ -154,6 +154,28 @@ def _loop_helpers_worker(rank, world, port, out):
         ref.bias.zero_()
     ref(x).pow(2).mean().backward()
     ok = ok and torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-6) and torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-5, atol=1e-6)
+    # a parameter that has NO gradient on one rank (its shard has no active sample; a branch unused on this step): the flat
+    # buffer still covers every parameter -- same collective length on all ranks -- and every rank ends with the same gradient
+    two = torch.nn.ModuleList([torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)])
+    with torch.no_grad():
+        for k, m in enumerate(two):
+            m.weight.fill_(0.5 + k)
+            m.bias.zero_()
+    inp = torch.ones(4, 3)
+    (two[0](inp).sum() + (two[1](inp).sum() if rank == 0 else 0.0)).backward()
+    assert (two[1].weight.grad is None) == (rank != 0)
+    P.allreduce_mean_grads_(list(two.parameters()))
+    ok = ok and torch.allclose(two[0].weight.grad, torch.full((2, 3), 4.0)) and torch.allclose(two[1].weight.grad, torch.full((2, 3), 4.0 / world))
+    # start-up synchronisation: every replica takes rank 0's values (bool tensors: the occupancy grid)
+    t_f, t_b = torch.full((5,), float(rank + 7)), torch.tensor([rank == 0, True, rank != 0])
+    P.broadcast_([t_f, t_b])
+    ok = ok and bool((t_f == 7.0).all()) and t_b.tolist() == [True, True, False]
+    ok = ok and P.check_global_batch(4096, world) == 4096 // world
+    try:
+        P.check_global_batch(4097, 2)
+        ok = False
+    except ValueError:
+        pass
     # evaluation: row bands rendered per rank, gathered on rank 0 -- also when there are fewer rows than ranks would like
     for H in (13, 1):
         o = torch.arange(H * 4 * 3, dtype=torch.float32).view(H, 4, 3)

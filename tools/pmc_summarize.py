@@ -12,6 +12,7 @@ usage: python tools/pmc_summarize.py gpurun_out/pmc_r01 profiles/r01_pmc_summary
 """
 import collections
 import csv
+import os
 import json
 import re
 import statistics
@@ -91,9 +92,16 @@ def main(src, dst):
             e["mfma_busy_frac"] = s["SQ_VALU_MFMA_BUSY_CYCLES"] / (s["GRBM_GUI_ACTIVE"] / 8 * 1024)
             e["wait_any/wave_cycles"] = s["SQ_WAIT_ANY"] / max(s["SQ_WAVE_CYCLES"], 1.0)
         out[k] = e
+    # what the counters were taken on: bench.py refuses to quote them as `traffic` once the kernels' sources have changed
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import kernel_sources_sha16
+    out["_meta"] = {"kernel_sources_sha16": kernel_sources_sha16(), "git_head": os.environ.get("NERF_GIT_HEAD", "unknown"),
+                    "collected_by": "tools/pmc_summarize.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ passes (separate passes)"}
     with open(dst, "w") as fh:
         json.dump(out, fh, indent=1)
     for k, e in out.items():
+        if k == "_meta":
+            continue
         print(f"{k:28s} {e['hbm_bytes_per_launch_corrected'] / 1e6:10.1f} MB  mfma_busy {e.get('mfma_busy_frac', 0):.3f}")
 
 
