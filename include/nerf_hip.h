@@ -527,6 +527,25 @@ int nerf_adamw_clip_step_shadow(float* params, const float* grads, float* exp_av
                          int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                          const float* normsq_dev, float max_norm, float grad_scale, void* params_f16_out, nerf_stream_t stream);
 
+/* The same two passes WITHOUT rewriting the gradient (38.5 instead of 42 bytes per parameter; what the engines call):
+ *   nerf_tv_normsq_codes   : normsq_dev[0] += sum (grads * grad_scale + TV term)^2 over n_tables equally long tables stored back
+ *                            to back (accumulating form: zero normsq_dev[0..1] once per step); grads is NOT modified; tv_codes
+ *                            (nerf_tv_codes_bytes(n) bytes; may be NULL when tv_weight == 0) receives the two-bit signs
+ *                            1 + sign(p[i+1] - p[i]) the TV term is made of (0 across a table seam)
+ *   nerf_adamw_clip_step_tv: AdamW with (grads * grad_scale + TV term rebuilt from tv_codes) * min(1, max_norm / (sqrt(normsq_dev[0])
+ *                            + 1e-6)).  Elements [0, tv_split) carry TV weight tv_weight_lo over tables of seg_lo elements, the rest
+ *                            tv_weight_hi / seg_hi (Part 4: the three deformation grids | the canonical grid in ONE launch);
+ *                            elements from lr_split on (0: none) step with lr_hi (networks | displacement_scale);
+ *                            params_f16_out optional.  tv_codes NULL: no TV term. */
+size_t nerf_tv_codes_bytes(int64_t n);
+int nerf_tv_normsq_codes(const float* params, const float* grads, int64_t n, int n_tables, float tv_weight, float grad_scale,
+                         float* normsq_dev, void* tv_codes, nerf_stream_t stream);
+int nerf_adamw_clip_step_tv(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, const float* normsq_dev, float max_norm,
+                            float grad_scale, const void* tv_codes, int64_t tv_split, float tv_weight_lo, int64_t seg_lo,
+                            float tv_weight_hi, int64_t seg_hi, int64_t lr_split, float lr_hi, void* params_f16_out,
+                            nerf_stream_t stream);
+
 /* ---- f3: Part 4 dual-hash dynamic field (csrc/p4mlp.hip) ------------------------------------------------------
  * replaces, for NeuralField(mode part4).forward (src/core.py:282-352), the tinycudann FullyFusedMLP networks
  * HashDeformationDecoder.deform_net (src/decoders.py:285-295, 313-316) and InstantNeRFDecoder at pos_dim 32 + 21

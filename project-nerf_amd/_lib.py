@@ -108,6 +108,10 @@ PROTOTYPES = {
     "nerf_p4_canon_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
     "nerf_p4_canon_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
     "nerf_p4_deform_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
+    "nerf_tv_codes_bytes": (size_t, [i64]),
+    "nerf_tv_normsq_codes": (i32, [c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_adamw_clip_step_tv": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, i64, f32, i64,
+                                      f32, i64, i64, f32, c_ptr, c_ptr]),
     "nerf_adamw_clip_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr]),
     "nerf_adamw_clip_step_shadow": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, c_ptr]),
 }

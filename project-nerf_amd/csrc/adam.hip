@@ -163,6 +163,126 @@ adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __r
   adam_sweep<VEC>(p, g, m, v, n, gs, lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2, shadow);
 }
 
+// ---- the same two passes WITHOUT rewriting the gradient (38.5 instead of 42 bytes per parameter) --------------------------
+// pass 1 leaves, instead of g + TV term (4 bytes written, 4 read back), the SIGNS it is made of: code_i = 1 + sign(p[i+1] - p[i])
+// in two bits (0 behind the last element of a table), four elements per byte; the TV term of element i is
+// tv_scale * (s[i-1] - s[i]).  Pass 2 rebuilds g * grad_scale + TV term from the codes -- from the OLD parameters' signs, whatever
+// its neighbours have already written.
+__device__ __forceinline__ int tv_code_at(const uint8_t* __restrict__ codes, int64_t i) {
+  return i < 0 ? 0 : (int)((codes[i >> 2] >> (2 * (int)(i & 3))) & 3u) - 1;
+}
+
+__global__ void __launch_bounds__(256)
+tv_normsq_codes_kernel(const float* __restrict__ p, const float* __restrict__ g, int64_t n, float tv_scale, float grad_scale,
+                       float* __restrict__ normsq, int64_t seg, uint8_t* __restrict__ codes, int vec) {
+  // four consecutive elements (one code byte) per thread and round; seg: elements per table (no pair across a seam)
+  float local = 0.0f;
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = 4 * q;
+    float pp[6], gg[4];                        // pp[0] = p[e0-1] ... pp[5] = p[e0+4]
+    if (vec && e0 + 4 <= n) {
+      const f4 a = reinterpret_cast<const f4*>(p)[q], b = reinterpret_cast<const f4*>(g)[q];
+      pp[1] = a[0]; pp[2] = a[1]; pp[3] = a[2]; pp[4] = a[3];
+      gg[0] = b[0]; gg[1] = b[1]; gg[2] = b[2]; gg[3] = b[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pp[1 + e] = e0 + e < n ? p[e0 + e] : 0.0f; gg[e] = e0 + e < n ? g[e0 + e] : 0.0f; }
+    }
+    if (tv_scale != 0.0f) {
+      pp[0] = e0 > 0 ? p[e0 - 1] : 0.0f;
+      pp[5] = e0 + 4 < n ? p[e0 + 4] : 0.0f;
+      unsigned byte = 0;
+      int s_prev = (e0 > 0 && e0 % seg != 0) ? (int)sgn(pp[1] - pp[0]) : 0;      // s[e0-1]: 0 across a seam
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t i = e0 + e;
+        const int s_cur = (i + 1 < n && (i + 1) % seg != 0) ? (int)sgn(pp[2 + e] - pp[1 + e]) : 0;
+        if (i < n) {
+          const float gi = gg[e] * grad_scale + tv_scale * (float)(s_prev - s_cur);
+          local += gi * gi;
+          byte |= (unsigned)(s_cur + 1) << (2 * e);
+        }
+        s_prev = s_cur;
+      }
+      codes[q] = (uint8_t)byte;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float gi = gg[e] * grad_scale; local += gi * gi; }     // elements past n are zero
+    }
+  }
+  __shared__ float part[4];
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  const float val[1] = {(part[0] + part[1]) + (part[2] + part[3])};
+  float* const out[1] = {normsq};
+  ordered_block_sum<1>(val, out, reinterpret_cast<unsigned*>(normsq + 1));
+}
+
+__global__ void __launch_bounds__(256)
+adamw_clip_tv_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                     float lr, float beta1, float beta2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2,
+                     const float* __restrict__ normsq, float max_norm, float grad_scale, const uint8_t* __restrict__ codes,
+                     int64_t tv_split, float tv_scale_lo, float tv_scale_hi, _Float16* __restrict__ shadow, int vec,
+                     int64_t lr_split, float lr_hi) {
+  float clip = 1.0f;
+  if (normsq != nullptr && max_norm > 0.0f) {
+    const float coef = max_norm / (sqrtf(*normsq) + 1e-6f);       // torch clip_grad_norm_; normsq is of the scaled gradient + TV term
+    clip = coef < 1.0f ? coef : 1.0f;
+  }
+  const int64_t n4 = (n + 3) / 4;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e0 = 4 * q;
+    const bool whole = vec && e0 + 4 <= n;
+    float pp[4], gg[4], mm[4], vv[4];
+    if (whole) {
+      const f4 a = reinterpret_cast<const f4*>(p)[q], b = reinterpret_cast<const f4*>(g)[q], c = reinterpret_cast<const f4*>(m)[q],
+               d = reinterpret_cast<const f4*>(v)[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pp[e] = a[e]; gg[e] = b[e]; mm[e] = c[e]; vv[e] = d[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool in = e0 + e < n;
+        pp[e] = in ? p[e0 + e] : 0.0f; gg[e] = in ? g[e0 + e] : 0.0f; mm[e] = in ? m[e0 + e] : 0.0f; vv[e] = in ? v[e0 + e] : 0.0f;
+      }
+    }
+    int s_prev = 0;
+    unsigned byte = 0x55u;                       // all codes 1 = sign 0
+    if (codes != nullptr) {
+      byte = codes[q];
+      s_prev = q > 0 ? (int)(codes[q - 1] >> 6) - 1 : 0;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int s_cur = (int)((byte >> (2 * e)) & 3u) - 1;
+      const float tv_scale = e0 + e < tv_split ? tv_scale_lo : tv_scale_hi;
+      const float gi = (gg[e] * grad_scale + tv_scale * (float)(s_prev - s_cur)) * clip;
+      adam_update(pp[e], gi, mm[e], vv[e], e0 + e < lr_split ? lr : lr_hi, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+      s_prev = s_cur;
+    }
+    if (whole) {
+      f4 a = {pp[0], pp[1], pp[2], pp[3]}, c = {mm[0], mm[1], mm[2], mm[3]}, d = {vv[0], vv[1], vv[2], vv[3]};
+      reinterpret_cast<f4*>(m)[q] = c;
+      reinterpret_cast<f4*>(v)[q] = d;
+      reinterpret_cast<f4*>(p)[q] = a;
+      if (shadow != nullptr) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 hh = {(_Float16)pp[0], (_Float16)pp[1], (_Float16)pp[2], (_Float16)pp[3]};
+        reinterpret_cast<h4*>(shadow)[q] = hh;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e0 + e < n) {
+          p[e0 + e] = pp[e]; m[e0 + e] = mm[e]; v[e0 + e] = vv[e];
+          if (shadow != nullptr) shadow[e0 + e] = (_Float16)pp[e];
+        }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (_Float16)src[i];
 }
@@ -259,4 +379,44 @@ static int adamw_clip_impl(float* params, const float* grads, float* exp_avg, fl
                        exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1),
                        (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale, shadow);
   return nerf::check_launch("nerf_adamw_clip_step");
+}
+
+// ---- TV + norm and clip + AdamW without the gradient rewrite (see tv_normsq_codes_kernel) ----
+extern "C" size_t nerf_tv_codes_bytes(int64_t n) { return n > 0 ? (size_t)((n + 3) / 4) : 0; }
+
+extern "C" int nerf_tv_normsq_codes(const float* params, const float* grads, int64_t n, int n_tables, float tv_weight, float grad_scale,
+                                    float* normsq_dev, void* tv_codes, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && normsq_dev && n_tables >= 1 && n % n_tables == 0, "nerf_tv_normsq_codes: bad arguments");
+  if (n == 0) return NERF_OK;
+  const int64_t seg = n / n_tables;
+  NERF_REQUIRE(params && grads && (tv_weight == 0.0f || tv_codes), "nerf_tv_normsq_codes: NULL pointer");
+  const float tv_scale = seg > 1 ? tv_weight / (float)(seg - 1) : 0.0f;
+  int64_t blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  const int vec = (((uintptr_t)params | (uintptr_t)grads) & 15) == 0;
+  hipLaunchKernelGGL(nerf::tv_normsq_codes_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n, tv_scale,
+                     grad_scale, normsq_dev, seg, static_cast<uint8_t*>(tv_codes), vec);
+  return nerf::check_launch("nerf_tv_normsq_codes");
+}
+
+extern "C" int nerf_adamw_clip_step_tv(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
+                                       float beta1, float beta2, float eps, float weight_decay, const float* normsq_dev, float max_norm,
+                                       float grad_scale, const void* tv_codes, int64_t tv_split, float tv_weight_lo, int64_t seg_lo,
+                                       float tv_weight_hi, int64_t seg_hi, int64_t lr_split, float lr_hi, void* params_f16_out,
+                                       nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && step >= 1 && tv_split >= 0 && seg_lo >= 0 && seg_hi >= 0, "nerf_adamw_clip_step_tv: n=%lld step=%d", (long long)n, step);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq, "nerf_adamw_clip_step_tv: NULL pointer");
+  NERF_REQUIRE(params_f16_out == nullptr || ((uintptr_t)params_f16_out & 7) == 0, "nerf_adamw_clip_step_tv: params_f16_out unaligned");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float lo = (tv_codes && seg_lo > 1) ? tv_weight_lo / (float)(seg_lo - 1) : 0.0f;
+  const float hi = (tv_codes && seg_hi > 1) ? tv_weight_hi / (float)(seg_hi - 1) : 0.0f;
+  int64_t blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const int vec = nerf::aligned16(params, grads, exp_avg, exp_avg_sq);
+  hipLaunchKernelGGL(nerf::adamw_clip_tv_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, exp_avg, exp_avg_sq,
+                     n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale,
+                     static_cast<const uint8_t*>(tv_codes), tv_split, lo, hi, static_cast<_Float16*>(params_f16_out), vec,
+                     lr_split <= 0 ? n : lr_split, lr_hi);
+  return nerf::check_launch("nerf_adamw_clip_step_tv");
 }

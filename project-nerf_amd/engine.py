@@ -434,8 +434,10 @@ class InstantNgpEngine:
         lr = self.lr()
         self.step_count += 1
         scale = 1.0 / self.world_size
+        if getattr(self, "_tv_codes", None) is None:
+            self._tv_codes = torch.empty((self.table.numel() + 3) // 4, dtype=torch.uint8, device=self.device)
         ops.tv_clip_adamw_step(self.table, self.g_table, *self.state["table"], self.step_count, lr, tv_weight=self.tv_weight,
-                               max_norm=1.0, weight_decay=self.wd, grad_scale=scale, scratch=self._scratch,
+                               max_norm=1.0, weight_decay=self.wd, grad_scale=scale, scratch=self._scratch, tv_codes=self._tv_codes,
                                shadow_f16=self.table_h if self._table_version == self.table._version else None)
         ops.tv_clip_adamw_step(self.net, self.g_net, *self.state["net"], self.step_count, lr, max_norm=1.0,
                                weight_decay=self.wd, grad_scale=scale, scratch=self._scratch)

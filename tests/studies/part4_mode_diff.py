@@ -1,0 +1,49 @@
+"""Where do the ordered-sum and the default Part 4 steps part ways?  (GPU diagnostic; python tests/studies/part4_mode_diff.py)
+Same engine, batch and probes in both modes; after every step: relative difference of the gradients and of the parameters,
+per table and for the networks."""
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(HERE, ".."))
+import project_nerf_amd  # noqa: F401,E402
+from project_nerf_amd import ops  # noqa: E402
+from test_gpu_deterministic import _part4_engine, _probes, _rays  # noqa: E402
+
+
+def run(steps, det, probes_every):
+    ops.set_deterministic(det)
+    eng = _part4_engine()
+    R, S = 1024, 32
+    o, d, target, g = _rays(R, 6)
+    t = torch.rand(R, 1, generator=g).cuda()
+    out = []
+    for step in range(1, steps + 1):
+        loss = float(eng.compute_gradients(o, d, target, t, S, probes=_probes(step) if (probes_every and step % probes_every == 0) else None))
+        grads = [eng.g_table(k).clone() for k in range(4)] + [eng.g_net.clone()]
+        eng.apply_gradients()
+        params = [eng.table(k).clone() for k in range(4)] + [eng.net.clone()]
+        out.append((loss, grads, params, float(eng._normsq_ws[0])))
+    ops.set_deterministic(False)
+    return out
+
+
+def rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+if __name__ == "__main__":
+    names = ["deform0", "deform1", "deform2", "canonical", "networks"]
+    for probes_every in (0, 3):
+        a, b, c = run(6, True, probes_every), run(6, False, probes_every), run(6, False, probes_every)
+        print(f"--- probes every {probes_every} steps --- (ordered vs default | default vs default)")
+        for k, (x, y, z) in enumerate(zip(a, b, c), 1):
+            print(f"step {k}: loss {x[0]:.8f} / {y[0]:.8f} / {z[0]:.8f}   normsq {x[3]:.6e} / {y[3]:.6e} / {z[3]:.6e}")
+            print("   grads : " + "  ".join(f"{n} {rel(p, q):.1e}|{rel(r, q):.1e} (|g| {float(q.norm()):.2e})" for n, p, q, r in zip(names, x[1], y[1], z[1])))
+            print("   params: " + "  ".join(f"{n} {rel(p, q):.1e}|{rel(r, q):.1e}" for n, p, q, r in zip(names, x[2], y[2], z[2])))
+            diff = (x[2][3] - y[2][3]).abs()
+            print(f"   canonical table: {int((diff > 0).sum())} of {diff.numel()} entries differ, max |d| {float(diff.max()):.3e}, "
+                  f"entries with |d| > 1e-3: {int((diff > 1e-3).sum())}")
