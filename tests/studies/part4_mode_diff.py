@@ -14,7 +14,7 @@ from project_nerf_amd import ops  # noqa: E402
 from test_gpu_deterministic import _part4_engine, _probes, _rays  # noqa: E402
 
 
-def run(steps, det, probes_every):
+def run(steps, det, probes_every, noise_after_step1=0.0):
     ops.set_deterministic(det)
     eng = _part4_engine()
     R, S = 1024, 32
@@ -25,6 +25,14 @@ def run(steps, det, probes_every):
         loss = float(eng.compute_gradients(o, d, target, t, S, probes=_probes(step) if (probes_every and step % probes_every == 0) else None))
         grads = [eng.g_table(k).clone() for k in range(4)] + [eng.g_net.clone()]
         eng.apply_gradients()
+        if step == 1 and noise_after_step1 > 0.0:
+            # a relative perturbation of the size the default mode's float atomics leave after one step, applied to the fp32
+            # master copies of the three deformation grids (the forward reads their fp16 copies)
+            gen = torch.Generator(device="cuda").manual_seed(1234)
+            for k in range(3):
+                t = eng.table(k)
+                t.mul_(1.0 + noise_after_step1 * torch.randn(t.shape, device="cuda", generator=gen))
+            eng.repack()
         params = [eng.table(k).clone() for k in range(4)] + [eng.net.clone()]
         out.append((loss, grads, params, float(eng._normsq_ws[0])))
     ops.set_deterministic(False)
@@ -37,6 +45,15 @@ def rel(a, b):
 
 if __name__ == "__main__":
     names = ["deform0", "deform1", "deform2", "canonical", "networks"]
+    # the decisive comparison: ORDERED sums in both runs (bit-reproducible: no race, no summation-order noise), one of them with
+    # its deformation grids perturbed by 1e-5 relative after the first step -- what the default mode's runs differ by at that point
+    a, b, a2 = run(4, True, 0), run(4, True, 0, noise_after_step1=1e-5), run(4, True, 0)
+    assert all(torch.equal(p, q) for x, y in zip(a, a2) for p, q in zip(x[1] + x[2], y[1] + y[2])), "ordered runs differ"
+    print("--- ordered sums, deformation grids perturbed by 1e-5 (relative) after step 1 vs unperturbed ---")
+    for k, (x, y) in enumerate(zip(a, b), 1):
+        print(f"step {k}: loss {x[0]:.8f} / {y[0]:.8f}")
+        print("   grads : " + "  ".join(f"{n} {rel(p, q):.1e}" for n, p, q in zip(names, x[1], y[1])))
+        print("   params: " + "  ".join(f"{n} {rel(p, q):.1e}" for n, p, q in zip(names, x[2], y[2])))
     for probes_every in (0, 3):
         a, b, c = run(6, True, probes_every), run(6, False, probes_every), run(6, False, probes_every)
         print(f"--- probes every {probes_every} steps --- (ordered vs default | default vs default)")
