@@ -172,32 +172,27 @@ __device__ __forceinline__ int tv_code_at(const uint8_t* __restrict__ codes, int
   return i < 0 ? 0 : (int)((codes[i >> 2] >> (2 * (int)(i & 3))) & 3u) - 1;
 }
 
+// generic form (any alignment, any n): one chunk of four elements per thread and round
 __global__ void __launch_bounds__(256)
 tv_normsq_codes_kernel(const float* __restrict__ p, const float* __restrict__ g, int64_t n, float tv_scale, float grad_scale,
-                       float* __restrict__ normsq, int64_t seg, uint8_t* __restrict__ codes, int vec) {
-  // four consecutive elements (one code byte) per thread and round; seg: elements per table (no pair across a seam)
+                       float* __restrict__ normsq, int64_t seg, uint8_t* __restrict__ codes) {
+  auto starts = [seg](int64_t e) { return e == 0 || e == seg || e == 2 * seg || e == 3 * seg; };
   float local = 0.0f;
   const int64_t n4 = (n + 3) / 4;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e0 = 4 * q;
     float pp[6], gg[4];                        // pp[0] = p[e0-1] ... pp[5] = p[e0+4]
-    if (vec && e0 + 4 <= n) {
-      const f4 a = reinterpret_cast<const f4*>(p)[q], b = reinterpret_cast<const f4*>(g)[q];
-      pp[1] = a[0]; pp[2] = a[1]; pp[3] = a[2]; pp[4] = a[3];
-      gg[0] = b[0]; gg[1] = b[1]; gg[2] = b[2]; gg[3] = b[3];
-    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { pp[1 + e] = e0 + e < n ? p[e0 + e] : 0.0f; gg[e] = e0 + e < n ? g[e0 + e] : 0.0f; }
-    }
+    for (int e = 0; e < 4; ++e) { pp[1 + e] = e0 + e < n ? p[e0 + e] : 0.0f; gg[e] = e0 + e < n ? g[e0 + e] : 0.0f; }
     if (tv_scale != 0.0f) {
       pp[0] = e0 > 0 ? p[e0 - 1] : 0.0f;
       pp[5] = e0 + 4 < n ? p[e0 + 4] : 0.0f;
       unsigned byte = 0;
-      int s_prev = (e0 > 0 && e0 % seg != 0) ? (int)sgn(pp[1] - pp[0]) : 0;      // s[e0-1]: 0 across a seam
+      int s_prev = !starts(e0) ? (int)sgn(pp[1] - pp[0]) : 0;      // s[e0-1]: 0 across a seam
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int64_t i = e0 + e;
-        const int s_cur = (i + 1 < n && (i + 1) % seg != 0) ? (int)sgn(pp[2 + e] - pp[1 + e]) : 0;
+        const int s_cur = (i + 1 < n && !starts(i + 1)) ? (int)sgn(pp[2 + e] - pp[1 + e]) : 0;
         if (i < n) {
           const float gi = gg[e] * grad_scale + tv_scale * (float)(s_prev - s_cur);
           local += gi * gi;
@@ -209,6 +204,63 @@ tv_normsq_codes_kernel(const float* __restrict__ p, const float* __restrict__ g,
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float gi = gg[e] * grad_scale; local += gi * gi; }     // elements past n are zero
+    }
+  }
+  __shared__ float part[4];
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  const float val[1] = {(part[0] + part[1]) + (part[2] + part[3])};
+  float* const out[1] = {normsq};
+  ordered_block_sum<1>(val, out, reinterpret_cast<unsigned*>(normsq + 1));
+}
+
+// the tables' form: 16-byte aligned, n a multiple of 4 and below 2^31.  kU chunks per thread and round, every load issued before the
+// first is used and NO branch around a load (the neighbours p[e0-1], p[e0+4] come from clamped addresses; a table seam can only lie on
+// a chunk's border since seg is a multiple of 4: two 32-bit seam tests per chunk).  The generic form above spent its time on 64-bit
+// seam tests per element and on one chunk's two loads in flight per thread: 2.4 TB/s.
+template <bool TV>
+__global__ void __launch_bounds__(256)
+tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict__ g, int n4, float tv_scale, float grad_scale,
+                            float* __restrict__ normsq, int seg, uint8_t* __restrict__ codes) {
+  constexpr int kU = 4;
+  const f4* __restrict__ p4 = reinterpret_cast<const f4*>(p);
+  const f4* __restrict__ g4 = reinterpret_cast<const f4*>(g);
+  const int span = gridDim.x * blockDim.x, n = 4 * n4;
+  float local = 0.0f;
+  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < n4; q0 += kU * span) {
+    f4 a[kU], b[kU];
+    float lo[kU], hi[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int q = min(q0 + u * span, n4 - 1);           // past the end: the last chunk again (masked below)
+      a[u] = p4[q];
+      b[u] = g4[q];
+      if (TV) {
+        lo[u] = p[max(4 * q - 1, 0)];
+        hi[u] = p[min(4 * q + 4, n - 1)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int q = q0 + u * span, e0 = 4 * q;
+      if (q >= n4) break;
+      float g0, g1, g2, g3;
+      if (TV) {
+        const bool first = e0 == 0 || e0 == seg || e0 == 2 * seg || e0 == 3 * seg;
+        const int e4 = e0 + 4;
+        const bool last = e4 == n || e4 == seg || e4 == 2 * seg || e4 == 3 * seg;
+        const int s_in = first ? 0 : (int)sgn(a[u][0] - lo[u]), s0 = (int)sgn(a[u][1] - a[u][0]), s1 = (int)sgn(a[u][2] - a[u][1]),
+                  s2 = (int)sgn(a[u][3] - a[u][2]), s3 = last ? 0 : (int)sgn(hi[u] - a[u][3]);
+        g0 = b[u][0] * grad_scale + tv_scale * (float)(s_in - s0);
+        g1 = b[u][1] * grad_scale + tv_scale * (float)(s0 - s1);
+        g2 = b[u][2] * grad_scale + tv_scale * (float)(s1 - s2);
+        g3 = b[u][3] * grad_scale + tv_scale * (float)(s2 - s3);
+        codes[q] = (uint8_t)((s0 + 1) | ((s1 + 1) << 2) | ((s2 + 1) << 4) | ((s3 + 1) << 6));
+      } else {
+        g0 = b[u][0] * grad_scale; g1 = b[u][1] * grad_scale; g2 = b[u][2] * grad_scale; g3 = b[u][3] * grad_scale;
+      }
+      local += (g0 * g0 + g1 * g1) + (g2 * g2 + g3 * g3);
     }
   }
   __shared__ float part[4];
@@ -254,12 +306,13 @@ adamw_clip_tv_kernel(float* __restrict__ p, const float* __restrict__ g, float* 
       byte = codes[q];
       s_prev = q > 0 ? (int)(codes[q - 1] >> 6) - 1 : 0;
     }
+    const float tv_scale = e0 < tv_split ? tv_scale_lo : tv_scale_hi;       // the splits are multiples of 4: one choice per chunk
+    const float lr_q = e0 < lr_split ? lr : lr_hi;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int s_cur = (int)((byte >> (2 * e)) & 3u) - 1;
-      const float tv_scale = e0 + e < tv_split ? tv_scale_lo : tv_scale_hi;
       const float gi = (gg[e] * grad_scale + tv_scale * (float)(s_prev - s_cur)) * clip;
-      adam_update(pp[e], gi, mm[e], vv[e], e0 + e < lr_split ? lr : lr_hi, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+      adam_update(pp[e], gi, mm[e], vv[e], lr_q, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
       s_prev = s_cur;
     }
     if (whole) {
@@ -386,16 +439,26 @@ extern "C" size_t nerf_tv_codes_bytes(int64_t n) { return n > 0 ? (size_t)((n + 
 
 extern "C" int nerf_tv_normsq_codes(const float* params, const float* grads, int64_t n, int n_tables, float tv_weight, float grad_scale,
                                     float* normsq_dev, void* tv_codes, nerf_stream_t stream) {
-  NERF_REQUIRE(n >= 0 && normsq_dev && n_tables >= 1 && n % n_tables == 0, "nerf_tv_normsq_codes: bad arguments");
+  NERF_REQUIRE(n >= 0 && normsq_dev && n_tables >= 1 && n_tables <= 4 && n % n_tables == 0, "nerf_tv_normsq_codes: bad arguments");
   if (n == 0) return NERF_OK;
   const int64_t seg = n / n_tables;
+  NERF_REQUIRE(n_tables == 1 || seg % 4 == 0, "nerf_tv_normsq_codes: %lld elements per table (a multiple of 4)", (long long)seg);
   NERF_REQUIRE(params && grads && (tv_weight == 0.0f || tv_codes), "nerf_tv_normsq_codes: NULL pointer");
   const float tv_scale = seg > 1 ? tv_weight / (float)(seg - 1) : 0.0f;
   int64_t blocks = ((n + 3) / 4 + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  const int vec = (((uintptr_t)params | (uintptr_t)grads) & 15) == 0;
-  hipLaunchKernelGGL(nerf::tv_normsq_codes_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n, tv_scale,
-                     grad_scale, normsq_dev, seg, static_cast<uint8_t*>(tv_codes), vec);
+  const int64_t cap = nerf::options().tv_blocks > 0 && nerf::options().tv_blocks <= 1024 ? nerf::options().tv_blocks : 1024;   // partials: NERF_NORMSQ_WS_FLOATS
+  if (blocks > cap) blocks = cap;
+  const bool fast = (((uintptr_t)params | (uintptr_t)grads) & 15) == 0 && n % 4 == 0 && n < ((int64_t)1 << 31) - 16;
+  uint8_t* codes = static_cast<uint8_t*>(tv_codes);
+  if (fast && tv_scale != 0.0f)
+    hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
+                       (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)seg, codes);
+  else if (fast)
+    hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<false>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
+                       (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)seg, codes);
+  else
+    hipLaunchKernelGGL(nerf::tv_normsq_codes_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n, tv_scale,
+                       grad_scale, normsq_dev, seg, codes);
   return nerf::check_launch("nerf_tv_normsq_codes");
 }
 
@@ -405,6 +468,8 @@ extern "C" int nerf_adamw_clip_step_tv(float* params, const float* grads, float*
                                        float tv_weight_hi, int64_t seg_hi, int64_t lr_split, float lr_hi, void* params_f16_out,
                                        nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && step >= 1 && tv_split >= 0 && seg_lo >= 0 && seg_hi >= 0, "nerf_adamw_clip_step_tv: n=%lld step=%d", (long long)n, step);
+  NERF_REQUIRE((tv_split % 4 == 0 || tv_split >= n) && (lr_split % 4 == 0 || lr_split >= n),
+               "nerf_adamw_clip_step_tv: tv_split / lr_split must be multiples of 4 (or past the end)");
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq, "nerf_adamw_clip_step_tv: NULL pointer");
   NERF_REQUIRE(params_f16_out == nullptr || ((uintptr_t)params_f16_out & 7) == 0, "nerf_adamw_clip_step_tv: params_f16_out unaligned");

@@ -41,6 +41,7 @@ static const OptionSlot kSlots[] = {
     {"hash_xcd", "NERF_HASH_XCD", &Options::hash_xcd},
     {"composite_wgs_per_cu", "NERF_COMPOSITE_WGS", &Options::composite_wgs_per_cu},
     {"deterministic", "NERF_DETERMINISTIC", &Options::deterministic},
+    {"tv_blocks", "NERF_TV_BLOCKS", &Options::tv_blocks},
 };
 
 Options& options() {

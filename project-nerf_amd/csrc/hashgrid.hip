@@ -58,7 +58,12 @@ __device__ __forceinline__ Corner corners_of(const HashLevels& L, int lvl, float
     const float wz = (c & 4) ? frac[2] : sub_rn(1.0f, frac[2]);
     out.w[c] = mul_rn(mul_rn(wx, wy), wz);
     unsigned e;
-    if (L.dense[lvl]) e = (gx + gy * res + gz * res * res) % size;
+    if (L.dense[lvl]) {
+      // (gx + gy res + gz res^2) % size: every coordinate is at most res and size >= res^3, so the index is below 2 size --
+      // one conditional subtraction gives the remainder (a runtime udiv costs ~30 VALU ops per corner)
+      e = gx + gy * res + gz * res * res;
+      e = e >= size ? e - size : e;
+    }
     else {
       const unsigned h = (gx * 1u) ^ (gy * 2654435761u) ^ (gz * 805459861u);
       e = pow2 ? (h & (size - 1)) : (h % size);     // same value; a runtime udiv costs ~30 VALU ops per corner

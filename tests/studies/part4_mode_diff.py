@@ -30,8 +30,8 @@ def run(steps, det, probes_every, noise_after_step1=0.0):
             # master copies of the three deformation grids (the forward reads their fp16 copies)
             gen = torch.Generator(device="cuda").manual_seed(1234)
             for k in range(3):
-                t = eng.table(k)
-                t.mul_(1.0 + noise_after_step1 * torch.randn(t.shape, device="cuda", generator=gen))
+                tab = eng.table(k)
+                tab.mul_(1.0 + noise_after_step1 * torch.randn(tab.shape, device="cuda", generator=gen))
             eng.repack()
         params = [eng.table(k).clone() for k in range(4)] + [eng.net.clone()]
         out.append((loss, grads, params, float(eng._normsq_ws[0])))

@@ -268,10 +268,15 @@ def test_decoder_ray_mode_ragged_tiles(ops, R, S, chain_family):
     # layers, so the tight bound is on the 99.5th percentile and a looser one on the maximum
     e_rgb = (rgb.cpu() - rb).abs()
     e_sig = (sigma.cpu() - sb[:, 0]).abs() / max(1.0, float(sb.max()))
-    assert float(torch.quantile(e_rgb.flatten(), 0.995)) < 6e-3 and float(e_rgb.max()) < 5e-2
-    assert float(torch.quantile(e_sig, 0.995)) < 6e-3 and float(e_sig.max()) < 5e-2
+    # measured over the six shapes and both families (gpurun_out/r04/ragged.txt): max 7.7e-3 / 9.2e-3, 99.5th percentile
+    # 2.2e-3 / 1.4e-3; against the fp32 oracle 1.46e-2 -- bounds at 1.5x
+    assert float(torch.quantile(e_rgb.flatten(), 0.995)) < 3.3e-3 and float(e_rgb.max()) < 1.2e-2
+    assert float(torch.quantile(e_sig, 0.995)) < 2.2e-3 and float(e_sig.max()) < 1.4e-2
     r32, s32 = O.nerf_field(params, pts, dirs)
-    assert float((rgb.cpu() - r32).abs().max()) < 8e-2
+    e32 = float((rgb.cpu() - r32).abs().max())
+    print(f"[ragged tiles {R}x{S} {chain_family}] max |d rgb| vs bf16 oracle {float(e_rgb.max()):.3e} (p99.5 {float(torch.quantile(e_rgb.flatten(), 0.995)):.2e}), "
+          f"rel d sigma {float(e_sig.max()):.3e} (p99.5 {float(torch.quantile(e_sig, 0.995)):.2e}), max |d rgb| vs fp32 oracle {e32:.3e}")
+    assert e32 < 2.2e-2
 
 
 def oracle_param_grads(params, pts, dirs, d_rgb, d_sigma):

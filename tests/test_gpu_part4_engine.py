@@ -89,7 +89,7 @@ def test_fused_forward_vs_reference_golden(fused_model, plain_model):
     assert rgb.shape == (400, 3) and sigma.shape == (400, 1) and delta.shape == (400, 3)
     e_d = float(np.abs(delta.cpu().numpy() - g["delta"]).max())
     print(f"[part4 fused forward vs g14] max |d delta_x| {e_d:.2e} of max |delta_x| {np.abs(g['delta']).max():.2e}")
-    assert e_d < 5e-3 * float(np.abs(g["delta"]).max())               # fp16 forward chain against fp32 (measured 1.3e-3)
+    assert e_d < 2e-3 * float(np.abs(g["delta"]).max())               # fp16 forward chain against fp32 (measured 1.3e-3)
     p, _ = plain_model
     saved = [mm.deform_decoder.displacement_scale.detach().clone() for mm in (m, p)]
     try:
