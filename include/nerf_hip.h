@@ -63,7 +63,7 @@ int nerf_abi_version(void);
  *   - nerf_hash_encode_bwd_ws*: no bin is cut into several work items (nothing is flushed with float atomics); the forms without a
  *     workspace return NERF_EINVAL;
  *   - nerf_hash_encode_bwd_input*: point on the thread, levels summed in order;
- *   - nerf_composite_mse*_bwd: pass `sum_ws` (the loss and regulariser sums; they do not enter the gradients).
+ *   - nerf_composite_mse*_bwd: pass `sum_ws` (the loss and regulariser sums; they do not enter the gradients; the engines always do).
  * Always ordered, option or not: the vanilla decoder's weight gradients, nerf_tv_normsq*.  Costs 0.1-0.3 ms per Instant / Part 4
  * step (profiles/). */
 int nerf_set_option(const char* name, int value);
@@ -469,9 +469,10 @@ int nerf_render_rays_fwd(const void* packed, const float* rays_o, const float* r
  * otherwise compact inputs as in nerf_composite_fwd_indexed.  loss_accum (device fp32) is ADDED to;
  * amax_accum (optional device fp32, max-accumulated; caller zeroes both) receives the vanilla decoder's
  * largest output-layer derivative for nerf_mlp_bwd_dgrad_ex.  pred_out [R,3] optional.
- * sum_ws: NULL (one float atomic per workgroup into loss_accum / reg_accum) or NERF_SUM_WS_FLOATS floats of scratch: the
- * workgroups' partial sums are then added in workgroup order (the same bits every run). */
-#define NERF_SUM_WS_FLOATS 8200
+ * sum_ws: NULL (float atomics: two or three same-address atomics per workgroup, which retire one after the other) or
+ * NERF_SUM_WS_FLOATS floats of scratch: every workgroup stores its partial sums there and a one-workgroup launch adds them in
+ * workgroup order (no atomics: faster, and the same bits every run). */
+#define NERF_SUM_WS_FLOATS 12288
 int nerf_composite_mse_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
                            const float* rays_d, const float* bg, int64_t bg_rows, const float* target,
                            float loss_weight, int64_t n_rays, int n_samples, float* pred_out, float* loss_accum,
@@ -507,7 +508,7 @@ int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  *                         gradients after the all-reduce) gets the same bits, hence the same clip coefficient
  *   nerf_adamw_clip_step: AdamW with grads scaled by grad_scale * min(1, max_norm / (norm + 1e-6)),
  *                         norm = grad_scale * sqrt(normsq_dev[0]); normsq_dev NULL or max_norm <= 0: no clip. */
-#define NERF_NORMSQ_WS_FLOATS 1032
+#define NERF_NORMSQ_WS_FLOATS 4104
 int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
                    float* normsq_dev, nerf_stream_t stream);
 /* the same pass WITHOUT zeroing normsq_dev[0..1] first: several parameter groups accumulate ONE global squared norm

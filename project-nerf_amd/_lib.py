@@ -147,8 +147,8 @@ def load():
     return lib
 
 
-NORMSQ_WS_FLOATS = 1032     # NERF_NORMSQ_WS_FLOATS
-SUM_WS_FLOATS = 8200        # NERF_SUM_WS_FLOATS
+NORMSQ_WS_FLOATS = 4104     # NERF_NORMSQ_WS_FLOATS
+SUM_WS_FLOATS = 12288       # NERF_SUM_WS_FLOATS
 
 
 def set_option(name: str, value: int) -> None:

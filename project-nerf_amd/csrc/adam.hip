@@ -219,8 +219,11 @@ tv_normsq_codes_kernel(const float* __restrict__ p, const float* __restrict__ g,
 // first is used and NO branch around a load (the neighbours p[e0-1], p[e0+4] come from clamped addresses; a table seam can only lie on
 // a chunk's border since seg is a multiple of 4: two 32-bit seam tests per chunk).  The generic form above spent its time on 64-bit
 // seam tests per element and on one chunk's two loads in flight per thread: 2.4 TB/s.
+// 1024 threads per workgroup, at most one workgroup per CU: every workgroup ends with a same-address ticket atomic, and those
+// retire one after the other (~20 ns each: 1024 workgroups of 256 spent 20 us of an 80-us launch queueing there; 4096: 60 us)
+constexpr int kTvFastThreads = 1024;
 template <bool TV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kTvFastThreads)
 tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict__ g, int n4, float tv_scale, float grad_scale,
                             float* __restrict__ normsq, int seg, uint8_t* __restrict__ codes) {
   constexpr int kU = 4;
@@ -263,11 +266,16 @@ tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict
       local += (g0 * g0 + g1 * g1) + (g2 * g2 + g3 * g3);
     }
   }
-  __shared__ float part[4];
+  __shared__ float part[kTvFastThreads / 64];
   local = wave_sum(local);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
   __syncthreads();
-  const float val[1] = {(part[0] + part[1]) + (part[2] + part[3])};
+  float sum = 0.0f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kTvFastThreads / 64; ++w) sum += part[w];
+  }
+  const float val[1] = {sum};
   float* const out[1] = {normsq};
   ordered_block_sum<1>(val, out, reinterpret_cast<unsigned*>(normsq + 1));
 }
@@ -373,7 +381,7 @@ static int tv_normsq_impl(const float* params, float* grads, int64_t n, float tv
   const float tv_scale = seg > 1 ? tv_weight / (float)(seg - 1) : 0.0f;      // d/dp of mean|p[1:] - p[:-1]| * w, per table
   int64_t blocks = (n / 4 + 255) / 256 + 1;
   if (blocks > 1024) blocks = 1024;      // measured: 512 +6 %, 256 +50 %, 2048 +15 % (one same-address atomic per workgroup against HBM streams in flight)
-  static_assert(NERF_NORMSQ_WS_FLOATS >= 2 + 1024, "one partial per workgroup");
+  static_assert(NERF_NORMSQ_WS_FLOATS >= 2 + 4096, "one partial per workgroup");
   if ((((uintptr_t)params | (uintptr_t)grads) & 15) == 0)
     hipLaunchKernelGGL(nerf::tv_normsq_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
                        tv_scale, grad_scale, normsq_dev, seg);
@@ -446,16 +454,22 @@ extern "C" int nerf_tv_normsq_codes(const float* params, const float* grads, int
   NERF_REQUIRE(params && grads && (tv_weight == 0.0f || tv_codes), "nerf_tv_normsq_codes: NULL pointer");
   const float tv_scale = seg > 1 ? tv_weight / (float)(seg - 1) : 0.0f;
   int64_t blocks = ((n + 3) / 4 + 255) / 256;
-  const int64_t cap = nerf::options().tv_blocks > 0 && nerf::options().tv_blocks <= 1024 ? nerf::options().tv_blocks : 1024;   // partials: NERF_NORMSQ_WS_FLOATS
+  const int64_t cap = 1024;   // generic form; partials: NERF_NORMSQ_WS_FLOATS
   if (blocks > cap) blocks = cap;
   const bool fast = (((uintptr_t)params | (uintptr_t)grads) & 15) == 0 && n % 4 == 0 && n < ((int64_t)1 << 31) - 16;
   uint8_t* codes = static_cast<uint8_t*>(tv_codes);
+  int n_cu = 256;
+  (void)nerf::device_cu_count(&n_cu);
+  int64_t fblocks = (n / 4 + 4 * nerf::kTvFastThreads - 1) / (4 * nerf::kTvFastThreads);          // four chunks per thread and round
+  const int64_t fcap = nerf::options().tv_blocks > 0 && nerf::options().tv_blocks <= 4096 ? nerf::options().tv_blocks : n_cu;
+  if (fblocks > fcap) fblocks = fcap;
+  if (fblocks < 1) fblocks = 1;
   if (fast && tv_scale != 0.0f)
-    hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
-                       (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)seg, codes);
+    hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<true>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
+                       params, grads, (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)seg, codes);
   else if (fast)
-    hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<false>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads,
-                       (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)seg, codes);
+    hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<false>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
+                       params, grads, (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)seg, codes);
   else
     hipLaunchKernelGGL(nerf::tv_normsq_codes_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n, tv_scale,
                        grad_scale, normsq_dev, seg, codes);

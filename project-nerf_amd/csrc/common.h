@@ -45,7 +45,7 @@ struct Options {
                                  // maximum), which retire one after the other in L2: 8 per CU 58 us, 4: 35, 2: 27, 1: 29 (8192 rays x 64, Part 4 step)
   int hash_xcd = 1;              // 1: hash-grid gather kernels launch XCD-aware (levels x and x + 8 on XCD x); 0: level-major 2-D launch (A/B)
   int hash_fwd_lds_kb = 36;      // dynamic LDS per hash-forward workgroup (occupancy throttle, see nerf_hash_encode_fwd); 0: none
-  int tv_blocks = 1024;          // workgroups of the TV + squared-norm pass (at most 1024: one partial each in the normsq workspace)
+  int tv_blocks = 0;             // > 0: workgroups (of 1024 threads) of the TV + squared-norm pass; 0: one per CU (A/B)
   int deterministic = 0;         // 1: every sum whose order depends on scheduling takes an ordered form -- compaction slots in sample order,
                                  // tiny-MLP weight gradients through partial tiles, hash bins never cut, d x from the hash grid level by level,
                                  // scalar sums (loss, regulariser, displacement-scale gradient) per workgroup and in workgroup order: two runs

@@ -334,20 +334,49 @@ composite_mse_bwd_kernel(const float* __restrict__ rgb, const float* __restrict_
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
   if (lane == 0) { part[threadIdx.x >> 6] = loss_local; part[4 + (threadIdx.x >> 6)] = amax; part[8 + (threadIdx.x >> 6)] = reg_local; }
   __syncthreads();
-  if (sum_ws != nullptr) {                 // the workgroups' partial sums added in workgroup order (the same bits every run)
-    const float val[2] = {(part[0] + part[1]) + (part[2] + part[3]), (part[8] + part[9]) + (part[10] + part[11])};
-    float* const out[2] = {loss_out, reg_out};
-    ordered_block_sum<2>(val, out, sum_ws);
+  if (sum_ws != nullptr) {
+    // no atomics at all: the workgroup's three partials go to sum_ws (plain stores), composite_sums_kernel adds them in workgroup
+    // order afterwards.  Same-address atomics retire one after the other (~20 ns each): two per workgroup on 512 workgroups
+    // were most of this kernel's time
+    if (threadIdx.x == 0) {
+      float* ws = reinterpret_cast<float*>(sum_ws);
+      ws[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+      ws[gridDim.x + blockIdx.x] = (part[8] + part[9]) + (part[10] + part[11]);
+      ws[2 * gridDim.x + blockIdx.x] = fmaxf(fmaxf(part[4], part[5]), fmaxf(part[6], part[7]));
+    }
+    return;
   }
   if (threadIdx.x == 0) {
-    if (sum_ws == nullptr) {
-      atomicAdd(loss_out, (part[0] + part[1]) + (part[2] + part[3]));
-      if (reg_out != nullptr) atomicAdd(reg_out, (part[8] + part[9]) + (part[10] + part[11]));
-    }
+    atomicAdd(loss_out, (part[0] + part[1]) + (part[2] + part[3]));
+    if (reg_out != nullptr) atomicAdd(reg_out, (part[8] + part[9]) + (part[10] + part[11]));
     if (amax_out != nullptr) {
       const float m = fmaxf(fmaxf(part[4], part[5]), fmaxf(part[6], part[7]));
       if (m == m && m < 3.0e38f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, m));
     }
+  }
+}
+
+// the partials of composite_mse_bwd_kernel, added in workgroup order (one workgroup; the same bits every run)
+__global__ void __launch_bounds__(256) composite_sums_kernel(const float* __restrict__ ws, int n_blocks, float* __restrict__ loss_out,
+                                                             float* __restrict__ reg_out, float* __restrict__ amax_out) {
+  __shared__ float part[3][4];
+  float s0 = 0.0f, s1 = 0.0f, m = 0.0f;
+  for (int b = threadIdx.x; b < n_blocks; b += 256) {
+    s0 += ws[b];
+    s1 += ws[n_blocks + b];
+    const float v = ws[2 * n_blocks + b];
+    if (v == v && v < 3.0e38f) m = fmaxf(m, v);
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s0; part[1][threadIdx.x >> 6] = s1; part[2][threadIdx.x >> 6] = m; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *loss_out += (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+    if (reg_out != nullptr) *reg_out += (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    if (amax_out != nullptr) *amax_out = fmaxf(*amax_out, fmaxf(fmaxf(part[2][0], part[2][1]), fmaxf(part[2][2], part[2][3])));
   }
 }
 
@@ -452,20 +481,21 @@ extern "C" int nerf_composite_bwd_indexed(const float* rgb_compact, const float*
 }
 
 // workgroups of the fused compositing + loss backward: composite_wgs_per_cu per CU of THIS device (at least one)
-static int64_t mse_blocks(int64_t n_rays) {
+static int64_t mse_blocks(int64_t n_rays, bool partials) {
   int n_cu = 256;
   (void)device_cu_count(&n_cu);
-  const int per_cu = options().composite_wgs_per_cu < 1 ? 1 : options().composite_wgs_per_cu;
+  // with partial sums (no atomics) the kernel can spread over the chip: eight workgroups of four waves per CU
+  const int per_cu = partials ? 8 : (options().composite_wgs_per_cu < 1 ? 1 : options().composite_wgs_per_cu);
   int64_t cap = (int64_t)n_cu * per_cu;
   if (cap > kOrderedSumMaxBlocks) cap = kOrderedSumMaxBlocks;
   const int64_t blocks = (n_rays + 3) / 4;
   return blocks < cap ? blocks : cap;
 }
-static int prepare_sum_ws(float* sum_ws, nerf_stream_t stream) {
-  static_assert(NERF_SUM_WS_FLOATS >= 1 + 2 * kOrderedSumMaxBlocks, "two partials per workgroup");
-  if (sum_ws != nullptr && hipMemsetAsync(sum_ws, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
-    return fail(NERF_ELAUNCH, "nerf_composite_mse_bwd: memset failed");
-  return NERF_OK;
+static int finish_sums(const float* sum_ws, unsigned n_blocks, float* loss, float* reg, float* amax, nerf_stream_t stream) {
+  static_assert(NERF_SUM_WS_FLOATS >= 3 * kOrderedSumMaxBlocks, "three partials per workgroup");
+  if (sum_ws == nullptr) return NERF_OK;
+  hipLaunchKernelGGL(composite_sums_kernel, dim3(1), dim3(256), 0, as_stream(stream), sum_ws, (int)n_blocks, loss, reg, amax);
+  return check_launch("nerf_composite_mse_bwd (sums)");
 }
 
 extern "C" int nerf_composite_mse_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
@@ -477,12 +507,12 @@ extern "C" int nerf_composite_mse_bwd(const float* rgb, const float* sigma, cons
   if (n_rays == 0) return NERF_OK;
   NERF_REQUIRE(rgb && sigma && z && rays_d && target && loss_accum && d_rgb && d_sigma, "nerf_composite_mse_bwd: NULL pointer");
   NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_mse_bwd: bg_rows=%lld", (long long)bg_rows);
-  const dim3 grid((unsigned)mse_blocks(n_rays));
-  if (int rc = prepare_sum_ws(sum_ws, stream); rc != NERF_OK) return rc;
+  const dim3 grid((unsigned)mse_blocks(n_rays, sum_ws != nullptr));
   DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
              slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, amax_accum,
              (const float*)nullptr, 0.0f, (float*)nullptr, (float*)nullptr, (float*)nullptr, reinterpret_cast<unsigned*>(sum_ws));
-  return check_launch("nerf_composite_mse_bwd");
+  if (int rc = check_launch("nerf_composite_mse_bwd"); rc != NERF_OK) return rc;
+  return finish_sums(sum_ws, grid.x, loss_accum, nullptr, amax_accum, stream);
 }
 
 extern "C" int nerf_composite_mse_reg_bwd(const float* rgb, const float* sigma, const int* slot_of_sample, const float* z,
@@ -496,10 +526,11 @@ extern "C" int nerf_composite_mse_reg_bwd(const float* rgb, const float* sigma, 
   NERF_REQUIRE(rgb && sigma && z && rays_d && target && loss_accum && d_rgb && d_sigma && extra && d_extra && reg_accum,
                "nerf_composite_mse_reg_bwd: NULL pointer");
   NERF_REQUIRE(bg == nullptr || bg_rows == 1 || bg_rows == n_rays, "nerf_composite_mse_reg_bwd: bg_rows=%lld", (long long)bg_rows);
-  const dim3 grid((unsigned)mse_blocks(n_rays));
-  if (int rc = prepare_sum_ws(sum_ws, stream); rc != NERF_OK) return rc;
+  const dim3 grid((unsigned)mse_blocks(n_rays, sum_ws != nullptr));
   DISPATCH_K(per_lane(n_samples), composite_mse_bwd_kernel, rgb, sigma, z, rays_d, bg, bg_rows, target, loss_weight,
              slot_of_sample, n_rays, n_samples, pred_out, loss_accum, d_rgb, d_sigma, (float*)nullptr, extra, reg_weight, d_extra,
              reg_accum, extra_map, reinterpret_cast<unsigned*>(sum_ws));
+  if (int rc = check_launch("nerf_composite_mse_reg_bwd"); rc != NERF_OK) return rc;
+  return finish_sums(sum_ws, grid.x, loss_accum, reg_accum, nullptr, stream);
   return check_launch("nerf_composite_mse_reg_bwd");
 }

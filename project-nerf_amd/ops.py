@@ -149,10 +149,8 @@ def deterministic() -> bool:
 
 
 def sum_ws(device) -> Optional[Tensor]:
-    """scratch of the ordered loss / regulariser sums of nerf_composite_mse*_bwd (None unless deterministic); one per
-    device: launches that share it must be stream-ordered"""
-    if not deterministic():
-        return None
+    """scratch of the loss / regulariser partial sums of nerf_composite_mse*_bwd (summed in workgroup order by a one-workgroup
+    launch: no atomics, the same bits every run); one per device: launches that share it must be stream-ordered"""
     key = torch.device(device)
     if key not in _SUM_WS:
         _SUM_WS[key] = torch.zeros(_lib.SUM_WS_FLOATS, device=key)
