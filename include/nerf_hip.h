@@ -403,6 +403,26 @@ int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_t n, int n_
                                              const unsigned* res_host, const unsigned* size_host,
                                              const unsigned* offset_host, const unsigned* dense_host, float bound,
                                              float* d_table, void* workspace, size_t workspace_bytes, nerf_stream_t stream);
+/* The speculative form of the binned scatter: NO count pass.  Bin capacities come from the TRUE record counts that the previous
+ * all-level call on this workspace (counted, precounted or speculative) left in it, + 1/8 + 64 records; a record that does not fit
+ * its bin is added with a float atomic by a last small launch (steady-state training batches fill their bins within a few percent
+ * from step to step: a handful of records).  Protocol: nerf_hash_encode_bwd_spec_begin (clears the status block) -> the decoder's
+ * backward max-accumulates the largest |gradient| into the workspace's slot (nerf_hash_encode_bwd_ws_slots): nerf_imlp_bwd_amax
+ * with row-major d_feat [n, 2L], or nerf_imlp_bwd_lm with the level-major copy in the workspace (then d_feat NULL here)
+ * -> nerf_hash_encode_bwd_ws_store_spec.  The caller decides WHEN the estimates are good (same
+ * occupancy grid, point count within ~10 % of the last call's) and reads the status block afterwards
+ * (nerf_hash_encode_bwd_spec_status: 8 x u32 at the start of the workspace: [3] records that overflowed, [4] != 0: records were
+ * LOST -- overflow list full or estimates larger than the workspace -- the gradient of that call is incomplete: fall back to the
+ * counted form).  Levels of at most 256 slices (tables up to 2^20 entries per level); not with option "deterministic". */
+int nerf_hash_encode_bwd_spec_begin(void* workspace, nerf_stream_t stream);
+int nerf_hash_encode_bwd_ws_store_spec(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                       const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                       const unsigned* dense_host, float bound, const float* d_feat, float* d_table, void* workspace,
+                                       size_t workspace_bytes, nerf_stream_t stream);
+int nerf_imlp_bwd_amax(const void* packed, void* workspace, const float* rgb, const float* sigma, const float* d_rgb,
+                       const float* d_sigma, int64_t n, float* grads_f32, float* d_feat, void* amax_bits, nerf_stream_t stream);
+const void* nerf_hash_encode_bwd_spec_status(const void* workspace);
+
 /* gradient with respect to the encoded positions (dynamic fields encode x + delta_x: reference
  * src/core.py:268-271, 341-344): d_pts [n,3] = d_feat . d features / d x, zero along an axis on which
  * HashRepresentation's clamp is active; d_pts is OVERWRITTEN. */

@@ -79,6 +79,10 @@ PROTOTYPES = {
     "nerf_hash_encode_fwd_f16_hist": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),
     "nerf_hash_encode_bwd_ws_slots": (i32, [c_ptr, i64, i32, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr)]),
     "nerf_hash_encode_bwd_ws_store_precounted": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),
+    "nerf_hash_encode_bwd_spec_begin": (i32, [c_ptr, c_ptr]),
+    "nerf_hash_encode_bwd_ws_store_spec": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr, size_t, c_ptr]),
+    "nerf_imlp_bwd_amax": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_hash_encode_bwd_spec_status": (c_ptr, [c_ptr]),
     "nerf_imlp_bwd_lm": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_input": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_input_f16": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),

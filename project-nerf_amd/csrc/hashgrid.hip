@@ -405,11 +405,17 @@ struct BinPlan {
 };
 
 struct BinHeader {                             // start of the workspace
-  unsigned n_items, n_records, amax_bits, pad;  // amax_bits: largest |d_feat| of the call as fp32 bits
+  unsigned n_items, n_records, amax_bits, n_overflow;  // amax_bits: largest |d_feat| of the call as fp32 bits
+  unsigned lost, spec_total, pad0, pad1;       // speculative form: records dropped (overflow list full / plan did not fit); total capacity
 };
 struct BinItem {
   unsigned entry0, begin, end, atomic;         // first table entry of the slice, record range, flush: mode | live entries << 2
+  unsigned bin;                                // the item's bin (speculative form: the range ends at the bin's cursor)
 };
+// Speculative form (nerf_hash_encode_bwd_ws_store_spec): NO count pass.  The bins' capacities come from the previous call's true
+// counts (kept in the workspace) + 1/8 + 64; a record that does not fit its bin goes to an overflow list that a last small launch
+// adds with float atomics.  Steady-state training batches fill their bins within a few percent from step to step.
+constexpr unsigned kMaxOverflow = 1u << 20;    // overflow records live behind the bins' records; their bins in a parallel array
 // flush modes of an item: read-modify-write of the non-zero sums (the slice belongs to this item, d_table holds other
 // contributions: the accumulate form), float atomics (the bin was cut into several items), plain STORE of the whole slice
 // (the overwrite form: d_table needs no zeroing and is not read back)
@@ -434,16 +440,21 @@ __device__ __forceinline__ unsigned record_slot(BinRecord r) { return (unsigned)
 __device__ __forceinline__ long long record_g0(BinRecord r) { return (long long)(r << 26) >> 38; }   // sign-extended bits [12,38)
 __device__ __forceinline__ long long record_g1(BinRecord r) { return (long long)r >> 38; }
 
+// records the workspace holds: every corner of every point and level, + a quarter and 64 per bin for the speculative form's margins
+static size_t bin_record_capacity(int64_t n, int n_levels) { const size_t r = (size_t)n * 8 * (size_t)n_levels; return r + r / 4 + 64 * (size_t)kMaxBins; }
 struct BinWorkspace {
   BinHeader* header;
-  unsigned* count;                             // [bins]
+  unsigned* count;                             // [bins]  (speculative form: the bins' capacities)
   unsigned* cursor;                            // [bins]
+  unsigned* est;                               // [bins] true record counts of the last call (persistent between calls)
+  unsigned* start;                             // [bins] first record of the bin (speculative form)
   BinItem* items;                              // [max_items]
   float2* grad_lm;                             // [levels][n] level-major copy of d_feat (the count pass writes it)
-  BinRecord* records;
+  BinRecord* records;                          // bin_record_capacity(n, L) records
+  unsigned* overflow_bin;                      // [kMaxOverflow] bin of overflow record o = records[bin_record_capacity + o]
 };
 
-static size_t bin_max_items(int64_t n, int n_levels) { return (size_t)(n * 8 * n_levels / kChunk) + kMaxBins; }
+static size_t bin_max_items(int64_t n, int n_levels) { return (size_t)(bin_record_capacity(n, n_levels) / kChunk) + kMaxBins; }
 
 static BinWorkspace carve(void* base, int64_t n, int n_levels) {
   char* p = static_cast<char*>(base);
@@ -451,6 +462,9 @@ static BinWorkspace carve(void* base, int64_t n, int n_levels) {
   w.header = reinterpret_cast<BinHeader*>(p);                 p += 256;
   w.count = reinterpret_cast<unsigned*>(p);                   p += sizeof(unsigned) * kMaxBins;
   w.cursor = reinterpret_cast<unsigned*>(p);                  p += sizeof(unsigned) * kMaxBins;
+  w.est = reinterpret_cast<unsigned*>(p);                     p += sizeof(unsigned) * kMaxBins;          // fixed offsets: survive a change of n
+  w.start = reinterpret_cast<unsigned*>(p);                   p += sizeof(unsigned) * kMaxBins;
+  w.overflow_bin = reinterpret_cast<unsigned*>(p);            p += sizeof(unsigned) * kMaxOverflow;
   w.items = reinterpret_cast<BinItem*>(p);                    p += (sizeof(BinItem) * bin_max_items(n, n_levels) + 255) / 256 * 256;
   w.grad_lm = reinterpret_cast<float2*>(p);                   p += (sizeof(float2) * (size_t)n * (size_t)n_levels + 255) / 256 * 256;
   w.records = reinterpret_cast<BinRecord*>(p);
@@ -458,8 +472,9 @@ static BinWorkspace carve(void* base, int64_t n, int n_levels) {
 }
 
 static size_t bin_workspace_bytes(int64_t n, int n_levels) {
-  return 256 + 2 * sizeof(unsigned) * kMaxBins + (sizeof(BinItem) * bin_max_items(n, n_levels) + 255) / 256 * 256 +
-         (sizeof(float2) * (size_t)n * (size_t)n_levels + 255) / 256 * 256 + sizeof(BinRecord) * (size_t)n * 8 * (size_t)n_levels;
+  return 256 + 4 * sizeof(unsigned) * kMaxBins + sizeof(unsigned) * kMaxOverflow +
+         (sizeof(BinItem) * bin_max_items(n, n_levels) + 255) / 256 * 256 +
+         (sizeof(float2) * (size_t)n * (size_t)n_levels + 255) / 256 * 256 + sizeof(BinRecord) * (bin_record_capacity(n, n_levels) + kMaxOverflow);
 }
 
 __device__ __forceinline__ bool point_gradient(const float* __restrict__ d_feat, int64_t p, int n_levels, int lvl, float& g0, float& g1) {
@@ -588,8 +603,12 @@ __device__ __forceinline__ int fixed_shift(unsigned amax_bits) {
 
 // one workgroup of 1024: bins in rounds of 1024 with a carried total
 __global__ void __launch_bounds__(1024)
-hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ count, unsigned* __restrict__ cursor,
-                     BinItem* __restrict__ items, BinHeader* __restrict__ header, int overwrite, unsigned chunk) {
+hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, unsigned* __restrict__ cursor,
+                     BinItem* __restrict__ items, BinHeader* __restrict__ header, int overwrite, unsigned chunk,
+                     unsigned* __restrict__ est, unsigned* __restrict__ start, unsigned spec_capacity) {
+  // est != null, spec_capacity == 0 (counted forms): the bins' true counts are also left in est for a later speculative call.
+  // spec_capacity > 0 (speculative form): NO counts exist -- a bin's capacity is est + est / 8 + 64 (written to count[], which the
+  // later passes read as the bin's size), its records start at start[bin]; the reduce pass reads the true fill from cursor[]
   // chunk: records per work item -- kChunk, or 0xffffffff (option "deterministic"): a bin is never cut, so no slice is
   // flushed with float atomics; the coarse dense levels' bins then serialise on one workgroup each
   __shared__ unsigned scan_r[1024], scan_i[1024], wave_r[16], wave_i[16];
@@ -599,7 +618,13 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
   __syncthreads();
   for (unsigned base = 0; base < n_bins; base += 1024) {
     const unsigned b = base + threadIdx.x;
-    const unsigned c = b < n_bins ? count[b] : 0u;
+    unsigned c = b < n_bins ? (spec_capacity ? est[b] : count[b]) : 0u;
+    if (b < n_bins) {
+      if (spec_capacity) {
+        c = c + (c >> 3) + 64u;
+        count[b] = c;
+      } else if (est != nullptr) est[b] = c;
+    }
     // overwrite form: every bin gets an item (an empty bin's item stores a slice of zeros)
     const unsigned it = c == 0 ? ((b < n_bins && overwrite) ? 1u : 0u) : (unsigned)(((unsigned long long)c + chunk - 1) / chunk);
     // inclusive scan of both columns: within the wave by shuffles, the sixteen wave totals through LDS (two barriers per round
@@ -621,6 +646,7 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
     const unsigned r0 = carry_r + scan_r[threadIdx.x] - c, i0 = carry_i + scan_i[threadIdx.x] - it;
     if (b < n_bins) {
       cursor[b] = r0;
+      if (start != nullptr) start[b] = r0;
       int li = 0;
       while (li + 1 < plan.count && plan.bin0[li + 1] <= b) ++li;
       const unsigned first = (b - plan.bin0[li]) << kSliceLog2;
@@ -633,6 +659,7 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
         item.begin = r0 + j * chunk;
         item.end = r0 + (unsigned)min((unsigned long long)c, (unsigned long long)(j + 1) * chunk);
         item.atomic = (it > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) | (L.dense[lvl] ? kItemRuns : 0u);
+        item.bin = b;
         items[i0 + j] = item;
       }
     }
@@ -646,6 +673,15 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, const unsigned* __restrict__ co
   if (threadIdx.x == 0) {
     header->n_items = carry_i;
     header->n_records = carry_r;
+    if (spec_capacity) {
+      header->spec_total = carry_r;
+      header->n_overflow = 0;
+      header->lost = 0;
+      if (carry_r > spec_capacity) {           // the estimates do not fit the workspace: nothing may be written
+        header->n_items = 0;
+        header->lost = 2;
+      }
+    }
   }
 }
 
@@ -658,7 +694,10 @@ __global__ void __launch_bounds__(512, 8)
 hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, BinPlan plan, const float* __restrict__ d_feat,
                         unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header,
                         const float2* __restrict__ grad_lm, const unsigned* __restrict__ count, float* __restrict__ zero_table,
-                        int all_live, unsigned chunk) {
+                        int all_live, unsigned chunk, const unsigned* __restrict__ spec_start, unsigned* __restrict__ overflow_bin,
+                        BinHeader* __restrict__ header_rw, unsigned overflow_base) {
+  // spec_start != null (speculative form, staged levels only): bin b holds count[b] records from spec_start[b] on; a record past
+  // that goes to the overflow list (records[overflow_base + o], its bin in overflow_bin[o])
   constexpr unsigned kBins = STAGED ? kStagedBins : kMaxSlices;
   __shared__ unsigned cnt[kBins], base[kBins];
   __shared__ unsigned start[STAGED ? kBins : 1], wave_sum[8], total;
@@ -712,10 +751,18 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
     if constexpr (STAGED) {
       // reserve the bins' runs in the workspace; exclusive scan of the counts = the runs' places in the stage
       const unsigned t = threadIdx.x;
-      unsigned v = 0;
+      unsigned v = 0, fit = 0;
       if (t < kStagedBins) {
         v = t < bins ? cnt[t] : 0u;
-        if (v != 0) base[t] = atomicAdd(cursor + plan.bin0[blockIdx.y] + t, v);
+        fit = v;
+        if (v != 0) {
+          const unsigned b0 = atomicAdd(cursor + plan.bin0[blockIdx.y] + t, v);
+          base[t] = b0;
+          if (spec_start != nullptr) {             // speculative form: how many of this round's records still fit the bin
+            const unsigned lim = spec_start[plan.bin0[blockIdx.y] + t] + count[plan.bin0[blockIdx.y] + t];
+            fit = b0 >= lim ? 0u : min(v, lim - b0);
+          }
+        }
         unsigned incl = v;
         for (int o = 1; o < 64; o <<= 1) {
           const unsigned up = __shfl_up(incl, o);
@@ -729,7 +776,7 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
         unsigned before = 0;
         for (unsigned w = 0; w < (t >> 6); ++w) before += wave_sum[w];
         start[t] += before;
-        if (t < bins) cnt[t] = 0;
+        if (t < bins) cnt[t] = fit;               // until the copy below: records of this round that fit; zeroed after it
         if (t == kStagedBins - 1) total = start[t] + v;
       }
       __syncthreads();
@@ -742,12 +789,21 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
         }
       }
       __syncthreads();
-      const unsigned count = total;
-      for (unsigned q = threadIdx.x; q < count; q += blockDim.x) {
-        const unsigned b = bin_of[q];
-        records[base[b] + (q - start[b])] = stage[q];
+      const unsigned staged = total;
+      for (unsigned q = threadIdx.x; q < staged; q += blockDim.x) {
+        const unsigned b = bin_of[q], idx = q - start[b];
+        unsigned dst = base[b] + idx;
+        if (idx >= cnt[b]) {                     // speculative form: the bin is full
+          const unsigned o = atomicAdd(&header_rw->n_overflow, 1u);
+          if (o >= kMaxOverflow) { header_rw->lost = 1; continue; }
+          overflow_bin[o] = plan.bin0[blockIdx.y] + b;
+          dst = overflow_base + o;
+        }
+        records[dst] = stage[q];
       }
-      __syncthreads();                          // stage, start and base are rewritten by the next round
+      __syncthreads();
+      for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) cnt[i] = 0;
+      __syncthreads();                          // stage, start, base and cnt are rewritten by the next round
     } else {
       for (unsigned i = threadIdx.x; i < bins; i += blockDim.x) {
         const unsigned v = cnt[i];
@@ -769,12 +825,21 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
 
 __global__ void __launch_bounds__(512)
 hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __restrict__ items, const BinRecord* __restrict__ records,
-                       float* __restrict__ d_table, unsigned table_entries) {
+                       float* __restrict__ d_table, unsigned table_entries, const unsigned* __restrict__ spec_cursor,
+                       const unsigned* __restrict__ spec_start, unsigned* __restrict__ est) {
+  // spec_cursor != null (speculative form): an item's range was planned from the bin's CAPACITY; what was written ends at the
+  // bin's cursor.  The bin's true count (cursor - start, overflow included) is left in est for the next call.
   __shared__ unsigned long long acc[2 * kSlice];            // 64 KiB of 64-bit fixed-point sums
   const int shift = fixed_shift(header->amax_bits);
   const float inv_scale = __uint_as_float((unsigned)(127 - shift) << 23);
   for (unsigned item_id = blockIdx.x; item_id < header->n_items; item_id += gridDim.x) {
-    const BinItem item = items[item_id];
+    BinItem item = items[item_id];
+    if (spec_cursor != nullptr) {
+      const unsigned fill = spec_cursor[item.bin];
+      if (threadIdx.x == 0 && item.begin == spec_start[item.bin]) est[item.bin] = fill - item.begin;
+      item.end = min(item.end, fill);
+      item.begin = min(item.begin, item.end);
+    }
     for (unsigned i = threadIdx.x; i < 2 * kSlice; i += blockDim.x) acc[i] = 0ull;
     __syncthreads();
     // kUnroll independent record loads in flight per lane: the loop is latency-bound otherwise (49 records per lane)
@@ -849,6 +914,25 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
       }
     }
     __syncthreads();
+  }
+}
+
+// speculative form: the records that did not fit their bins, added with float atomics (a handful per step in steady state)
+__global__ void __launch_bounds__(256)
+hash_bin_overflow_kernel(const BinHeader* __restrict__ header, const BinRecord* __restrict__ overflow, const unsigned* __restrict__ overflow_bin,
+                         HashLevels L, BinPlan plan, float* __restrict__ d_table) {
+  const unsigned n = min(header->n_overflow, kMaxOverflow);
+  const float inv_scale = __uint_as_float((unsigned)(127 - fixed_shift(header->amax_bits)) << 23);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const BinRecord rec = overflow[i];
+    const unsigned bin = overflow_bin[i];
+    int li = 0;
+    while (li + 1 < plan.count && plan.bin0[li + 1] <= bin) ++li;
+    const int tbl = (plan.first + li) / L.n_levels, lvl = plan.first + li - tbl * L.n_levels;
+    const unsigned entry = tbl * plan.table_stride + L.offset[lvl] + ((bin - plan.bin0[li]) << kSliceLog2) + record_slot(rec);
+    const long long a0 = record_g0(rec), a1 = record_g1(rec);
+    if (a0 != 0) atomicAdd(d_table + 2 * (size_t)entry + 0, __ll2float_rn(a0) * inv_scale);
+    if (a1 != 0) atomicAdd(d_table + 2 * (size_t)entry + 1, __ll2float_rn(a1) * inv_scale);
   }
 }
 
@@ -993,7 +1077,10 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
                          int level0, int level1, nerf_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0,
-                         bool overwrite = false, bool precounted = false) {
+                         bool overwrite = false, int precounted = 0) {
+  // precounted: 0 the count pass runs here; 1 counts by the forward (nerf_hash_encode_fwd_f16_hist); 2 speculative: no counts at all
+  // (capacities from the last call's true counts).  1 and 2: largest |gradient| and level-major gradients by nerf_imlp_bwd_lm
+  const bool spec = precounted == 2;
   NERF_REQUIRE(level0 >= 0 && level0 <= level1 && level1 <= n_levels, "nerf_hash_encode_bwd: levels [%d, %d) of %d", level0, level1, n_levels);
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
@@ -1028,15 +1115,18 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
     if (binned) {
       NERF_REQUIRE(workspace_bytes >= bin_workspace_bytes(n, n_levels), "nerf_hash_encode_bwd_ws: workspace of %zu bytes, need %zu",
                    workspace_bytes, bin_workspace_bytes(n, n_levels));
-      NERF_REQUIRE((size_t)n * 8 * (size_t)n_levels < 0xffffffffull, "nerf_hash_encode_bwd_ws: n=%lld too large for 32-bit record offsets", (long long)n);
+      NERF_REQUIRE(bin_record_capacity(n, n_levels) < 0xffffffffull, "nerf_hash_encode_bwd_ws: n=%lld too large for 32-bit record offsets", (long long)n);
       const BinWorkspace w = carve(workspace, n, n_levels);
       const unsigned n_bins = plan.bin0[plan.count];
-      if (!precounted && hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * n_bins, as_stream(stream)) != hipSuccess)   // header + counts
+      const bool whole = level0 == 0 && level1 == n_levels;      // the bins of a level range are numbered from 0: est[] only for whole calls
+      NERF_REQUIRE(!spec || (whole && overwrite), "nerf_hash_encode_bwd_ws_store_spec: all levels, overwrite form");
+      if (precounted == 0 && hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * n_bins, as_stream(stream)) != hipSuccess)   // header + counts
         return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws: memset failed");
       int64_t bx = (n + 511) / 512;
       const int64_t bx_count = bx > 256 ? 256 : bx, bx_scatter = bx > 128 ? 128 : bx;
-      const bool point_major = precounted || n_bins <= kPmBins;
-      if (precounted) {
+      // level-major gradients: written by the count pass here, or by nerf_imlp_bwd_lm (precounted forms called without d_feat)
+      const bool point_major = precounted != 0 ? d_feat == nullptr : n_bins <= kPmBins;
+      if (precounted != 0) {
         // counts by the forward (nerf_hash_encode_fwd_f16_hist), largest |gradient| and level-major gradients by the
         // decoder's backward (nerf_imlp_bwd_lm): nothing to do here
       } else if (point_major) {
@@ -1050,27 +1140,35 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
                            w.count, w.header);
       const float2* grad_lm = point_major ? w.grad_lm : nullptr;
       const unsigned chunk = options().deterministic ? 0xffffffffu : kChunk;
-      hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header,
-                         overwrite ? 1 : 0, chunk);
-      float* zero_table = overwrite ? d_table : nullptr;
       bool any_staged = false, any_direct = false;
       for (int i = 0; i < plan.count; ++i) (plan.bin0[i + 1] - plan.bin0[i] <= kStagedBins ? any_staged : any_direct) = true;
+      NERF_REQUIRE(!spec || !any_direct, "nerf_hash_encode_bwd_ws_store_spec: a level with more than %u slices", kStagedBins);
+      hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header,
+                         overwrite ? 1 : 0, chunk, whole ? w.est : nullptr, spec ? w.start : nullptr,
+                         spec ? (unsigned)bin_record_capacity(n, n_levels) : 0u);
+      float* zero_table = overwrite ? d_table : nullptr;
+      const unsigned* spec_start = spec ? w.start : nullptr;
       if (any_staged)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted ? 1 : 0, chunk);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted == 1 ? 1 : 0, chunk,
+                           spec_start, w.overflow_bin, w.header, (unsigned)bin_record_capacity(n, n_levels));
       if (any_direct)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
-                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted ? 1 : 0, chunk);
+                           plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted == 1 ? 1 : 0, chunk,
+                           (const unsigned*)nullptr, w.overflow_bin, w.header, 0u);
       size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
       if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
       hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,
-                         d_table, table_entries);
+                         d_table, table_entries, spec ? w.cursor : (const unsigned*)nullptr, spec_start, w.est);
+      if (spec)
+        hipLaunchKernelGGL(hash_bin_overflow_kernel, dim3(64), dim3(256), 0, as_stream(stream), w.header,
+                           w.records + bin_record_capacity(n, n_levels), w.overflow_bin, L, plan, d_table);
     }
   }
   if (options().deterministic && !binned && level0 < level1)
     return fail(NERF_EINVAL, "nerf_hash_encode_bwd: option \"deterministic\" needs the workspace form (nerf_hash_encode_bwd_ws*) -- the "
                              "other forms end in float atomics");
-  if (precounted && !binned)
+  if (precounted != 0 && !binned)
     return fail(NERF_EINVAL, "nerf_hash_encode_bwd_ws_store_precounted: the binned form is not available for this table shape / option set");
   if (overwrite && !binned && level0 < level1) {
     // the atomic forms accumulate: give them the zeroed range the overwrite contract promises
@@ -1207,19 +1305,21 @@ extern "C" int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n,
   hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm, (plan.count + per_row - 1) / per_row), dim3(256), 0, as_stream(stream), pts, n,
                      L, plan, d_feat, w.count, w.header, w.grad_lm, per_row);
   const unsigned chunk = options().deterministic ? 0xffffffffu : kChunk;
-  hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header, 1, chunk);
+  hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header, 1, chunk,
+                     (unsigned*)nullptr, (unsigned*)nullptr, 0u);
   int64_t bx = (n + 511) / 512;
   const int64_t bx_scatter = bx > 128 ? 128 : bx;
   if (any_staged)
     hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
-                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0, chunk);
+                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0, chunk, (const unsigned*)nullptr, w.overflow_bin, w.header, 0u);
   if (any_direct)
     hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
-                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0, chunk);
+                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0, chunk, (const unsigned*)nullptr, w.overflow_bin, w.header, 0u);
   size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records, d_table,
-                     (unsigned)((uint64_t)(n_tables - 1) * (uint64_t)table_stride + entries));
+                     (unsigned)((uint64_t)(n_tables - 1) * (uint64_t)table_stride + entries), (const unsigned*)nullptr, (const unsigned*)nullptr,
+                     (unsigned*)nullptr);
   return check_launch("nerf_hash_encode_bwd_ws_store_tables");
 }
 
@@ -1229,8 +1329,35 @@ extern "C" int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_
                                                         float* d_table, void* workspace, size_t workspace_bytes, nerf_stream_t stream) {
   NERF_REQUIRE(n > 0 && workspace != nullptr, "nerf_hash_encode_bwd_ws_store_precounted: n=%lld, workspace %p", (long long)n, workspace);
   return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, nullptr, d_table, 0, n_levels,
-                       stream, workspace, workspace_bytes, true, true);
+                       stream, workspace, workspace_bytes, true, 1);
 }
+
+// The speculative form: NO count pass -- bin capacities from the true counts the previous call (counted or speculative, all levels,
+// on this workspace) left behind.  Call nerf_hash_encode_bwd_spec_begin before the decoder's backward (which max-accumulates the
+// largest |gradient| into the workspace's slot: nerf_imlp_bwd_amax with row-major d_feat [n, 2L] handed over here, or nerf_imlp_bwd_lm
+// with the level-major copy in the workspace and d_feat NULL), then this.  A record that does not fit its bin is
+// added with a float atomic at the end; *header (nerf_hash_encode_bwd_spec_status) tells how many, and whether any was lost.
+extern "C" int nerf_hash_encode_bwd_spec_begin(void* workspace, nerf_stream_t stream) {
+  NERF_REQUIRE(workspace != nullptr, "nerf_hash_encode_bwd_spec_begin: NULL workspace");
+  if (hipMemsetAsync(workspace, 0, sizeof(BinHeader), as_stream(stream)) != hipSuccess)
+    return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_spec_begin: memset failed");
+  return NERF_OK;
+}
+
+extern "C" int nerf_hash_encode_bwd_ws_store_spec(const float* pts, int64_t n, int n_levels, const float* scale_host,
+                                                  const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
+                                                  const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
+                                                  void* workspace, size_t workspace_bytes, nerf_stream_t stream) {
+  NERF_REQUIRE(n > 0 && workspace != nullptr, "nerf_hash_encode_bwd_ws_store_spec: n=%lld, workspace %p", (long long)n, workspace);
+  NERF_REQUIRE(!options().deterministic, "nerf_hash_encode_bwd_ws_store_spec: overflow records end in float atomics (option \"deterministic\" is set)");
+  return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table, 0, n_levels,
+                       stream, workspace, workspace_bytes, true, 2);
+}
+
+// device address of the workspace's 8-word status block: [0] items, [1] record capacity planned, [2] largest |gradient| bits,
+// [3] records that went to the overflow list, [4] != 0: records were LOST (the gradient of that call is incomplete: 1 the overflow list
+// was full, 2 the estimates did not fit the workspace), [5] capacity planned
+extern "C" const void* nerf_hash_encode_bwd_spec_status(const void* workspace) { return workspace; }
 
 static int hash_bwd_input_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
                                const float* scale_host, const unsigned* res_host, const unsigned* size_host,

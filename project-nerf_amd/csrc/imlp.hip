@@ -245,12 +245,23 @@ __global__ void __launch_bounds__(kIThreads) imlp_bwd_kernel(const IArgs a) {
         f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
         *reinterpret_cast<f32x4*>(a.d_feat + n * 32 + 8 * g + 4 * half) = v;
       }
+      if (a.amax_bits != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(acc[r]));
+      }
     });
   }
   if (a.amax_bits != nullptr) {
+    // ONE global atomic per workgroup at most, none once a larger value is visible: same-address atomics retire one after the other
+    // (~20 ns each): one per wave -- 4096 of them -- doubled this kernel's time
+    __shared__ unsigned wg_amax;
+    if (threadIdx.x == 0) wg_amax = 0;
+    __syncthreads();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-    if (lane == 0 && amax > 0.0f && amax <= 3.0e38f) atomicMax(a.amax_bits, __builtin_bit_cast(unsigned, amax));
+    if (lane == 0 && amax > 0.0f && amax <= 3.0e38f) atomicMax(&wg_amax, __builtin_bit_cast(unsigned, amax));
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_amax > __hip_atomic_load(a.amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.amax_bits, wg_amax);
   }
 }
 
@@ -355,6 +366,15 @@ extern "C" int nerf_imlp_bwd(const void* packed, void* workspace, const float* r
                              float* d_feat, nerf_stream_t stream) {
   NERF_REQUIRE(n == 0 || d_feat != nullptr, "nerf_imlp_bwd: d_feat is NULL");
   return imlp_bwd_impl(packed, workspace, rgb, sigma, d_rgb, d_sigma, n, grads_f32, d_feat, nullptr, nullptr, stream);
+}
+
+// row-major feature gradients AND their largest magnitude (amax_bits: device u32, max-accumulated fp32 bits; the caller zeroes it):
+// what the speculative hash backward needs without the level-major copy (whose stores cost this kernel 33 us on 200 k points)
+extern "C" int nerf_imlp_bwd_amax(const void* packed, void* workspace, const float* rgb, const float* sigma,
+                                  const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
+                                  float* d_feat, void* amax_bits, nerf_stream_t stream) {
+  NERF_REQUIRE(n == 0 || (d_feat != nullptr && amax_bits != nullptr), "nerf_imlp_bwd_amax: NULL output");
+  return imlp_bwd_impl(packed, workspace, rgb, sigma, d_rgb, d_sigma, n, grads_f32, d_feat, nullptr, static_cast<unsigned*>(amax_bits), stream);
 }
 
 extern "C" int nerf_imlp_bwd_lm(const void* packed, void* workspace, const float* rgb, const float* sigma,

@@ -13,6 +13,7 @@ residual (the reference's nn.MSELoss, run.py:308,334).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -257,6 +258,13 @@ class InstantNgpEngine:
         # (tools/ab_instant_precount.py: 0.699 against 0.651 ms per step -- eight LDS atomics per point and level in the
         # latency-bound forward cost more than the 0.05 ms count pass they replace): off by default
         self.precount = bool(cfg.get("precount", False))
+        # speculative hash backward (default on, single rank): NO count pass -- the bins' capacities come from the true counts of the
+        # previous step's call; records that do not fit are added with atomics by a last small launch, a lost record (never seen in
+        # training; the status block is read back one step late) switches the form off.  Used when the occupancy grid is the one
+        # the estimates were taken on and the active-sample count is within 10 % of that call's
+        self.spec_bwd = bool(cfg.get("speculative_hash_backward", True)) and not os.environ.get("NERF_NO_SPECULATIVE_BWD")   # env: A/B aid
+        self._spec_from = None          # (workspace address, occupancy-grid identity, point count) of the call that left the estimates
+        self._spec_pending = None       # (pinned status words, event) of the last speculative call
         self.table_h = torch.empty(self.table.numel(), device=self.device, dtype=torch.float16) if self.half_table else None
         self._table_version = None
         self.packed = ops.imlp_pack(self.net)
@@ -379,6 +387,10 @@ class InstantNgpEngine:
             # hands its feature gradients over level-major -- the hash backward starts at its plan pass
             precount = sync_grads_async is None and self.half_table and self.precount
             hws = self._hash_bwd_workspace(n)
+            grid_id = (self.binary_grid.data_ptr(), self.binary_grid._version)
+            spec = self._speculative_ok(hws, grid_id, n) and sync_grads_async is None and not precount
+            if spec:
+                ops._lib.check(lib.nerf_hash_encode_bwd_spec_begin(hws.data_ptr(), ops._stream()), "nerf_hash_encode_bwd_spec_begin")
             rgb, sigma, ws = self._field(pts, dirs, True, hist_ws=hws if precount else None)
             P = lambda t: t.data_ptr()
             # a fresh zeroed loss slot per step out of a ring cleared once per lap (no fill launch per step)
@@ -388,16 +400,29 @@ class InstantNgpEngine:
                 self._loss_ring.zero_()
             loss = self._loss_ring[slot:slot + 1]
             d_rgb, d_sigma, _ = ops.composite_mse_bwd(rgb, sigma, z, rays_d, self.bg, target, loss, slots=slots)
-            if precount:
+            if precount or spec:
                 import ctypes
                 amax_p, lm_p = ctypes.c_void_p(), ctypes.c_void_p()
                 ops._lib.check(lib.nerf_hash_encode_bwd_ws_slots(P(hws), n, self.levels.n_levels, ctypes.byref(amax_p), ctypes.byref(lm_p)),
                                "nerf_hash_encode_bwd_ws_slots")
+                # the decoder's backward hands its feature gradients over level-major and max-accumulates their largest magnitude
                 ops._lib.check(lib.nerf_imlp_bwd_lm(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(self.g_net),
                                                     lm_p, amax_p, ops._stream()), "nerf_imlp_bwd_lm")
-                ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_precounted(P(pts), n, self.levels.n_levels, *self.levels.host_args(),
-                                                                            float(self.bound), P(self.g_table), P(hws), hws.numel(),
-                                                                            ops._stream()), "nerf_hash_encode_bwd_ws_store_precounted")
+                if spec:                           # no count pass: capacities from the last call's true counts
+                    ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_spec(P(pts), n, self.levels.n_levels, *self.levels.host_args(),
+                                                                          float(self.bound), None, P(self.g_table), P(hws), hws.numel(),
+                                                                          ops._stream()), "nerf_hash_encode_bwd_ws_store_spec")
+                else:
+                    ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_precounted(P(pts), n, self.levels.n_levels, *self.levels.host_args(),
+                                                                                float(self.bound), P(self.g_table), P(hws), hws.numel(),
+                                                                                ops._stream()), "nerf_hash_encode_bwd_ws_store_precounted")
+                self._spec_from = (hws.data_ptr(), grid_id, n)
+                if spec:                           # status words read back without waiting: checked before the next speculative call
+                    status = torch.empty(8, dtype=torch.int32, pin_memory=True)
+                    status.copy_(hws[:32].view(torch.int32), non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._spec_pending = (status, ev)
                 return loss[0].clone()
             d_feat = torch.empty(n, 2 * self.levels.n_levels, device=self.device)
             ops._lib.check(lib.nerf_imlp_bwd(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
@@ -406,6 +431,7 @@ class InstantNgpEngine:
             # overwrite form: the table gradient is stored slice by slice -- no 52 MB memset, no read-back
             if sync_grads_async is None:
                 ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, workspace=hws, overwrite=True)
+                self._spec_from = (hws.data_ptr(), grid_id, n)      # the counted call left the bins' true counts in the workspace
             else:
                 for lo, hi in self.level_groups():
                     ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, level_range=(lo, hi), workspace=hws, overwrite=True)
@@ -417,6 +443,23 @@ class InstantNgpEngine:
             if wire is not None:
                 view.copy_(wire)
         return loss
+
+    def _speculative_ok(self, hws: Tensor, grid_id, n: int) -> bool:
+        """may this step's hash backward trust the record counts the last call left in the workspace?"""
+        if not (self.spec_bwd and self.half_table) or ops.deterministic() or self._spec_from is None:
+            return False
+        if self._spec_pending is not None:
+            status, ev = self._spec_pending
+            if ev.query():
+                self._spec_pending = None
+                if int(status[4]) != 0:
+                    import warnings
+                    warnings.warn(f"speculative hash backward: records were lost (status {status.tolist()}): one step's table gradient was "
+                                  "incomplete; the counted form is used from here on")
+                    self.spec_bwd = False
+                    return False
+        ws_ptr, last_grid, n_last = self._spec_from
+        return ws_ptr == hws.data_ptr() and last_grid == grid_id and 0.5 * n_last <= n <= 1.1 * n_last
 
     def _hash_bwd_workspace(self, n: int) -> Tensor:
         """Workspace of the binned hash-gradient scatter, grown to the largest point count seen (8 B per corner

@@ -681,3 +681,120 @@ def test_hash_backward_tables_form_equals_one_pass_per_table(ops, n=9000):
     for k in range(3):
         ops.hash_encode_fwd_nat(pts, tabs[k * E:(k + 1) * E], t, 1.5, one[k], fp16=True)
     assert torch.equal(img, one)
+
+
+def _spec_call(ops, lib, pts, levels, d_feat, g_table, ws, row_major=True):
+    """nerf_hash_encode_bwd_spec_begin -> the producer's outputs (largest |gradient| bits, level-major gradients) written into the
+    workspace's slots the way nerf_imlp_bwd_lm does -> nerf_hash_encode_bwd_ws_store_spec; returns the status words"""
+    import ctypes
+    n, L = pts.shape[0], levels.n_levels
+    st = torch.cuda.current_stream().cuda_stream
+    ops._lib.check(lib.nerf_hash_encode_bwd_spec_begin(ws.data_ptr(), st), "spec_begin")
+    amax_p, lm_p = ctypes.c_void_p(), ctypes.c_void_p()
+    ops._lib.check(lib.nerf_hash_encode_bwd_ws_slots(ws.data_ptr(), n, L, ctypes.byref(amax_p), ctypes.byref(lm_p)), "slots")
+    a_off, l_off = amax_p.value - ws.data_ptr(), lm_p.value - ws.data_ptr()
+    ws[a_off:a_off + 4].view(torch.float32).copy_(d_feat.abs().max().reshape(1))            # fp32 bits of the largest |gradient|
+    ws[l_off:l_off + n * L * 8].view(torch.float32).view(L, n, 2).copy_(d_feat.view(n, L, 2).permute(1, 0, 2))
+    # level-major gradients in the workspace (d_feat NULL) or row-major ones handed over: both forms
+    ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_spec(pts.data_ptr(), n, L, *levels.host_args(), 1.5, d_feat.data_ptr() if row_major else None,
+                                                          g_table.data_ptr(), ws.data_ptr(), ws.numel(), st), "store_spec")
+    return ws[:32].view(torch.int32).cpu().tolist()
+
+
+@pytest.mark.gpu
+def test_hash_backward_speculative_form(ops):
+    """nerf_hash_encode_bwd_ws_store_spec (no count pass; bin capacities from the previous call's true counts):
+    the same batch again -> every record fits, integer sums: BIT-equal to the counted form; a batch 8 % larger at other positions
+    -> the few records past their bins' capacities arrive through the overflow list (float atomics): equal to 1e-6; estimates from a
+    batch a sixth of the size -> most records overflow: equal while the list holds them, flagged as lost when it does not."""
+    lib = ops._lib.load()
+    t = ops.HashLevelTable(16, 19, 16, 1.5)
+    gen = torch.Generator().manual_seed(77)
+
+    def batch(n, seed):
+        g = torch.Generator().manual_seed(seed)
+        # samples along rays through the box: coherent like a training batch (runs of samples per coarse cell)
+        o = torch.nn.functional.normalize(torch.randn(n // 16, 1, 3, generator=g), dim=-1) * 1.3
+        d = torch.nn.functional.normalize(torch.randn(n // 16, 1, 3, generator=g), dim=-1)
+        pts = (o * 0.3 + d * torch.linspace(-1.0, 1.0, 16).view(1, 16, 1)).reshape(-1, 3)
+        return pts.cuda().contiguous(), (torch.randn(pts.shape[0], 32, generator=g) * 1e-3).cuda()
+    n = 48000
+    pts, d_feat = batch(n, 1)
+    ws = torch.empty(ops.hash_encode_bwd_workspace_bytes(int(n * 1.1), 16), dtype=torch.uint8, device="cuda")
+    ref = torch.full((t.entries, 2), float("nan"), device="cuda")
+    ops.hash_encode_bwd(pts, t, 1.5, d_feat, ref, workspace=ws, overwrite=True)           # counted: leaves the bins' true counts
+    out = torch.full_like(ref, float("nan"))
+    status = _spec_call(ops, lib, pts, t, d_feat, out, ws)
+    assert status[3] == 0 and status[4] == 0, status
+    # cut bins (the coarse dense levels) meet through float atomics in both forms; everything else is stored from integer sums
+    assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    assert float((out != ref).float().mean()) < 0.02
+    # another, larger batch on the same estimates
+    pts2, d_feat2 = batch(int(n * 1.08) // 16 * 16, 2)
+    ref2 = torch.full_like(ref, float("nan"))
+    ws_b = torch.empty_like(ws)
+    ops.hash_encode_bwd(pts2, t, 1.5, d_feat2, ref2, workspace=ws_b, overwrite=True)
+    out2 = torch.full_like(ref, float("nan"))
+    status = _spec_call(ops, lib, pts2, t, d_feat2, out2, ws)
+    print(f"[speculative hash backward] +8 % batch at other positions: {status[3]} of {pts2.shape[0] * 128} records overflowed, lost {status[4]}")
+    assert status[4] == 0 and bool(torch.isfinite(out2).all())
+    assert float((out2 - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max())
+    # ... and that call left ITS counts: the same batch again overflows nothing (level-major gradients this time)
+    status = _spec_call(ops, lib, pts2, t, d_feat2, out2, ws, row_major=False)
+    assert status[3] == 0 and status[4] == 0 and float((out2 - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max())
+    # estimates from a much smaller batch: heavy overflow
+    pts3, d_feat3 = batch(8000, 3)
+    tmp = torch.empty_like(ref)
+    ops.hash_encode_bwd(pts3, t, 1.5, d_feat3, tmp, workspace=ws, overwrite=True)
+    out3 = torch.full_like(ref, float("nan"))
+    status = _spec_call(ops, lib, pts, t, d_feat, out3, ws)
+    print(f"[speculative hash backward] estimates of a batch a sixth of the size: {status[3]} records overflowed, lost flag {status[4]}")
+    assert status[3] > 0
+    if status[4] == 0:
+        assert float((out3 - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+    else:
+        assert status[3] > (1 << 20)                                      # the list was full: flagged, never silent
+
+
+@pytest.mark.gpu
+def test_instant_engine_speculative_backward_equals_counted_backward():
+    """InstantNgpEngine with `speculative_hash_backward` (default): the first step counts, the following steps on the same occupancy
+    grid take the speculative form; losses, network gradients and table gradients against an engine that counts every step."""
+    import yaml
+    from conftest import ROOT
+    from project_nerf_amd.engine import InstantNgpEngine
+    ops_mod = __import__("project_nerf_amd").ops
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "part2_instant.yaml.example")))
+    R, S = 2048, 64
+    gen = torch.Generator().manual_seed(4)
+    o = torch.randn(R, 3, generator=gen)
+    o = (o / o.norm(dim=-1, keepdim=True) * 4.0311).cuda()
+    d = ((torch.rand(R, 3, generator=gen) - 0.5) * 1.6).cuda() - o
+    d = (d / d.norm(dim=-1, keepdim=True)).contiguous()
+    target = torch.rand(R, 3, generator=gen).cuda()
+    ax = torch.linspace(-1.5, 1.5, 128)
+    gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing="ij")
+    grid = ((gx ** 2 + gy ** 2 + gz ** 2) < 1.2 ** 2).cuda()
+    runs = []
+    for spec in (True, False):
+        eng = InstantNgpEngine(dict(cfg, speculative_hash_backward=spec), seed=0)
+        eng.table.copy_((torch.rand(eng.table.numel(), generator=torch.Generator().manual_seed(5)) - 0.5).cuda())
+        eng.net[2048:2048 + 64] *= 20.0
+        ops_mod.imlp_pack(eng.net, eng.packed)
+        eng.binary_grid = grid
+        rec, used = [], 0
+        for step in range(4):
+            u = torch.rand(R, S, generator=torch.Generator().manual_seed(100 + step)).cuda()
+            eng.g_table.fill_(float("nan"))
+            loss = float(eng.compute_gradients(o, d, target, S, u=u))
+            used += eng._spec_pending is not None and spec
+            rec.append((loss, eng.g_net.clone(), eng.g_table.clone()))
+        runs.append(rec)
+        if spec:
+            assert eng._spec_from is not None and used >= 2, used                 # steps 2.. took the speculative form
+            torch.cuda.synchronize()
+            assert int(eng._spec_pending[0][4]) == 0
+    for (l1, n1, t1), (l0, n0, t0) in zip(*runs):
+        assert abs(l1 - l0) < 1e-6 * max(l0, 1.0) and bool(torch.isfinite(t1).all())
+        assert float((n1 - n0).abs().max()) <= 1e-5 * float(n0.abs().max())
+        assert float((t1 - t0).abs().max()) <= 2e-6 * float(t0.abs().max())
