@@ -567,6 +567,19 @@ int nerf_adamw_clip_step_tv(float* params, const float* grads, float* exp_avg, f
                             float tv_weight_hi, int64_t seg_hi, int64_t lr_split, float lr_hi, void* params_f16_out,
                             nerf_stream_t stream);
 
+/* ... and on a PIECE [params, params + n) of ONE table of table_elems elements: the sharded optimiser of the data-parallel engines
+ * (reduce-scatter the table gradient, every rank steps its 1/N slice, all-gather the fp16 copy the forward reads).
+ * halo bit 0: params[-1] belongs to the same table and holds its current value (one element exchanged per seam and step), bit 1:
+ * params[n] does -- the TV terms at the piece's ends then equal the whole-table pass.  tv_codes points at the piece's first code
+ * byte inside a buffer with at least one byte before it.  n a multiple of 4, 16-byte aligned pointers.  normsq_dev accumulates the
+ * piece's part: the ranks' parts are summed by ONE scalar all-reduce before the AdamW launches. */
+int nerf_tv_normsq_codes_piece(const float* params, const float* grads, int64_t n, int64_t table_elems, int halo, float tv_weight,
+                               float grad_scale, float* normsq_dev, void* tv_codes, nerf_stream_t stream);
+int nerf_adamw_clip_step_tv_piece(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, const float* normsq_dev, float max_norm,
+                                  float grad_scale, const void* tv_codes, float tv_weight, int64_t table_elems, int halo_lo,
+                                  void* params_f16_out, nerf_stream_t stream);
+
 /* ---- f3: Part 4 dual-hash dynamic field (csrc/p4mlp.hip) ------------------------------------------------------
  * replaces, for NeuralField(mode part4).forward (src/core.py:282-352), the tinycudann FullyFusedMLP networks
  * HashDeformationDecoder.deform_net (src/decoders.py:285-295, 313-316) and InstantNeRFDecoder at pos_dim 32 + 21

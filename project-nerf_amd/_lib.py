@@ -116,6 +116,9 @@ PROTOTYPES = {
     "nerf_tv_normsq_codes": (i32, [c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_adamw_clip_step_tv": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, i64, f32, i64,
                                       f32, i64, i64, f32, c_ptr, c_ptr]),
+    "nerf_tv_normsq_codes_piece": (i32, [c_ptr, c_ptr, i64, i64, i32, f32, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_adamw_clip_step_tv_piece": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, f32, i64, i32,
+                                            c_ptr, c_ptr]),
     "nerf_adamw_clip_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr]),
     "nerf_adamw_clip_step_shadow": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, c_ptr]),
 }

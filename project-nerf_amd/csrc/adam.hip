@@ -225,7 +225,9 @@ constexpr int kTvFastThreads = 1024;
 template <bool TV>
 __global__ void __launch_bounds__(kTvFastThreads)
 tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict__ g, int n4, float tv_scale, float grad_scale,
-                            float* __restrict__ normsq, int seg, uint8_t* __restrict__ codes) {
+                            float* __restrict__ normsq, int seg, uint8_t* __restrict__ codes, int halo) {
+  // halo (a PIECE of one table: the sharded optimiser's slice): bit 0 -- p[-1] belongs to the same table, bit 1 -- p[n] does; the
+  // piece's first TV term then reaches back to p[-1] (its sign is also left in codes[-1] for the AdamW pass), its last one on to p[n]
   constexpr int kU = 4;
   const f4* __restrict__ p4 = reinterpret_cast<const f4*>(p);
   const f4* __restrict__ g4 = reinterpret_cast<const f4*>(g);
@@ -240,8 +242,8 @@ tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict
       a[u] = p4[q];
       b[u] = g4[q];
       if (TV) {
-        lo[u] = p[max(4 * q - 1, 0)];
-        hi[u] = p[min(4 * q + 4, n - 1)];
+        lo[u] = p[max(4 * q - 1, (halo & 1) ? -1 : 0)];
+        hi[u] = p[min(4 * q + 4, (halo & 2) ? n : n - 1)];
       }
     }
 #pragma unroll
@@ -250,9 +252,9 @@ tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict
       if (q >= n4) break;
       float g0, g1, g2, g3;
       if (TV) {
-        const bool first = e0 == 0 || e0 == seg || e0 == 2 * seg || e0 == 3 * seg;
+        const bool first = (e0 == 0 && !(halo & 1)) || e0 == seg || e0 == 2 * seg || e0 == 3 * seg;
         const int e4 = e0 + 4;
-        const bool last = e4 == n || e4 == seg || e4 == 2 * seg || e4 == 3 * seg;
+        const bool last = (e4 == n && !(halo & 2)) || (e4 != n && (e4 == seg || e4 == 2 * seg || e4 == 3 * seg));
         const int s_in = first ? 0 : (int)sgn(a[u][0] - lo[u]), s0 = (int)sgn(a[u][1] - a[u][0]), s1 = (int)sgn(a[u][2] - a[u][1]),
                   s2 = (int)sgn(a[u][3] - a[u][2]), s3 = last ? 0 : (int)sgn(hi[u] - a[u][3]);
         g0 = b[u][0] * grad_scale + tv_scale * (float)(s_in - s0);
@@ -260,6 +262,7 @@ tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict
         g2 = b[u][2] * grad_scale + tv_scale * (float)(s1 - s2);
         g3 = b[u][3] * grad_scale + tv_scale * (float)(s2 - s3);
         codes[q] = (uint8_t)((s0 + 1) | ((s1 + 1) << 2) | ((s2 + 1) << 4) | ((s3 + 1) << 6));
+        if (q == 0 && (halo & 1)) codes[-1] = (uint8_t)((s_in + 1) << 6);      // the sign the AdamW pass reads as the piece's s[-1]
       } else {
         g0 = b[u][0] * grad_scale; g1 = b[u][1] * grad_scale; g2 = b[u][2] * grad_scale; g3 = b[u][3] * grad_scale;
       }
@@ -285,7 +288,7 @@ adamw_clip_tv_kernel(float* __restrict__ p, const float* __restrict__ g, float* 
                      float lr, float beta1, float beta2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2,
                      const float* __restrict__ normsq, float max_norm, float grad_scale, const uint8_t* __restrict__ codes,
                      int64_t tv_split, float tv_scale_lo, float tv_scale_hi, _Float16* __restrict__ shadow, int vec,
-                     int64_t lr_split, float lr_hi) {
+                     int64_t lr_split, float lr_hi, int halo_lo) {
   float clip = 1.0f;
   if (normsq != nullptr && max_norm > 0.0f) {
     const float coef = max_norm / (sqrtf(*normsq) + 1e-6f);       // torch clip_grad_norm_; normsq is of the scaled gradient + TV term
@@ -312,7 +315,7 @@ adamw_clip_tv_kernel(float* __restrict__ p, const float* __restrict__ g, float* 
     unsigned byte = 0x55u;                       // all codes 1 = sign 0
     if (codes != nullptr) {
       byte = codes[q];
-      s_prev = q > 0 ? (int)(codes[q - 1] >> 6) - 1 : 0;
+      s_prev = (q > 0 || halo_lo) ? (int)(codes[q - 1] >> 6) - 1 : 0;      // halo_lo: a piece inside a table, codes[-1] holds s[-1]
     }
     const float tv_scale = e0 < tv_split ? tv_scale_lo : tv_scale_hi;       // the splits are multiples of 4: one choice per chunk
     const float lr_q = e0 < lr_split ? lr : lr_hi;
@@ -466,10 +469,10 @@ extern "C" int nerf_tv_normsq_codes(const float* params, const float* grads, int
   if (fblocks < 1) fblocks = 1;
   if (fast && tv_scale != 0.0f)
     hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<true>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
-                       params, grads, (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)seg, codes);
+                       params, grads, (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)seg, codes, 0);
   else if (fast)
     hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<false>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
-                       params, grads, (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)seg, codes);
+                       params, grads, (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)seg, codes, 0);
   else
     hipLaunchKernelGGL(nerf::tv_normsq_codes_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n, tv_scale,
                        grad_scale, normsq_dev, seg, codes);
@@ -496,6 +499,52 @@ extern "C" int nerf_adamw_clip_step_tv(float* params, const float* grads, float*
   hipLaunchKernelGGL(nerf::adamw_clip_tv_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, exp_avg, exp_avg_sq,
                      n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale,
                      static_cast<const uint8_t*>(tv_codes), tv_split, lo, hi, static_cast<_Float16*>(params_f16_out), vec,
-                     lr_split <= 0 ? n : lr_split, lr_hi);
+                     lr_split <= 0 ? n : lr_split, lr_hi, 0);
   return nerf::check_launch("nerf_adamw_clip_step_tv");
+}
+
+// ---- the same two passes on a PIECE [params, params + n) of ONE table of table_elems elements (the sharded optimiser of the
+// data-parallel engines: every rank steps its slice of the flat table buffer).  halo bit 0: params[-1] belongs to the same table and
+// holds its current value, bit 1: params[n] does -- the TV terms at the piece's ends then equal the whole-table pass.  tv_codes points
+// at the piece's first code byte inside a buffer that has at least one byte before it (codes[-1] receives the sign of
+// params[0] - params[-1]).  n a multiple of 4, 16-byte aligned pointers.
+extern "C" int nerf_tv_normsq_codes_piece(const float* params, const float* grads, int64_t n, int64_t table_elems, int halo, float tv_weight,
+                                          float grad_scale, float* normsq_dev, void* tv_codes, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && normsq_dev && table_elems >= n && halo >= 0 && halo <= 3, "nerf_tv_normsq_codes_piece: bad arguments");
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(params && grads && (tv_weight == 0.0f || tv_codes), "nerf_tv_normsq_codes_piece: NULL pointer");
+  NERF_REQUIRE((((uintptr_t)params | (uintptr_t)grads) & 15) == 0 && n % 4 == 0 && n < ((int64_t)1 << 31) - 16,
+               "nerf_tv_normsq_codes_piece: 16-byte aligned pointers and n a multiple of 4");
+  const float tv_scale = table_elems > 1 ? tv_weight / (float)(table_elems - 1) : 0.0f;
+  int n_cu = 256;
+  (void)nerf::device_cu_count(&n_cu);
+  int64_t fblocks = (n / 4 + 4 * nerf::kTvFastThreads - 1) / (4 * nerf::kTvFastThreads);
+  if (fblocks > n_cu) fblocks = n_cu;
+  if (tv_scale != 0.0f)
+    hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<true>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
+                       params, grads, (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)n, static_cast<uint8_t*>(tv_codes), halo);
+  else
+    hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<false>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
+                       params, grads, (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)n, static_cast<uint8_t*>(tv_codes), 0);
+  return nerf::check_launch("nerf_tv_normsq_codes_piece");
+}
+
+extern "C" int nerf_adamw_clip_step_tv_piece(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                                             float lr, float beta1, float beta2, float eps, float weight_decay, const float* normsq_dev,
+                                             float max_norm, float grad_scale, const void* tv_codes, float tv_weight, int64_t table_elems,
+                                             int halo_lo, void* params_f16_out, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && step >= 1 && table_elems >= n, "nerf_adamw_clip_step_tv_piece: n=%lld step=%d", (long long)n, step);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq, "nerf_adamw_clip_step_tv_piece: NULL pointer");
+  NERF_REQUIRE(params_f16_out == nullptr || ((uintptr_t)params_f16_out & 7) == 0, "nerf_adamw_clip_step_tv_piece: params_f16_out unaligned");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float sc = (tv_codes && table_elems > 1) ? tv_weight / (float)(table_elems - 1) : 0.0f;
+  int64_t blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  const int vec = nerf::aligned16(params, grads, exp_avg, exp_avg_sq);
+  hipLaunchKernelGGL(nerf::adamw_clip_tv_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, exp_avg, exp_avg_sq,
+                     n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), normsq_dev, max_norm, grad_scale,
+                     static_cast<const uint8_t*>(tv_codes), n, sc, sc, static_cast<_Float16*>(params_f16_out), vec, n, lr,
+                     (tv_codes && halo_lo) ? 1 : 0);
+  return nerf::check_launch("nerf_adamw_clip_step_tv_piece");
 }

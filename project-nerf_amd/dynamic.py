@@ -250,9 +250,16 @@ def run_dynamic(cfg, args):
         parallel.broadcast_([eng.tables, eng.net, eng.grid, eng.binary_grid])
         eng.repack()
         sync_async = parallel.allreduce_sum_async if world > 1 else None
+        if world > 1 and cfg.get("dp_sharded_optimizer", True):
+            # reduce-scatter of the flat table gradient, every rank steps its 1/N slice of the four grids (TV + ONE
+            # squared norm + AdamW), all-gather of the fp16 copies the forward reads (project-nerf_amd/sharded.py)
+            eng.enable_sharded_optimizer(rank)
+            sync_async = None
+            say(f">>> sharded optimiser: every rank steps {eng.shard.per} of {eng.tables.numel()} table parameters")
         pixels = train_set.H * train_set.W
 
         def sync():
+            eng.gather_master()                             # sharded optimiser: the other ranks' slices of the fp32 master
             eng.copy_to_model(model)
             grid.grid, grid.binary_grid = eng.grid.clone(), eng.binary_grid.clone()
 
@@ -291,6 +298,7 @@ def run_dynamic(cfg, args):
                     best = v
                     save_best(step, best)
         if world > 1:
+            eng.gather_master()
             say(f">>> replica divergence after {iters} steps: {parallel.replica_divergence([eng.tables, eng.net, eng.binary_grid]):.3e}")
         sync()
     elif not args.eval_only:

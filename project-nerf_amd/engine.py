@@ -235,7 +235,15 @@ class InstantNgpEngine:
         self.levels = ops.HashLevelTable(cfg.get("n_levels", 16), cfg.get("log2_hashmap_size", 19),
                                          cfg.get("base_resolution", 16), cfg.get("per_level_scale", 1.5))
         g = torch.Generator().manual_seed(seed)
-        self.table = ((torch.rand(self.levels.entries * 2, generator=g) * 2 - 1) * 1e-4).to(self.device)
+        # the table's buffers are allocated padded to world equal slices of whole 1024-element blocks (sharded optimiser:
+        # project-nerf_amd/sharded.py); the views below are the table itself
+        from .sharded import padded_length
+        n_tab = self.levels.entries * 2
+        n_pad = padded_length(n_tab, max(int(world_size), 1))
+        self._table_buf = torch.zeros(n_pad, device=self.device)
+        self._table_buf[:n_tab] = ((torch.rand(n_tab, generator=g) * 2 - 1) * 1e-4).to(self.device)
+        self.table = self._table_buf[:n_tab]
+        self.shard = None
 
         def xavier(rows, cols, fi, fo):
             return (torch.rand(rows, cols, generator=g) * 2 - 1) * (6.0 / (fi + fo)) ** 0.5
@@ -245,8 +253,10 @@ class InstantNgpEngine:
         w3[3:] = 0
         self.net = torch.cat([xavier(64, 32, 32, 64).reshape(-1), xavier(16, 64, 64, 16).reshape(-1), w1.reshape(-1),
                               xavier(64, 64, 64, 64).reshape(-1), w3.reshape(-1)]).to(self.device)
-        self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in (("table", self.table), ("net", self.net))}
-        self.g_table = torch.zeros_like(self.table)
+        self._m_buf, self._v_buf = torch.zeros(n_pad, device=self.device), torch.zeros(n_pad, device=self.device)
+        self.state = {"table": (self._m_buf[:n_tab], self._v_buf[:n_tab]), "net": (torch.zeros_like(self.net), torch.zeros_like(self.net))}
+        self._g_table_buf = torch.zeros(n_pad, device=self.device)
+        self.g_table = self._g_table_buf[:n_tab]
         self.g_net = torch.empty_like(self.net)
         self._hash_ws = None
         # fp16 copy of the table for the forward gathers (tinycudann evaluates its grid from fp16 parameters next to
@@ -265,7 +275,8 @@ class InstantNgpEngine:
         self.spec_bwd = bool(cfg.get("speculative_hash_backward", True)) and not os.environ.get("NERF_NO_SPECULATIVE_BWD")   # env: A/B aid
         self._spec_from = None          # (workspace address, occupancy-grid identity, point count) of the call that left the estimates
         self._spec_pending = None       # (pinned status words, event) of the last speculative call
-        self.table_h = torch.empty(self.table.numel(), device=self.device, dtype=torch.float16) if self.half_table else None
+        self._table_h_buf = torch.zeros(n_pad, device=self.device, dtype=torch.float16) if self.half_table else None
+        self.table_h = self._table_h_buf[:n_tab] if self.half_table else None
         self._table_version = None
         self.packed = ops.imlp_pack(self.net)
         self.near, self.far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
@@ -280,6 +291,7 @@ class InstantNgpEngine:
         self.binary_grid = torch.ones(res, res, res, dtype=torch.bool, device=self.device)
         self.step_count, self.world_size = 0, world_size
         self._scratch = ops.normsq_ws(self.device)
+        self._net_scratch = ops.normsq_ws(self.device)
         self._loss_ring = torch.zeros(1024, device=self.device)
 
     def lr(self) -> float:
@@ -337,7 +349,23 @@ class InstantNgpEngine:
                                         jitter=jitter, first_ray=first_ray)
 
     def compute_gradients(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
-                          u: Optional[Tensor] = None, sync_grads_async=None, reduce_dtype=None, prepared=None) -> Tensor:
+                          u: Optional[Tensor] = None, sync_grads_async=None, reduce_dtype=None, prepared=None,
+                          shard_grads: bool = False) -> Tensor:
+        """``shard_grads`` (after enable_sharded_optimizer): the local gradients as on one GPU, then ONE reduce-scatter of the table
+        gradient (this rank ends with the summed gradient of its slice) and the tiny MLPs' small all-reduce -- the same two
+        collectives on every rank whatever its shard held.  Otherwise see _compute_gradients."""
+        if shard_grads and self.shard is not None:
+            import torch.distributed as dist
+            loss = self._compute_gradients(rays_o, rays_d, target, n_samples, u=u, prepared=prepared)
+            self.shard.reduce_scatter_grads()
+            if self.world_size > 1:
+                dist.all_reduce(self.g_net, op=dist.ReduceOp.SUM)
+            return loss
+        return self._compute_gradients(rays_o, rays_d, target, n_samples, u=u, sync_grads_async=sync_grads_async, reduce_dtype=reduce_dtype,
+                                       prepared=prepared)
+
+    def _compute_gradients(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
+                           u: Optional[Tensor] = None, sync_grads_async=None, reduce_dtype=None, prepared=None) -> Tensor:
         """Forward + backward of one batch (reference run.py:579-619): fills ``g_table`` / ``g_net`` with the
         gradients of the LOCAL mean-squared error and returns the loss.  ``sync_grads_async(view)`` (data
         parallel) starts the all-reduce of a finished gradient range and returns a handle: the tiny-MLP
@@ -470,6 +498,24 @@ class InstantNgpEngine:
             self._hash_ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=self.device)
         return self._hash_ws
 
+    def enable_sharded_optimizer(self, rank: int) -> None:
+        """Data parallelism as SURVEY 8(e) specifies for the table (project-nerf_amd/sharded.py): reduce-scatter of the table
+        gradient, this rank steps its 1/world slice, the fp16 copy the forward reads is all-gathered.  Call once, after the replicas'
+        parameters were made equal; compute_gradients(shard_grads=True) + apply_gradients() then take this path."""
+        from .sharded import ShardedTableOptimizer
+        if not self.half_table:
+            raise ValueError("the sharded optimiser all-gathers the fp16 copy of the table: half_table must stay on")
+        self._gather_table()
+        n = self.table.numel()
+        self.shard = ShardedTableOptimizer([(0, n, self.tv_weight)], n, rank, self.world_size, self._table_buf, self._g_table_buf,
+                                           self._m_buf, self._v_buf, self._table_h_buf)
+
+    def gather_master(self) -> None:
+        """sharded optimiser: bring the fp32 master copy of every slice up to date on this rank (checkpoints, validation)"""
+        if self.shard is not None:
+            self.shard.gather_master()
+            self._table_version = self.table._version
+
     def apply_gradients(self) -> None:
         """TV-L1 + global-norm clip + AdamW on the table, clip + AdamW on the tiny MLPs, cosine LR
         (reference run.py:611-630).  After a summing all-reduce the DATA gradient is averaged (1/world);
@@ -477,6 +523,22 @@ class InstantNgpEngine:
         lr = self.lr()
         self.step_count += 1
         scale = 1.0 / self.world_size
+        if self.shard is not None:
+            # the table group sharded over the ranks: this rank's slice of TV + norm and of clip + AdamW, ONE scalar all-reduce
+            # for the table's squared norm; the tiny MLPs (their own clip, reference run.py:624-627) stepped on every rank
+            import torch.distributed as dist
+            normsq = self._scratch
+            normsq[:2].zero_()
+            self.shard.accumulate_normsq(normsq, scale)
+            if self.world_size > 1:
+                dist.all_reduce(normsq[0:1], op=dist.ReduceOp.SUM)
+            self.shard.adamw(normsq, self.step_count, lr, self.wd, 1.0, scale)
+            ops.tv_clip_adamw_step(self.net, self.g_net, *self.state["net"], self.step_count, lr, max_norm=1.0,
+                                   weight_decay=self.wd, grad_scale=scale, scratch=self._net_scratch)
+            self.shard.exchange()
+            self._table_version = self.table._version      # the fp16 copy is current (all-gathered); the fp32 master only in this slice
+            ops.imlp_pack(self.net, self.packed)
+            return
         if getattr(self, "_tv_codes", None) is None:
             self._tv_codes = torch.empty((self.table.numel() + 3) // 4, dtype=torch.uint8, device=self.device)
         ops.tv_clip_adamw_step(self.table, self.g_table, *self.state["table"], self.step_count, lr, tv_weight=self.tv_weight,
@@ -489,8 +551,8 @@ class InstantNgpEngine:
     def train_step(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, n_samples: int = 128,
                    u: Optional[Tensor] = None, sync_grads=None, sync_grads_async=None, reduce_dtype=None, prepared=None) -> Tensor:
         loss = self.compute_gradients(rays_o, rays_d, target, n_samples, u=u, sync_grads_async=sync_grads_async,
-                                      reduce_dtype=reduce_dtype, prepared=prepared)
-        if sync_grads is not None:                # blocking form: two collectives after the backward pass
+                                      reduce_dtype=reduce_dtype, prepared=prepared, shard_grads=self.shard is not None)
+        if sync_grads is not None and self.shard is None:                # blocking form: two collectives after the backward pass
             sync_grads(self.g_table)
             sync_grads(self.g_net)
         self.apply_gradients()

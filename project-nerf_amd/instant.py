@@ -125,8 +125,16 @@ def run_instant(cfg, args):
         # squared norm summed in a fixed order, replicated occupancy-grid updates)
         parallel.broadcast_([eng.table, eng.net, eng.grid, eng.binary_grid])
         eng.packed = ops.imlp_pack(eng.net)
+        sharded = world > 1 and cfg.get("dp_sharded_optimizer", True) and eng.half_table
+        if sharded:
+            # reduce-scatter of the table gradient, every rank steps its 1/N slice of the table (TV + norm + AdamW),
+            # all-gather of the fp16 copy the forward reads (project-nerf_amd/sharded.py); `dp_sharded_optimizer: false`: the
+            # replicated optimiser (all-reduce of the whole table gradient, level group by level group)
+            eng.enable_sharded_optimizer(rank)
+            say(f">>> sharded optimiser: every rank steps {eng.shard.per} of {eng.table.numel()} table parameters")
 
         def sync():
+            eng.gather_master()                              # sharded optimiser: the other ranks' slices of the fp32 master
             with torch.no_grad():
                 model.representation.encoding.params.copy_(eng.table)
                 model.decoder.sigma_net.params.copy_(eng.net[:model.decoder.sigma_net.params.numel()])
@@ -149,7 +157,8 @@ def run_instant(cfg, args):
                 ahead.append(draw())
             o, d, target, prepared = ahead.pop()
             ahead.append(draw())
-            loss_rgb = eng.train_step(o, d, target, n_samples, prepared=prepared, sync_grads_async=sync_async, reduce_dtype=wire)
+            loss_rgb = eng.train_step(o, d, target, n_samples, prepared=prepared, sync_grads_async=None if sharded else sync_async,
+                                      reduce_dtype=wire)
             if step < iters * stop:
                 interval = 32 if step < iters * 0.1 else (128 if step < iters * 0.5 else 512)
                 if step >= warm and step % interval == 0:
@@ -168,6 +177,7 @@ def run_instant(cfg, args):
                     torch.save({"model_state_dict": model.state_dict(), "config": cfg, "step": step, "val_psnr": best,
                                 "density_grid": grid.state_dict()}, os.path.join(log_dir, "best_model.pth"))
         if world > 1:
+            eng.gather_master()
             say(f">>> replica divergence after {iters} steps: {parallel.replica_divergence([eng.table, eng.net, eng.binary_grid]):.3e}")
         sync()
     elif not args.eval_only:

@@ -244,15 +244,23 @@ class DualHashEngine:
         self.table_offsets = [0, nd, 2 * nd, 3 * nd]
         total = 3 * nd + nc
         g = torch.Generator().manual_seed(seed)
-        # ONE flat buffer for the four grids (start | mid | end | canonical): one memset, one AdamW launch
-        self.tables = ((torch.rand(total, generator=g) * 2 - 1) * 1e-4).to(self.device)
-        self.tables_h = torch.empty(total, dtype=torch.float16, device=self.device)
-        self.g_tables = torch.zeros(total, device=self.device)
+        # ONE flat buffer for the four grids (start | mid | end | canonical): one memset, one AdamW launch.  The buffers are allocated
+        # padded to world equal slices of whole 1024-element blocks (the sharded optimiser's reduce-scatter / all-gather); the views
+        # below are the tables themselves
+        from .sharded import padded_length
+        n_pad = padded_length(total, max(self.world_size, 1))
+        self._tables_buf = torch.zeros(n_pad, device=self.device)
+        self._tables_buf[:total] = ((torch.rand(total, generator=g) * 2 - 1) * 1e-4).to(self.device)
+        self._tables_h_buf = torch.zeros(n_pad, dtype=torch.float16, device=self.device)
+        self._g_tables_buf = torch.zeros(n_pad, device=self.device)
+        self.tables, self.tables_h, self.g_tables = self._tables_buf[:total], self._tables_h_buf[:total], self._g_tables_buf[:total]
+        self.shard = None                         # ShardedTableOptimizer once enable_sharded_optimizer() was called
         self.net = torch.zeros(N_PARAMS, device=self.device)
         # network gradients and the step's four scalars (loss, regulariser, squared gradient norm, spare) in one buffer: one fill per step
         self._g_net_scalars = torch.zeros(N_PARAMS + 4, device=self.device)
         self.g_net = self._g_net_scalars[:N_PARAMS]
-        self.state = {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in (("tables", self.tables), ("net", self.net))}
+        self._m_buf, self._v_buf = torch.zeros(n_pad, device=self.device), torch.zeros(n_pad, device=self.device)
+        self.state = {"tables": (self._m_buf[:total], self._v_buf[:total]), "net": (torch.zeros_like(self.net), torch.zeros_like(self.net))}
         self.packed = torch.empty(_lib.load().nerf_p4_packed_bytes(), dtype=torch.uint8, device=self.device)
         self.near, self.far = float(cfg.get("near", 2.0)), float(cfg.get("far", 6.0))
         self.lr0, self.eta_min = float(cfg.get("learning_rate", 5e-4)), float(cfg.get("eta_min", 1e-4))
@@ -349,7 +357,8 @@ class DualHashEngine:
                                         jitter=(self.seed, self._counter), first_ray=first_ray), self._counter
 
     def compute_gradients(self, rays_o: Tensor, rays_d: Tensor, target: Tensor, times: Tensor, n_samples: int, prepared=None,
-                          first_ray: int = 0, bg: Optional[Tensor] = None, sync_grads_async=None, probes=None) -> Tensor:
+                          first_ray: int = 0, bg: Optional[Tensor] = None, sync_grads_async=None, probes=None,
+                          shard_grads: bool = False) -> Tensor:
         """Forward + backward of one batch: fills g_net / g_tables with the gradient of
         MSE + deformation_reg_weight * mean(mean_delta_x^2) (+ the probe regularisers) of the LOCAL rays; returns the RGB loss.
         ``sync_grads_async(view)``: data-parallel hook, called with gradient ranges as they become final."""
@@ -379,10 +388,17 @@ class DualHashEngine:
             g_tabs = [self.g_table(k) for k in range(4)]
             backward_chain(self.packed, self.net, self.table(3, half=True), self.levels_d, self.levels_c, self.bound, pts if x_def is None else x_def,
                            xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch, overwrite=True, tables_ws=self._hash_scratch_tables,
-                           after_grid=(lambda k: reduce(g_tabs[k])) if (sync_grads_async is not None and probes is None) else None)
+                           after_grid=(lambda k: reduce(g_tabs[k])) if (sync_grads_async is not None and probes is None and not shard_grads) else None)
         if probes is not None:
             self._probe_regularisers(probes)
-        if sync_grads_async is not None:
+        if shard_grads and self.shard is not None:
+            # sharded optimiser: ONE reduce-scatter of the flat table gradient (every rank ends with the summed gradient of its
+            # slice) + the networks' small all-reduce; the same two collectives on every rank whatever its shard held
+            import torch.distributed as dist
+            self.shard.reduce_scatter_grads()
+            if self.world_size > 1:
+                dist.all_reduce(self.g_net, op=dist.ReduceOp.SUM)
+        elif sync_grads_async is not None:
             if n == 0 or probes is not None:
                 for k in (3, 0, 1, 2):                       # the order and sizes of the busy ranks' collectives
                     reduce(self.g_table(k))
@@ -445,10 +461,51 @@ class DualHashEngine:
         backward_chain(self.packed, self.net, self.table(3), self.levels_d, self.levels_c, self.bound, X, None, ws, None, None, None, None,
                        g, self.g_net, [self.g_table(k) for k in range(4)], hash_ws=self._hash_scratch)
 
+    def enable_sharded_optimizer(self, rank: int) -> None:
+        """Data parallelism as SURVEY 8(e) specifies for the big tables (project-nerf_amd/sharded.py): the table gradient is
+        reduce-scattered, this rank steps its 1/world slice of the flat table buffer, the fp16 copy is all-gathered.  Call once,
+        after the replicas' parameters were made equal; compute_gradients(shard_grads=True) + apply_gradients() then take this path."""
+        from .sharded import ShardedTableOptimizer
+        nd, nc = self.table_sizes[0], self.table_sizes[3]
+        tabs = [(k * nd, nd, self.tv_disp) for k in range(3)] + [(3 * nd, nc, self.tv_canon)]
+        self.shard = ShardedTableOptimizer(tabs, self.tables.numel(), rank, self.world_size, self._tables_buf, self._g_tables_buf,
+                                           self._m_buf, self._v_buf, self._tables_h_buf)
+
+    def gather_master(self) -> None:
+        """sharded optimiser: bring the fp32 master copy of every slice up to date on this rank (checkpoints, validation)"""
+        if self.shard is not None:
+            self.shard.gather_master()
+
+    def _apply_gradients_sharded(self) -> None:
+        """apply_gradients with the table groups sharded over the ranks: this rank's slice of TV + norm and of clip + AdamW, ONE
+        scalar all-reduce for the squared norm (the networks' part is added by rank 0), the networks stepped on every rank"""
+        import torch.distributed as dist
+        lib, st, sh = _lib.load(), ops._stream(), self.shard
+        scale = 1.0 / self.world_size
+        normsq = self._normsq_ws
+        normsq[:2].zero_()
+        sh.accumulate_normsq(normsq, scale)
+        if sh.rank == 0:
+            _lib.check(lib.nerf_tv_normsq_codes(P(self.net), P(self.g_net), N_PARAMS, 1, 0.0, scale, P(normsq), None, st), "nerf_tv_normsq_codes")
+        if self.world_size > 1:
+            dist.all_reduce(normsq[0:1], op=dist.ReduceOp.SUM)      # every rank: the same bits, hence the same clip coefficient
+        lr_t, lr_n, lr_s = self.lr(2.0), self.lr(1.0), self.lr(5.0)
+        self.step_count += 1
+        step = self.step_count
+        sh.adamw(normsq, step, lr_t, self.wd, self.max_norm, scale)
+        m, v = self.state["net"]
+        _lib.check(lib.nerf_adamw_clip_step_tv(P(self.net), P(self.g_net), P(m), P(v), N_PARAMS, step, lr_n, 0.9, 0.999, 1e-8, self.wd,
+                                               P(normsq), self.max_norm, scale, None, 0, 0.0, 0, 0.0, 0, SCALE, lr_s, None, st),
+                   "nerf_adamw_clip_step_tv")
+        sh.exchange()                             # neighbours' edge elements (next step's TV terms), fp16 copy of every slice
+        pack(self.net, self.packed)
+
     def apply_gradients(self) -> None:
         """TV-L1 on the four grids, ONE global-norm clip over every parameter (clip_grad_norm_(model.parameters()),
         run.py:1943), AdamW with the reference's group rates and cosine schedule; after a summing all-reduce the data
         gradient is averaged (1/world), the TV terms are added unscaled."""
+        if self.shard is not None:
+            return self._apply_gradients_sharded()
         lib = _lib.load()
         st = ops._stream()
         scale = 1.0 / self.world_size
@@ -481,7 +538,7 @@ class DualHashEngine:
     def train_step(self, rays_o, rays_d, target, times, n_samples, prepared=None, first_ray: int = 0, bg=None, sync_grads_async=None,
                    probes=None) -> Tensor:
         loss = self.compute_gradients(rays_o, rays_d, target, times, n_samples, prepared=prepared, first_ray=first_ray, bg=bg,
-                                      sync_grads_async=sync_grads_async, probes=probes)
+                                      sync_grads_async=sync_grads_async, probes=probes, shard_grads=self.shard is not None)
         self.apply_gradients()
         return loss
 

@@ -30,6 +30,11 @@ CONFIGS = {
 }
 
 
+# the replicated optimiser (all-reduce of the whole table gradient level group by level group) with the DEFAULT bf16 wire
+CONFIGS["part2_instant_replicated_bf16_wire"] = dict(CONFIGS["part2_instant"], dp_sharded_optimizer=False)
+del CONFIGS["part2_instant_replicated_bf16_wire"]["dp_gradient_wire"]
+
+
 CONFIGS["part4"] = dict(
     mode="part4", downscale=1, white_bkgd=True, near=2.0, far=6.0, n_samples=32, render_n_samples=32, batch_size=2048, chunk=4096,
     train_iters=48, learning_rate=1e-2, weight_decay=1e-5, eta_min=1e-4, max_grad_norm=1.0, log_every=2, val_every=10000,
@@ -89,26 +94,28 @@ def test_two_rank_cli_run_follows_the_single_rank_trajectory(mode, scene, tmp_pa
     n_logs = cfg["train_iters"] // cfg["log_every"]
     assert len(l1) == len(l2) == n_logs, (s1[-800:], s2[-800:])          # rank 0 alone prints: one line per logged step
     assert "data parallel: 2 ranks" in s2 and len(p1) == len(p2) == 1
-    # same global batch, same jitter, gradients summed and averaged: the trajectories agree up to summation order (float
-    # atomics in the small launches' flush, bf16 rounding flips downstream of it).  Part 4 amplifies that noise fastest --
-    # AdamW normalises the tiny, noisy gradients of rarely touched hash entries to +-lr steps, at 2x / 5x rates -- so its
-    # first eight steps are held tightly (measured: equal to 3e-5) and the rest of the run loosely.
-    # Single steps of the late Part 4 run swing by 10-30 % between two launches of the SAME command (summation order is not
-    # reproducible), so the late check is on the mean of the last quarter of the run, with a wide bound per step.
-    # (three logged steps = six training steps: the first occupancy-grid update at step 8 turns a last-bit difference of the
-    # weights into a different set of active samples as soon as one voxel sits on the threshold)
-    early = 3 if mode == "part4" else 1
+    if mode != "part2_nerf" and cfg.get("dp_sharded_optimizer", True):
+        assert "sharded optimiser: every rank steps" in s2              # reduce-scatter + sliced TV / AdamW + all-gather (sharded.py)
+    if mode != "part2_nerf":
+        # the replicas end BIT-EQUAL (tables, networks, occupancy grid): identical summed gradients, ONE squared norm that is the
+        # same bits on every rank, replicated grid updates -- whatever summation-order noise did to the trajectory itself
+        assert "replica divergence after" in s2 and "steps: 0.000e+00" in s2, s2[-1500:]
+    # same global batch, same jitter, gradients summed and averaged: the first logged steps agree with the single-rank run up to
+    # summation order (measured: 3e-5).  Later steps are a SMOKE test only for the hash-grid modes: their training map amplifies a
+    # 1e-5 relative perturbation of the tables to a 3 % change of the next step's gradients and to O(1) after two more
+    # (tests/studies/part4_mode_diff.py, profiles/r04_part4_sensitivity.txt: the same growth with the ordered sums on, i.e. without
+    # any summation-order noise) -- a two-rank run is another partition of the same sums, so its trajectory leaves the single-rank
+    # one after a few steps by construction.  What IS held tightly: the shards' summed gradients equal the full batch's
+    # (tests/test_gpu_data_parallel.py), the sharded optimiser equals the replicated one from the same state
+    # (tests/test_gpu_sharded_optimizer.py), the replicas stay bit-equal (above).
+    early = 3 if mode == "part4" else (len(l1) if mode == "part2_nerf" else 2)
     for k, (a, b) in enumerate(zip(l1, l2)):
-        if mode == "part4" and k >= early:
-            break                                                         # chaotic from here on: compared as a whole below
-        bound = 2e-3 if k < early else 2e-2
+        if k >= early:
+            break
+        bound = 2e-3 if k < 1 else 2e-2
         assert abs(a - b) <= bound * max(a, 1e-3), (k, l1, l2)
-    if mode == "part4":
-        q = max(len(l1) // 4, 1)
-        m1, m2 = sum(l1[-q:]) / q, sum(l2[-q:]) / q
-        assert abs(m1 - m2) <= 0.5 * m1, (m1, m2, l1, l2)                   # both runs end in the same region
-        assert l2[-1] < l2[0]
-    assert l1[-1] < l1[0]                                                  # and it trains
-    # row-band evaluation = whole-frame evaluation; Part 4's two runs end at measurably different weights after 40 chaotic
-    # steps (12 dB region: +-0.6 dB between launches of the same command), so its bound is on the training noise
-    assert abs(p1[0] - p2[0]) < (3.0 if mode == "part4" else 0.5), (p1, p2)
+    assert l1[-1] < l1[0] and l2[-1] < l2[0]                              # both train
+    assert all(v == v and v < 1e3 for v in l2)
+    # row-band evaluation = whole-frame evaluation (vanilla: same weights up to summation order); the hash-grid modes end at
+    # different weights (above): their PSNR is a smoke test
+    assert abs(p1[0] - p2[0]) < (0.5 if mode == "part2_nerf" else 4.0), (p1, p2)

@@ -201,3 +201,57 @@ def test_world_size_2_training_loop_helpers():
         out = mgr.dict()
         mp.spawn(_loop_helpers_worker, args=(2, port, out), nprocs=2, join=True)
         assert dict(out) == {0: True, 1: True}
+
+
+def _sharded_worker(rank, world, port, out):
+    """project-nerf_amd/sharded.py's collectives and slice bookkeeping with real gloo collectives (no kernels: no GPU here)"""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import project_nerf_amd  # noqa: F401
+    from project_nerf_amd import parallel as P, sharded as S
+    P.init_distributed("cpu")
+    n = 5 * 1024 + 512                                       # not a multiple of world x 1024
+    n_pad = S.padded_length(n, world)
+    per = n_pad // world
+    ok = n_pad % (world * 1024) == 0 and n_pad >= n and per * world == n_pad
+    flat = torch.zeros(n_pad)
+    flat[:n] = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    S.reduce_scatter_sum_(flat, per, rank, world)
+    want = torch.zeros(n_pad)
+    want[:n] = torch.arange(n, dtype=torch.float32) * sum(range(1, world + 1))
+    ok = ok and torch.equal(flat[rank * per:(rank + 1) * per], want[rank * per:(rank + 1) * per])
+    half = torch.zeros(n_pad, dtype=torch.float16)
+    half[rank * per:(rank + 1) * per] = float(rank + 1)
+    S.all_gather_slices_(half, per, rank, world)
+    ok = ok and all(bool((half[r * per:(r + 1) * per] == float(r + 1)).all()) for r in range(world))
+    # slices, pieces and halos of a four-table layout (Part 4's: three equal deformation grids + a larger canonical grid)
+    nd, nc = 1536, n - 3 * 1536
+    tabs = [(k * nd, nd, 0.1) for k in range(3)] + [(3 * nd, nc, 0.2)]
+    bufs = [torch.zeros(n_pad) for _ in range(4)] + [torch.zeros(n_pad, dtype=torch.float16)]
+    opt = S.ShardedTableOptimizer(tabs, n, rank, world, *bufs)
+    covered = torch.zeros(n, dtype=torch.int32)
+    for a, cnt, table_elems, tv_w, halo in opt.pieces:
+        covered[a:a + cnt] += 1
+        off = next(o for o, c, _ in tabs if o <= a < o + c)
+        ok = ok and (halo & 1) == (1 if a > off else 0) and table_elems in (nd, nc) and a % 4 == 0 and cnt % 4 == 0
+    total = covered.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    ok = ok and bool((total == 1).all())                      # every table element belongs to exactly one rank's pieces
+    # the neighbours' edge elements after a step
+    opt.params[:n] = torch.arange(n, dtype=torch.float32) + 1000.0 * rank
+    opt.exchange()
+    if rank > 0:
+        ok = ok and float(opt.params[opt.lo - 1]) == float(opt.lo - 1) + 1000.0 * (rank - 1)
+    if rank + 1 < world and opt.hi < n:
+        ok = ok and float(opt.params[opt.hi]) == float(opt.hi) + 1000.0 * (rank + 1)
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world_size_2_sharded_optimizer_collectives():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_sharded_worker, args=(2, port, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: True}
