@@ -36,6 +36,12 @@ int nerf_comm_world(nerf_comm_t comm);
 /* in-place sum over the ranks of buf[count] (gradients: the flat 595,844-float decoder gradient in two
  * ranges, the tiny-MLP gradient, one level group of the hash-table gradient; bf16 halves the wire bytes) */
 int nerf_comm_allreduce_sum(nerf_comm_t comm, void* buf, int64_t count, int dtype, nerf_comm_stream_t stream);
+/* The exchange of the sharded optimiser (reduce-scatter the table gradient, every rank steps its 1/N slice, all-gather
+ * the fp16 copy the forward reads; project-nerf_amd/sharded.py).  buf holds `world` equal slices of `per` elements.
+ *   nerf_comm_reduce_scatter_sum: slice `rank` of buf <- sum over the ranks of that slice (in place; the other slices are unspecified)
+ *   nerf_comm_all_gather        : slice r of buf <- rank r's slice r, on every rank (in place); elem_bytes 2 (fp16 copy) or 4 (fp32 master) */
+int nerf_comm_reduce_scatter_sum(nerf_comm_t comm, void* buf, int64_t per, int dtype, nerf_comm_stream_t stream);
+int nerf_comm_all_gather(nerf_comm_t comm, void* buf, int64_t per, int elem_bytes, nerf_comm_stream_t stream);
 /* evaluation: rank r holds tile [counts[r]] floats (its row band); root receives them back to back in
  * rank order into out[sum(counts)].  counts is a HOST array of `world` entries, the same on every rank;
  * out is ignored on the other ranks. */

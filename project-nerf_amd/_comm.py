@@ -19,6 +19,8 @@ PROTOTYPES = {
     "nerf_comm_rank": (i32, [c_ptr]),
     "nerf_comm_world": (i32, [c_ptr]),
     "nerf_comm_allreduce_sum": (i32, [c_ptr, c_ptr, i64, i32, c_ptr]),
+    "nerf_comm_reduce_scatter_sum": (i32, [c_ptr, c_ptr, i64, i32, c_ptr]),
+    "nerf_comm_all_gather": (i32, [c_ptr, c_ptr, i64, i32, c_ptr]),
     "nerf_comm_gather_tiles": (i32, [c_ptr, c_ptr, ctypes.POINTER(i64), c_ptr, i32, c_ptr]),
     "nerf_comm_destroy": (i32, [c_ptr]),
 }
@@ -85,6 +87,25 @@ class NativeComm:
             raise TypeError(f"allreduce_sum_: fp32 or bf16, got {flat.dtype}")
         _check(load().nerf_comm_allreduce_sum(self._h, flat.data_ptr(), flat.numel(), dtype, torch.cuda.current_stream().cuda_stream),
                "nerf_comm_allreduce_sum")
+        return flat
+
+    def reduce_scatter_sum_(self, flat: torch.Tensor, per: int) -> torch.Tensor:
+        """sharded optimiser: flat = world equal slices of ``per`` elements; slice ``rank`` becomes the sum over the ranks (in place)"""
+        if flat.device.type != "cuda" or not flat.is_contiguous() or flat.numel() != per * self.world:
+            raise NerfCommError("reduce_scatter_sum_: a contiguous HIP tensor of world x per elements is required")
+        dtype = {torch.float32: 0, torch.bfloat16: 1}.get(flat.dtype)
+        if dtype is None:
+            raise TypeError(f"reduce_scatter_sum_: fp32 or bf16, got {flat.dtype}")
+        _check(load().nerf_comm_reduce_scatter_sum(self._h, flat.data_ptr(), per, dtype, torch.cuda.current_stream().cuda_stream),
+               "nerf_comm_reduce_scatter_sum")
+        return flat
+
+    def all_gather_(self, flat: torch.Tensor, per: int) -> torch.Tensor:
+        """sharded optimiser: every rank's slice ``rank`` of flat (fp16 copy or fp32 master) on every rank, in place"""
+        if flat.device.type != "cuda" or not flat.is_contiguous() or flat.numel() != per * self.world or flat.element_size() not in (2, 4):
+            raise NerfCommError("all_gather_: a contiguous HIP tensor of world x per elements of 2 or 4 bytes is required")
+        _check(load().nerf_comm_all_gather(self._h, flat.data_ptr(), per, flat.element_size(), torch.cuda.current_stream().cuda_stream),
+               "nerf_comm_all_gather")
         return flat
 
     def gather_row_bands(self, band: torch.Tensor, rows_total: int, dst: int = 0):

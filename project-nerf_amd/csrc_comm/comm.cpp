@@ -86,6 +86,35 @@ extern "C" int nerf_comm_allreduce_sum(nerf_comm_t comm, void* buf, int64_t coun
   return 0;
 }
 
+// The exchange of the sharded optimiser: buf holds world equal slices of `per` elements; afterwards slice `rank` of
+// buf is the sum over the ranks of that slice (the other slices are unspecified) ...
+extern "C" int nerf_comm_reduce_scatter_sum(nerf_comm_t comm, void* buf, int64_t per, int dtype, nerf_comm_stream_t stream) {
+  if (!comm) return fail(kInval, "nerf_comm_reduce_scatter_sum: NULL communicator");
+  if (per < 0) return fail(kInval, "nerf_comm_reduce_scatter_sum: per=%lld", (long long)per);
+  if (dtype != NERF_COMM_F32 && dtype != NERF_COMM_BF16) return fail(kInval, "nerf_comm_reduce_scatter_sum: dtype=%d", dtype);
+  if (per == 0) return 0;
+  if (!buf) return fail(kInval, "nerf_comm_reduce_scatter_sum: NULL buffer");
+  const size_t esz = dtype == NERF_COMM_F32 ? 4 : 2;
+  char* mine = static_cast<char*>(buf) + (size_t)comm->rank * (size_t)per * esz;     // in place: RCCL allows recv = send + rank * count
+  COMM_CHECK(ncclReduceScatter(buf, mine, (size_t)per, dtype == NERF_COMM_F32 ? ncclFloat32 : ncclBfloat16, ncclSum, comm->comm,
+                               static_cast<hipStream_t>(stream)),
+             "ncclReduceScatter");
+  return 0;
+}
+
+// ... and every rank's slice `rank` of buf (per elements of elem_bytes = 2 or 4: the fp16 copy of the table, the fp32 master for
+// checkpoints) on every rank, in place
+extern "C" int nerf_comm_all_gather(nerf_comm_t comm, void* buf, int64_t per, int elem_bytes, nerf_comm_stream_t stream) {
+  if (!comm) return fail(kInval, "nerf_comm_all_gather: NULL communicator");
+  if (per < 0 || (elem_bytes != 2 && elem_bytes != 4)) return fail(kInval, "nerf_comm_all_gather: per=%lld elem_bytes=%d", (long long)per, elem_bytes);
+  if (per == 0) return 0;
+  if (!buf) return fail(kInval, "nerf_comm_all_gather: NULL buffer");
+  const char* mine = static_cast<const char*>(buf) + (size_t)comm->rank * (size_t)per * (size_t)elem_bytes;
+  COMM_CHECK(ncclAllGather(mine, buf, (size_t)per, elem_bytes == 4 ? ncclFloat32 : ncclFloat16, comm->comm, static_cast<hipStream_t>(stream)),
+             "ncclAllGather");
+  return 0;
+}
+
 extern "C" int nerf_comm_gather_tiles(nerf_comm_t comm, const float* tile, const int64_t* counts_host, float* out, int root,
                                       nerf_comm_stream_t stream) {
   if (!comm || !counts_host) return fail(kInval, "nerf_comm_gather_tiles: NULL");

@@ -127,6 +127,15 @@ def test_native_rccl_comm_single_rank_world():
             comm.allreduce_sum_(h)
         torch.cuda.current_stream().wait_stream(side)
         assert torch.equal(g, want) and torch.equal(h, want_h)
+        # the sharded optimiser's exchange on a world of one rank: both collectives are the identity on the rank's slice
+        flat = torch.randn(4096, device="cuda")
+        keep = flat.clone()
+        comm.reduce_scatter_sum_(flat, 4096)
+        half = torch.randn(4096, device="cuda").half()
+        keep_h = half.clone()
+        comm.all_gather_(half, 4096)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, keep) and torch.equal(half, keep_h)
         band = torch.rand(100, 800, 3, device="cuda")
         img = comm.gather_row_bands(band, 100, dst=0)
         torch.cuda.synchronize()
