@@ -64,8 +64,8 @@ int nerf_abi_version(void);
  *     workspace return NERF_EINVAL;
  *   - nerf_hash_encode_bwd_input*: point on the thread, levels summed in order;
  *   - nerf_composite_mse*_bwd: pass `sum_ws` (the loss and regulariser sums; they do not enter the gradients; the engines always do).
- * Always ordered, option or not: the vanilla decoder's weight gradients, nerf_tv_normsq*.  Costs 0.1-0.3 ms per Instant / Part 4
- * step (profiles/). */
+ * Always ordered, option or not: the vanilla decoder's weight gradients, nerf_tv_normsq*.  Measured cost per step: Part 4 0.3 ms,
+ * Instant 0.8 ms (uncut bins of the coarse dense levels serialise on one workgroup each; profiles/r04_deterministic_cost.txt). */
 int nerf_set_option(const char* name, int value);
 int nerf_get_option(const char* name, int* value_out);
 
