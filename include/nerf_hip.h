@@ -156,6 +156,14 @@ int nerf_sample_compact_jitter_shard(const float* rays_o, const float* rays_d, u
                                      const uint8_t* binary_grid, int resolution, float bound, float* z_out,
                                      int* slot_of_sample, float* pts_compact, float* dirs_compact,
                                      unsigned* active_count, nerf_stream_t stream);
+/* ... as a link of a CHAIN of calls on one stream: active_count is NOT cleared by the call (the previous link cleared it, the caller
+ * clears it before the first link) and the kernel clears *next_count, the counter the caller hands to the next link.  Two counters
+ * used alternately need no fill launch per call; read call k's count before call k + 2 is queued. */
+int nerf_sample_compact_jitter_chain(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,
+                                     int64_t first_ray, int64_t n_rays, int n_samples, float near_plane, float far_plane,
+                                     const uint8_t* binary_grid, int resolution, float bound, float* z_out,
+                                     int* slot_of_sample, float* pts_compact, float* dirs_compact,
+                                     unsigned* active_count, unsigned* next_count, nerf_stream_t stream);
 
 /* the same compaction with the slots in SAMPLE ORDER (option "deterministic": the single-pass kernels reserve slots with a returning
  * atomic per 4096 samples, so the order of the compact arrays -- and with it the order of every later sum over samples -- depends
@@ -387,6 +395,15 @@ int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n, int n_tabl
                                          const unsigned* offset_host, const unsigned* dense_host, float bound,
                                          const float* d_feat, int64_t dfeat_stride, float* d_table, void* workspace,
                                          size_t workspace_bytes, nerf_stream_t stream);
+/* ... its speculative form (protocol of nerf_hash_encode_bwd_ws_store_spec below: no count pass, capacities from the true counts the
+ * previous call on this workspace left; the producer -- nerf_p4_deform_bwd -- max-accumulates the largest |d feature| into the slot
+ * nerf_hash_encode_bwd_ws_slots(workspace, n, n_levels * n_tables, ...) names; d_feat row-major, or NULL: the producer wrote the
+ * level-major copy into the workspace's grad_lm slot) */
+int nerf_hash_encode_bwd_ws_store_tables_spec(const float* pts, int64_t n, int n_tables, int64_t table_stride, int n_levels,
+                                              const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                              const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                              const float* d_feat, int64_t dfeat_stride, float* d_table, void* workspace,
+                                              size_t workspace_bytes, void* status_host, nerf_stream_t stream);
 /* The count pass of the binned backward done where the information already exists (Instant-NGP step, all levels):
  *   nerf_hash_encode_fwd_f16_hist  the forward also counts the corners per (level, table slice) into `bwd_workspace`
  *                                  (>= nerf_hash_encode_bwd_workspace_bytes(n, L); its header and counts are zeroed here);
@@ -398,6 +415,10 @@ int nerf_hash_encode_fwd_f16_hist(const float* pts, int64_t n, const void* table
                                   const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                                   const unsigned* offset_host, const unsigned* dense_host, float bound,
                                   void* out_nat_bf16, void* bwd_workspace, size_t bwd_workspace_bytes, nerf_stream_t stream);
+/* (amax_bits_out: NERF_AMAX_WORDS u32 words; a producer max-accumulates the fp32 bits of its largest |d feature| into ANY of them --
+ * its workgroups spread over all, same-address atomics retire one after the other -- the consumer takes the maximum of all and
+ * clears them; grad_lm_out: float2 [n_levels][n], level-major) */
+#define NERF_AMAX_WORDS 32
 int nerf_hash_encode_bwd_ws_slots(void* workspace, int64_t n, int n_levels, void** amax_bits_out, void** grad_lm_out);
 int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_t n, int n_levels, const float* scale_host,
                                              const unsigned* res_host, const unsigned* size_host,
@@ -406,19 +427,22 @@ int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_t n, int n_
 /* The speculative form of the binned scatter: NO count pass.  Bin capacities come from the TRUE record counts that the previous
  * all-level call on this workspace (counted, precounted or speculative) left in it, + 1/8 + 64 records; a record that does not fit
  * its bin is added with a float atomic by a last small launch (steady-state training batches fill their bins within a few percent
- * from step to step: a handful of records).  Protocol: nerf_hash_encode_bwd_spec_begin (clears the status block) -> the decoder's
+ * from step to step: a handful of records).  Protocol: nerf_hash_encode_bwd_spec_begin (clears the header; needed only when the
+ * PREVIOUS call on the workspace was a counted one -- a speculative call's last launch leaves the header clean) -> the decoder's
  * backward max-accumulates the largest |gradient| into the workspace's slot (nerf_hash_encode_bwd_ws_slots): nerf_imlp_bwd_amax
  * with row-major d_feat [n, 2L], or nerf_imlp_bwd_lm with the level-major copy in the workspace (then d_feat NULL here)
  * -> nerf_hash_encode_bwd_ws_store_spec.  The caller decides WHEN the estimates are good (same
- * occupancy grid, point count within ~10 % of the last call's) and reads the status block afterwards
- * (nerf_hash_encode_bwd_spec_status: 8 x u32 at the start of the workspace: [3] records that overflowed, [4] != 0: records were
- * LOST -- overflow list full or estimates larger than the workspace -- the gradient of that call is incomplete: fall back to the
- * counted form).  Levels of at most 256 slices (tables up to 2^20 entries per level); not with option "deterministic". */
+ * occupancy grid, point count within ~10 % of the last call's) and reads the status block afterwards: 8 x u32, published by the
+ * call's last launch at nerf_hash_encode_bwd_spec_status(workspace) (device) and, when status_host is given, in that host-mapped
+ * pinned block as well (no copy launch; word [7] is written LAST, as 1, after a system-scope fence: a caller that cleared it before
+ * the call may poll it instead of recording an event) -- [3] records that
+ * overflowed, [4] != 0: records were LOST (overflow list full or estimates larger than the workspace): the gradient of that call is
+ * incomplete, fall back to the counted form.  Levels of at most 256 slices (tables up to 2^20 entries per level); not with option "deterministic". */
 int nerf_hash_encode_bwd_spec_begin(void* workspace, nerf_stream_t stream);
 int nerf_hash_encode_bwd_ws_store_spec(const float* pts, int64_t n, int n_levels, const float* scale_host,
                                        const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                                        const unsigned* dense_host, float bound, const float* d_feat, float* d_table, void* workspace,
-                                       size_t workspace_bytes, nerf_stream_t stream);
+                                       size_t workspace_bytes, void* status_host, nerf_stream_t stream);
 int nerf_imlp_bwd_amax(const void* packed, void* workspace, const float* rgb, const float* sigma, const float* d_rgb,
                        const float* d_sigma, int64_t n, float* grads_f32, float* d_feat, void* amax_bits, nerf_stream_t stream);
 const void* nerf_hash_encode_bwd_spec_status(const void* workspace);
@@ -436,6 +460,19 @@ int nerf_hash_encode_bwd_input_f16(const float* pts, int64_t n, const void* tabl
                                    const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                                    const unsigned* offset_host, const unsigned* dense_host, float bound,
                                    const float* d_feat, float* d_pts, nerf_stream_t stream);
+/* ... ADDED to d_pts instead of overwriting it: a gradient that reaches the positions by another path as well (Part 4: the
+ * displacement regulariser's, reference run.py:1852-1858) is already there -- no zeroing launch, no separate add */
+int nerf_hash_encode_bwd_input_f16_accum(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                         const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                         const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                         const float* d_feat, float* d_pts, nerf_stream_t stream);
+/* ... from LEVEL-MAJOR feature gradients float2 [n_levels][n] (the layout a producer leaves in the hash backward's workspace,
+ * nerf_hash_encode_bwd_ws_slots: this launch walks one level per workgroup, so its reads are coalesced); accumulate != 0: added to
+ * d_pts.  Not with option "deterministic". */
+int nerf_hash_encode_bwd_input_lm_f16(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                      const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                      const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                      const void* grad_lm, float* d_pts, int accumulate, nerf_stream_t stream);
 
 
 /* ---- a7: Instant decoder (two bias-free tiny MLPs, bf16 MFMA) -----------------------
@@ -462,7 +499,7 @@ int nerf_imlp_bwd(const void* packed, void* workspace, const float* rgb, const f
                   const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
                   float* d_feat, nerf_stream_t stream);
 /* nerf_imlp_bwd with the feature gradients written level-major [16][n] float2 (grad_lm) and their largest magnitude
- * max-accumulated into *amax_bits (fp32 bits): the inputs of nerf_hash_encode_bwd_ws_store_precounted */
+ * max-accumulated into amax_bits (NERF_AMAX_WORDS words of fp32 bits): the inputs of nerf_hash_encode_bwd_ws_store_precounted */
 int nerf_imlp_bwd_lm(const void* packed, void* workspace, const float* rgb, const float* sigma,
                      const float* d_rgb, const float* d_sigma, int64_t n, float* grads_f32,
                      void* grad_lm, void* amax_bits, nerf_stream_t stream);
@@ -549,8 +586,10 @@ int nerf_adamw_clip_step_shadow(float* params, const float* grads, float* exp_av
                          const float* normsq_dev, float max_norm, float grad_scale, void* params_f16_out, nerf_stream_t stream);
 
 /* The same two passes WITHOUT rewriting the gradient (38.5 instead of 42 bytes per parameter; what the engines call):
- *   nerf_tv_normsq_codes   : normsq_dev[0] += sum (grads * grad_scale + TV term)^2 over n_tables equally long tables stored back
- *                            to back (accumulating form: zero normsq_dev[0..1] once per step); grads is NOT modified; tv_codes
+ *   nerf_tv_normsq_codes   : normsq_dev[0] (accumulate != 0: +)= sum (grads * grad_scale + TV term)^2 over n_tables equally long tables
+ *                            stored back to back -- the first call of a step STORES (accumulate 0: no zeroing launch), the
+ *                            groups that share the norm add (accumulate 1); normsq_dev[1] (the ordered sum's ticket) is zero before
+ *                            the first call ever and left zero by every call; grads is NOT modified; tv_codes
  *                            (nerf_tv_codes_bytes(n) bytes; may be NULL when tv_weight == 0) receives the two-bit signs
  *                            1 + sign(p[i+1] - p[i]) the TV term is made of (0 across a table seam)
  *   nerf_adamw_clip_step_tv: AdamW with (grads * grad_scale + TV term rebuilt from tv_codes) * min(1, max_norm / (sqrt(normsq_dev[0])
@@ -560,7 +599,7 @@ int nerf_adamw_clip_step_shadow(float* params, const float* grads, float* exp_av
  *                            params_f16_out optional.  tv_codes NULL: no TV term. */
 size_t nerf_tv_codes_bytes(int64_t n);
 int nerf_tv_normsq_codes(const float* params, const float* grads, int64_t n, int n_tables, float tv_weight, float grad_scale,
-                         float* normsq_dev, void* tv_codes, nerf_stream_t stream);
+                         float* normsq_dev, int accumulate, void* tv_codes, nerf_stream_t stream);
 int nerf_adamw_clip_step_tv(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
                             float beta1, float beta2, float eps, float weight_decay, const float* normsq_dev, float max_norm,
                             float grad_scale, const void* tv_codes, int64_t tv_split, float tv_weight_lo, int64_t seg_lo,
@@ -574,11 +613,19 @@ int nerf_adamw_clip_step_tv(float* params, const float* grads, float* exp_avg, f
  * byte inside a buffer with at least one byte before it.  n a multiple of 4, 16-byte aligned pointers.  normsq_dev accumulates the
  * piece's part: the ranks' parts are summed by ONE scalar all-reduce before the AdamW launches. */
 int nerf_tv_normsq_codes_piece(const float* params, const float* grads, int64_t n, int64_t table_elems, int halo, float tv_weight,
-                               float grad_scale, float* normsq_dev, void* tv_codes, nerf_stream_t stream);
+                               float grad_scale, float* normsq_dev, int accumulate, void* tv_codes, nerf_stream_t stream);
 int nerf_adamw_clip_step_tv_piece(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
                                   float beta1, float beta2, float eps, float weight_decay, const float* normsq_dev, float max_norm,
                                   float grad_scale, const void* tv_codes, float tv_weight, int64_t table_elems, int halo_lo,
                                   void* params_f16_out, nerf_stream_t stream);
+
+/* One SMALL group (n <= 65536: a tiny MLP's weights) in one launch (every workgroup sums the whole gradient itself, in a fixed order,
+ * then steps its own 1024 elements): squared norm of grads * grad_scale, clip_grad_norm_(max_norm) and AdamW.step() (reference run.py:624-629, the decoder group) -- instead of a zeroing
+ * launch, a norm launch and an AdamW launch of ~4.5 us each.  normsq_out (nullable) receives the squared norm; zero_grads != 0:
+ * grads is left zeroed for the next step's accumulating backward. */
+int nerf_clip_adamw_small(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float max_norm, float grad_scale, float* normsq_out,
+                          int zero_grads, nerf_stream_t stream);
 
 /* ---- f3: Part 4 dual-hash dynamic field (csrc/p4mlp.hip) ------------------------------------------------------
  * replaces, for NeuralField(mode part4).forward (src/core.py:282-352), the tinycudann FullyFusedMLP networks
@@ -614,11 +661,16 @@ int nerf_p4_deform_fwd(const void* packed, const float* params_f32, void* worksp
 /* canonical chain on the canonical grid's features (workspace slot 3), t' and unit view directions */
 int nerf_p4_canon_fwd(const void* packed, void* workspace, const float* t_deform, const float* dirs, int64_t n, float* rgb,
                       float* sigma, int train, nerf_stream_t stream);
-/* backward passes; parameter gradients are ACCUMULATED into grads_f32 [nerf_p4_param_count()] (zero it once per step) */
+/* backward passes; parameter gradients are ACCUMULATED into grads_f32 [nerf_p4_param_count()] (zero it once per step).
+ * amax_bits (nullable): NERF_AMAX_WORDS device words that max-accumulate the largest |d feature| the pass wrote, as fp32 bits;
+ * grad_lm (nullable): INSTEAD of the row-major d features of workspace slots 4..7, the level-major copy float2 [levels][n]
+ * (deformation chain: [3 x 12][n], virtual level = grid * 12 + level) -- both are the slots nerf_hash_encode_bwd_ws_slots names in
+ * the hash backward's workspace, for the speculative scatters (nerf_hash_encode_bwd_ws_store_spec / _tables_spec with d_feat NULL)
+ * and nerf_hash_encode_bwd_input_lm_f16. */
 int nerf_p4_canon_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma, const float* d_rgb,
-                      const float* d_sigma, int64_t n, float* grads_f32, nerf_stream_t stream);
+                      const float* d_sigma, int64_t n, float* grads_f32, void* amax_bits, void* grad_lm, nerf_stream_t stream);
 int nerf_p4_deform_bwd(const void* packed, const float* params_f32, void* workspace, const float* d_delta_x, int64_t n,
-                       float* grads_f32, nerf_stream_t stream);
+                       float* grads_f32, void* amax_bits, void* grad_lm, nerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,8 @@ PROTOTYPES = {
                                          c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_sample_compact_jitter_shard": (i32, [c_ptr, c_ptr, ctypes.c_uint64, ctypes.c_uint64, i64, i64, i32, f32, f32, c_ptr, i32, f32,
                                                c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_sample_compact_jitter_chain": (i32, [c_ptr, c_ptr, ctypes.c_uint64, ctypes.c_uint64, i64, i64, i32, f32, f32, c_ptr, i32, f32,
+                                               c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_composite_fwd_indexed": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_composite_bwd_indexed": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, i64, i32, c_ptr, c_ptr, c_ptr]),
     "nerf_sample_pdf": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr, c_ptr]),
@@ -76,16 +78,20 @@ PROTOTYPES = {
     "nerf_hash_encode_bwd_ws_store": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, i32, i32, c_ptr, size_t, c_ptr]),
     "nerf_hash_encode_bwd_tables_workspace_bytes": (size_t, [i64, i32, i32]),
     "nerf_hash_encode_bwd_ws_store_tables": (i32, [c_ptr, i64, i32, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, i64, c_ptr, c_ptr, size_t, c_ptr]),
+    "nerf_hash_encode_bwd_ws_store_tables_spec": (i32, [c_ptr, i64, i32, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, i64, c_ptr, c_ptr, size_t,
+                                                        c_ptr, c_ptr]),
     "nerf_hash_encode_fwd_f16_hist": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),
     "nerf_hash_encode_bwd_ws_slots": (i32, [c_ptr, i64, i32, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr)]),
     "nerf_hash_encode_bwd_ws_store_precounted": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, size_t, c_ptr]),
     "nerf_hash_encode_bwd_spec_begin": (i32, [c_ptr, c_ptr]),
-    "nerf_hash_encode_bwd_ws_store_spec": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr, size_t, c_ptr]),
+    "nerf_hash_encode_bwd_ws_store_spec": (i32, [c_ptr, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr, size_t, c_ptr, c_ptr]),
     "nerf_imlp_bwd_amax": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_spec_status": (c_ptr, [c_ptr]),
     "nerf_imlp_bwd_lm": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_input": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
     "nerf_hash_encode_bwd_input_f16": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_hash_encode_bwd_input_f16_accum": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_hash_encode_bwd_input_lm_f16": (i32, [c_ptr, i64, c_ptr, i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, f32, c_ptr, c_ptr, i32, c_ptr]),
     "nerf_imlp_packed_bytes": (size_t, []),
     "nerf_imlp_workspace_bytes": (size_t, [i64]),
     "nerf_imlp_hash_operand_offset": (size_t, [i64]),
@@ -110,13 +116,14 @@ PROTOTYPES = {
     "nerf_p4_sample_inputs": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, ctypes.c_uint64, ctypes.c_uint64, i64, c_ptr, c_ptr, c_ptr]),
     "nerf_p4_deform_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
     "nerf_p4_canon_fwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, i32, c_ptr]),
-    "nerf_p4_canon_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
-    "nerf_p4_deform_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr]),
+    "nerf_p4_canon_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "nerf_p4_deform_bwd": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_tv_codes_bytes": (size_t, [i64]),
-    "nerf_tv_normsq_codes": (i32, [c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_tv_normsq_codes": (i32, [c_ptr, c_ptr, i64, i32, f32, f32, c_ptr, i32, c_ptr, c_ptr]),
+    "nerf_clip_adamw_small": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, f32, f32, c_ptr, i32, c_ptr]),
     "nerf_adamw_clip_step_tv": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, i64, f32, i64,
                                       f32, i64, i64, f32, c_ptr, c_ptr]),
-    "nerf_tv_normsq_codes_piece": (i32, [c_ptr, c_ptr, i64, i64, i32, f32, f32, c_ptr, c_ptr, c_ptr]),
+    "nerf_tv_normsq_codes_piece": (i32, [c_ptr, c_ptr, i64, i64, i32, f32, f32, c_ptr, i32, c_ptr, c_ptr]),
     "nerf_adamw_clip_step_tv_piece": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr, f32, i64, i32,
                                             c_ptr, c_ptr]),
     "nerf_adamw_clip_step": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, i64, i32, f32, f32, f32, f32, f32, c_ptr, f32, f32, c_ptr]),

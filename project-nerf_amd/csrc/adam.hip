@@ -175,7 +175,7 @@ __device__ __forceinline__ int tv_code_at(const uint8_t* __restrict__ codes, int
 // generic form (any alignment, any n): one chunk of four elements per thread and round
 __global__ void __launch_bounds__(256)
 tv_normsq_codes_kernel(const float* __restrict__ p, const float* __restrict__ g, int64_t n, float tv_scale, float grad_scale,
-                       float* __restrict__ normsq, int64_t seg, uint8_t* __restrict__ codes) {
+                       float* __restrict__ normsq, int64_t seg, uint8_t* __restrict__ codes, int accumulate) {
   auto starts = [seg](int64_t e) { return e == 0 || e == seg || e == 2 * seg || e == 3 * seg; };
   float local = 0.0f;
   const int64_t n4 = (n + 3) / 4;
@@ -212,7 +212,7 @@ tv_normsq_codes_kernel(const float* __restrict__ p, const float* __restrict__ g,
   __syncthreads();
   const float val[1] = {(part[0] + part[1]) + (part[2] + part[3])};
   float* const out[1] = {normsq};
-  ordered_block_sum<1>(val, out, reinterpret_cast<unsigned*>(normsq + 1));
+  ordered_block_sum<1>(val, out, reinterpret_cast<unsigned*>(normsq + 1), accumulate != 0);
 }
 
 // the tables' form: 16-byte aligned, n a multiple of 4 and below 2^31.  kU chunks per thread and round, every load issued before the
@@ -225,7 +225,7 @@ constexpr int kTvFastThreads = 1024;
 template <bool TV>
 __global__ void __launch_bounds__(kTvFastThreads)
 tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict__ g, int n4, float tv_scale, float grad_scale,
-                            float* __restrict__ normsq, int seg, uint8_t* __restrict__ codes, int halo) {
+                            float* __restrict__ normsq, int seg, uint8_t* __restrict__ codes, int halo, int accumulate) {
   // halo (a PIECE of one table: the sharded optimiser's slice): bit 0 -- p[-1] belongs to the same table, bit 1 -- p[n] does; the
   // piece's first TV term then reaches back to p[-1] (its sign is also left in codes[-1] for the AdamW pass), its last one on to p[n]
   constexpr int kU = 4;
@@ -280,7 +280,47 @@ tv_normsq_codes_fast_kernel(const float* __restrict__ p, const float* __restrict
   }
   const float val[1] = {sum};
   float* const out[1] = {normsq};
-  ordered_block_sum<1>(val, out, reinterpret_cast<unsigned*>(normsq + 1));
+  ordered_block_sum<1>(val, out, reinterpret_cast<unsigned*>(normsq + 1), accumulate != 0);
+}
+
+// One small parameter group (a tiny MLP's few thousand weights) in ONE launch: squared norm of the scaled gradient, clip coefficient,
+// AdamW -- instead of a zeroing launch, a norm launch and an AdamW launch of ~4.5 us each for 45 KB of data.  EVERY workgroup sums
+// the whole gradient itself (threads in a fixed stride, waves in order: the same bits in every workgroup and every run -- the vector
+// sits in L2) and then steps its own kSmallOptThreads elements: no exchange between workgroups, one element per thread in the update.
+// zero_grads: the gradient is left zeroed for the next step's accumulating backward (not while other workgroups may still read it:
+// only with one workgroup, i.e. n <= kSmallOptThreads -- the launcher falls back to a memset otherwise).
+constexpr int kSmallOptThreads = 1024;
+__global__ void __launch_bounds__(kSmallOptThreads)
+clip_adamw_small_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n, float lr,
+                        float beta1, float beta2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2, float max_norm, float grad_scale,
+                        float* __restrict__ normsq_out, int zero_grads) {
+  float local = 0.0f;
+  for (int i = threadIdx.x; i < n; i += kSmallOptThreads) { const float gi = g[i] * grad_scale; local += gi * gi; }
+  __shared__ float part[kSmallOptThreads / 64];
+  __shared__ float total;
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kSmallOptThreads / 64; ++w) sum += part[w];
+    total = sum;
+    if (normsq_out != nullptr && blockIdx.x == 0) *normsq_out = sum;
+  }
+  __syncthreads();
+  float clip = 1.0f;
+  if (max_norm > 0.0f) {
+    const float coef = max_norm / (sqrtf(total) + 1e-6f);         // torch clip_grad_norm_
+    clip = coef < 1.0f ? coef : 1.0f;
+  }
+  const int i = blockIdx.x * kSmallOptThreads + threadIdx.x;
+  if (i < n) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, g[i] * grad_scale * clip, mm, vv, lr, beta1, beta2, eps, wd, inv_bc1, inv_sqrt_bc2);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (zero_grads) g[i] = 0.0f;
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -449,9 +489,13 @@ static int adamw_clip_impl(float* params, const float* grads, float* exp_avg, fl
 extern "C" size_t nerf_tv_codes_bytes(int64_t n) { return n > 0 ? (size_t)((n + 3) / 4) : 0; }
 
 extern "C" int nerf_tv_normsq_codes(const float* params, const float* grads, int64_t n, int n_tables, float tv_weight, float grad_scale,
-                                    float* normsq_dev, void* tv_codes, nerf_stream_t stream) {
+                                    float* normsq_dev, int accumulate, void* tv_codes, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && normsq_dev && n_tables >= 1 && n_tables <= 4 && n % n_tables == 0, "nerf_tv_normsq_codes: bad arguments");
-  if (n == 0) return NERF_OK;
+  if (n == 0) {        // nothing to add; a storing call still leaves the norm defined
+    if (!accumulate && hipMemsetAsync(normsq_dev, 0, sizeof(float), nerf::as_stream(stream)) != hipSuccess)
+      return nerf::fail(NERF_ELAUNCH, "nerf_tv_normsq_codes: memset failed");
+    return NERF_OK;
+  }
   const int64_t seg = n / n_tables;
   NERF_REQUIRE(n_tables == 1 || seg % 4 == 0, "nerf_tv_normsq_codes: %lld elements per table (a multiple of 4)", (long long)seg);
   NERF_REQUIRE(params && grads && (tv_weight == 0.0f || tv_codes), "nerf_tv_normsq_codes: NULL pointer");
@@ -469,13 +513,13 @@ extern "C" int nerf_tv_normsq_codes(const float* params, const float* grads, int
   if (fblocks < 1) fblocks = 1;
   if (fast && tv_scale != 0.0f)
     hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<true>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
-                       params, grads, (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)seg, codes, 0);
+                       params, grads, (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)seg, codes, 0, accumulate);
   else if (fast)
     hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<false>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
-                       params, grads, (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)seg, codes, 0);
+                       params, grads, (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)seg, codes, 0, accumulate);
   else
     hipLaunchKernelGGL(nerf::tv_normsq_codes_kernel, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n, tv_scale,
-                       grad_scale, normsq_dev, seg, codes);
+                       grad_scale, normsq_dev, seg, codes, accumulate);
   return nerf::check_launch("nerf_tv_normsq_codes");
 }
 
@@ -509,9 +553,13 @@ extern "C" int nerf_adamw_clip_step_tv(float* params, const float* grads, float*
 // at the piece's first code byte inside a buffer that has at least one byte before it (codes[-1] receives the sign of
 // params[0] - params[-1]).  n a multiple of 4, 16-byte aligned pointers.
 extern "C" int nerf_tv_normsq_codes_piece(const float* params, const float* grads, int64_t n, int64_t table_elems, int halo, float tv_weight,
-                                          float grad_scale, float* normsq_dev, void* tv_codes, nerf_stream_t stream) {
+                                          float grad_scale, float* normsq_dev, int accumulate, void* tv_codes, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && normsq_dev && table_elems >= n && halo >= 0 && halo <= 3, "nerf_tv_normsq_codes_piece: bad arguments");
-  if (n == 0) return NERF_OK;
+  if (n == 0) {
+    if (!accumulate && hipMemsetAsync(normsq_dev, 0, sizeof(float), nerf::as_stream(stream)) != hipSuccess)
+      return nerf::fail(NERF_ELAUNCH, "nerf_tv_normsq_codes_piece: memset failed");
+    return NERF_OK;
+  }
   NERF_REQUIRE(params && grads && (tv_weight == 0.0f || tv_codes), "nerf_tv_normsq_codes_piece: NULL pointer");
   NERF_REQUIRE((((uintptr_t)params | (uintptr_t)grads) & 15) == 0 && n % 4 == 0 && n < ((int64_t)1 << 31) - 16,
                "nerf_tv_normsq_codes_piece: 16-byte aligned pointers and n a multiple of 4");
@@ -522,10 +570,10 @@ extern "C" int nerf_tv_normsq_codes_piece(const float* params, const float* grad
   if (fblocks > n_cu) fblocks = n_cu;
   if (tv_scale != 0.0f)
     hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<true>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
-                       params, grads, (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)n, static_cast<uint8_t*>(tv_codes), halo);
+                       params, grads, (int)(n / 4), tv_scale, grad_scale, normsq_dev, (int)n, static_cast<uint8_t*>(tv_codes), halo, accumulate);
   else
     hipLaunchKernelGGL(nerf::tv_normsq_codes_fast_kernel<false>, dim3((int)fblocks), dim3(nerf::kTvFastThreads), 0, nerf::as_stream(stream),
-                       params, grads, (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)n, static_cast<uint8_t*>(tv_codes), 0);
+                       params, grads, (int)(n / 4), 0.0f, grad_scale, normsq_dev, (int)n, static_cast<uint8_t*>(tv_codes), 0, accumulate);
   return nerf::check_launch("nerf_tv_normsq_codes_piece");
 }
 
@@ -547,4 +595,25 @@ extern "C" int nerf_adamw_clip_step_tv_piece(float* params, const float* grads, 
                      static_cast<const uint8_t*>(tv_codes), n, sc, sc, static_cast<_Float16*>(params_f16_out), vec, n, lr,
                      (tv_codes && halo_lo) ? 1 : 0);
   return nerf::check_launch("nerf_adamw_clip_step_tv_piece");
+}
+
+// ---- one small group (n <= 65536: a tiny MLP's weights) in ONE launch (n / 1024 workgroups, each summing the whole gradient itself):
+// squared norm of grads * grad_scale (fixed order), global-norm
+// clip, AdamW (clip_grad_norm_ + AdamW.step() of reference run.py:624-629 for the decoder group).  normsq_out (nullable) receives
+// the squared norm; zero_grads: the gradient vector is left zeroed (the next backward accumulates into it).
+extern "C" int nerf_clip_adamw_small(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, float max_norm, float grad_scale,
+                                     float* normsq_out, int zero_grads, nerf_stream_t stream) {
+  NERF_REQUIRE(n >= 0 && n <= 65536 && step >= 1, "nerf_clip_adamw_small: n=%lld (at most 65536) step=%d", (long long)n, step);
+  if (n == 0) return NERF_OK;
+  NERF_REQUIRE(params && grads && exp_avg && exp_avg_sq, "nerf_clip_adamw_small: NULL pointer");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const int blocks = (int)((n + nerf::kSmallOptThreads - 1) / nerf::kSmallOptThreads);
+  hipLaunchKernelGGL(nerf::clip_adamw_small_kernel, dim3(blocks), dim3(nerf::kSmallOptThreads), 0, nerf::as_stream(stream), params, grads,
+                     exp_avg, exp_avg_sq, (int)n, lr, beta1, beta2, eps, weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), max_norm,
+                     grad_scale, normsq_out, (zero_grads && blocks == 1) ? 1 : 0);
+  if (int rc = nerf::check_launch("nerf_clip_adamw_small"); rc != NERF_OK) return rc;
+  if (zero_grads && blocks > 1 && hipMemsetAsync(grads, 0, sizeof(float) * (size_t)n, nerf::as_stream(stream)) != hipSuccess)
+    return nerf::fail(NERF_ELAUNCH, "nerf_clip_adamw_small: memset failed");
+  return NERF_OK;
 }

@@ -168,7 +168,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- ordered sum of V values per workgroup of a 1-D launch (instead of V same-address float atomics per workgroup) ----
 // Every workgroup publishes its values (thread 0 passes them) and takes a ticket; the workgroup that draws the last
-// ticket adds all partials IN WORKGROUP ORDER and accumulates the totals into *out[v] (null: skipped) -- the same bits
+// ticket adds all partials IN WORKGROUP ORDER and accumulates the totals into (accumulate false: stores them to) *out[v] (null:
+// skipped) -- the same bits
 // whatever the order the workgroups finished in.  ws: 1 + V * gridDim.x words, ws[0] (the ticket) zero before the first
 // launch; the last workgroup leaves it zero again.  Every access to ws is a returning device-scope atomic (coherent
 // across the XCDs' L2s without a cache write-back); the ticket is taken only after the partials' atomics have returned.
@@ -176,7 +177,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 constexpr int kOrderedSumMaxBlocks = 4096;
 inline size_t ordered_sum_ws_words(int n_values) { return 1 + (size_t)n_values * kOrderedSumMaxBlocks; }
 template <int V>
-__device__ __forceinline__ void ordered_block_sum(const float (&val)[V], float* const (&out)[V], unsigned* ws) {
+__device__ __forceinline__ void ordered_block_sum(const float (&val)[V], float* const (&out)[V], unsigned* ws, bool accumulate = true) {
   __shared__ unsigned last_block;
   const unsigned B = gridDim.x;
   if (threadIdx.x == 0) {
@@ -193,9 +194,27 @@ __device__ __forceinline__ void ordered_block_sum(const float (&val)[V], float* 
     float s = 0.0f;
     for (unsigned b = threadIdx.x; b < B; b += 64) s += __uint_as_float(atomicOr(&ws[1 + v * B + b], 0u));
     s = wave_sum(s);
-    if (threadIdx.x == 0 && out[v] != nullptr) *out[v] += s;
+    if (threadIdx.x == 0 && out[v] != nullptr) *out[v] = accumulate ? *out[v] + s : s;   // !accumulate: no zeroing launch before the call
   }
   if (threadIdx.x == 0) atomicExch(&ws[0], 0u);
+}
+
+// ---- largest |value| of a launch, for a consumer in a LATER launch: kAmaxSlots words instead of one.  A workgroup max-accumulates
+// its value (fp32 bits) into word (workgroup & 31): 1024 workgroups that finish together queue 32 deep on 32 addresses instead of
+// 1024 deep on one (same-address atomics retire one after the other, ~20 ns each: 8 us at the tail of a 10-us kernel).  The
+// consumer takes the maximum of all words.  Called by all threads of the workgroup; amax: the thread's own maximum (>= 0).
+constexpr int kAmaxSlots = 32;
+static_assert(kAmaxSlots == NERF_AMAX_WORDS, "include/nerf_hip.h");
+__device__ __forceinline__ void publish_amax_slots(float amax, unsigned* __restrict__ slots) {
+  __shared__ unsigned wg_amax;
+  if (threadIdx.x == 0) wg_amax = 0;
+  __syncthreads();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((threadIdx.x & 63) == 0 && amax > 0.0f && amax <= 3.0e38f) atomicMax(&wg_amax, __builtin_bit_cast(unsigned, amax));
+  __syncthreads();
+  unsigned* slot = slots + (blockIdx.x & (kAmaxSlots - 1));
+  if (threadIdx.x == 0 && wg_amax > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, wg_amax);
 }
 
 }  // namespace nerf

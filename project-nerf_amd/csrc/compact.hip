@@ -33,7 +33,8 @@ sample_compact_kernel(const float* __restrict__ rays_o, const float* __restrict_
                       const uint8_t* __restrict__ grid, int res, float bound, float scale,
                       float* __restrict__ z_out, int* __restrict__ slot_of_sample,
                       float* __restrict__ pts_c, float* __restrict__ dirs_c, unsigned* __restrict__ count,
-                      uint64_t key, uint64_t counter, int draw, uint64_t first_sample) {
+                      uint64_t key, uint64_t counter, int draw, uint64_t first_sample, unsigned* __restrict__ zero_out) {
+  if (zero_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_out = 0u;      // the NEXT call's counter (chained form)
   const int64_t total = n_rays * (int64_t)S;
   const int64_t span = (int64_t)kCompactThreads * kCompactPer;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -224,12 +225,18 @@ static int sample_compact_impl(const float* rays_o, const float* rays_d, const f
                                int resolution, float bound, float* z_out, int* slot_of_sample, float* pts_compact,
                                float* dirs_compact, unsigned* active_count, nerf_stream_t stream,
                                uint64_t key, uint64_t counter, int draw, uint64_t first_sample = 0, void* scratch = nullptr,
-                               size_t scratch_bytes = 0) {
+                               size_t scratch_bytes = 0, unsigned* next_count = nullptr) {
   NERF_REQUIRE(n_rays >= 0 && n_samples >= 2 && resolution > 0 && resolution <= 32768 && bound > 0.0f, "nerf_sample_compact: bad sizes");
   NERF_REQUIRE(active_count != nullptr, "nerf_sample_compact: active_count is NULL");
-  if (hipMemsetAsync(active_count, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
+  // chained form (next_count): active_count was cleared by the previous call of the chain (or by the caller), this call's kernel
+  // clears *next_count -- no fill launch per call
+  if (next_count == nullptr && hipMemsetAsync(active_count, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
     return fail(NERF_ELAUNCH, "nerf_sample_compact: memset failed");
-  if (n_rays == 0) return NERF_OK;
+  if (n_rays == 0) {
+    if (next_count != nullptr && hipMemsetAsync(next_count, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_sample_compact: memset failed");
+    return NERF_OK;
+  }
   NERF_REQUIRE(rays_o && rays_d && binary_grid && z_out && slot_of_sample && pts_compact && dirs_compact,
                "nerf_sample_compact: NULL pointer");
   const float step = 1.0f / (float)(n_samples - 1);
@@ -252,7 +259,7 @@ static int sample_compact_impl(const float* rays_o, const float* rays_d, const f
   }
   hipLaunchKernelGGL(sample_compact_kernel, dim3((int)blocks), dim3(kCompactThreads), 0, as_stream(stream), rays_o, rays_d, u, n_rays,
                      n_samples, near_plane, far_plane, step, binary_grid, resolution, bound, scale, z_out, slot_of_sample,
-                     pts_compact, dirs_compact, active_count, key, counter, draw, first_sample);
+                     pts_compact, dirs_compact, active_count, key, counter, draw, first_sample, next_count);
   return check_launch("nerf_sample_compact");
 }
 
@@ -274,6 +281,22 @@ extern "C" int nerf_sample_compact_jitter_shard(const float* rays_o, const float
   return sample_compact_impl(rays_o, rays_d, nullptr, n_rays, n_samples, near_plane, far_plane, binary_grid, resolution, bound,
                              z_out, slot_of_sample, pts_compact, dirs_compact, active_count, stream, squares_key(seed), counter, 1,
                              (uint64_t)first_ray * (uint64_t)n_samples);
+}
+
+// The same call as a link of a CHAIN of calls on one stream: active_count is NOT cleared here (it was cleared by the previous link, or
+// by the caller before the first), and the kernel clears *next_count, the counter the caller passes to the next link -- two counters
+// used alternately need no fill launch per call (4.3 us + its launch gap in a 0.5-ms step).
+extern "C" int nerf_sample_compact_jitter_chain(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,
+                                                int64_t first_ray, int64_t n_rays, int n_samples, float near_plane, float far_plane,
+                                                const uint8_t* binary_grid, int resolution, float bound, float* z_out,
+                                                int* slot_of_sample, float* pts_compact, float* dirs_compact,
+                                                unsigned* active_count, unsigned* next_count, nerf_stream_t stream) {
+  NERF_REQUIRE(first_ray >= 0 && counter < ((uint64_t)1 << 24) && (first_ray + n_rays) * (int64_t)n_samples < ((int64_t)1 << 40),
+               "nerf_sample_compact_jitter_chain: counter / batch out of range");
+  NERF_REQUIRE(next_count != nullptr && next_count != active_count, "nerf_sample_compact_jitter_chain: next_count NULL or equal to active_count");
+  return sample_compact_impl(rays_o, rays_d, nullptr, n_rays, n_samples, near_plane, far_plane, binary_grid, resolution, bound,
+                             z_out, slot_of_sample, pts_compact, dirs_compact, active_count, stream, squares_key(seed), counter, 1,
+                             (uint64_t)first_ray * (uint64_t)n_samples, nullptr, 0, next_count);
 }
 
 extern "C" int nerf_sample_compact_jitter(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,

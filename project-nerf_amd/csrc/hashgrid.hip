@@ -231,13 +231,17 @@ hash_fwd_kernel(const float* __restrict__ pts, int64_t n, int64_t n_pad, const T
 template <class TableT>
 __global__ void __launch_bounds__(256)
 hash_bwd_input_kernel(const float* __restrict__ pts, int64_t n, const TableT* __restrict__ table, HashLevels L,
-                      const float* __restrict__ d_feat, float* __restrict__ d_pts, int n_chunks) {
+                      const float* __restrict__ d_feat, float* __restrict__ d_pts, int n_chunks, const float2* __restrict__ grad_lm) {
   const LevelChunk lc = level_chunk(L.n_levels, n_chunks);
   if (lc.lvl >= L.n_levels) return;
   const int lvl = lc.lvl;
   const float two_b = 2.0f * L.bound;
   for (int64_t p = lc.chunk * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)lc.chunks * blockDim.x) {
-    const float g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0], g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1];
+    float g0, g1;
+    if (grad_lm != nullptr) {                    // level-major [L][n] float2: this launch walks one level per workgroup -- coalesced
+      const float2 g = grad_lm[(int64_t)lvl * n + p];
+      g0 = g.x; g1 = g.y;
+    } else { g0 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 0]; g1 = d_feat[p * (2 * L.n_levels) + 2 * lvl + 1]; }
     if (g0 == 0.0f && g1 == 0.0f) continue;
     const float px = pts[p * 3 + 0], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
     const Corner c = corners_of(L, lvl, px, py, pz);
@@ -275,7 +279,7 @@ hash_bwd_input_kernel(const float* __restrict__ pts, int64_t n, const TableT* __
 template <class TableT>
 __global__ void __launch_bounds__(256)
 hash_bwd_input_ordered_kernel(const float* __restrict__ pts, int64_t n, const TableT* __restrict__ table, HashLevels L,
-                              const float* __restrict__ d_feat, float* __restrict__ d_pts) {
+                              const float* __restrict__ d_feat, float* __restrict__ d_pts, int accumulate) {
   const float two_b = 2.0f * L.bound;
   for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
     const float px = pts[p * 3 + 0], py = pts[p * 3 + 1], pz = pts[p * 3 + 2];
@@ -311,7 +315,8 @@ hash_bwd_input_ordered_kernel(const float* __restrict__ pts, int64_t n, const Ta
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const bool inside = x01[a] >= 0.0f && x01[a] <= 1.0f;          // torch.clamp passes the gradient on its closed interval
-      d_pts[p * 3 + a] = inside ? sum[a] : 0.0f;
+      const float v = inside ? sum[a] : 0.0f;
+      d_pts[p * 3 + a] = accumulate ? d_pts[p * 3 + a] + v : v;
     }
   }
 }
@@ -406,8 +411,11 @@ struct BinPlan {
 
 struct BinHeader {                             // start of the workspace
   unsigned n_items, n_records, amax_bits, n_overflow;  // amax_bits: largest |d_feat| of the call as fp32 bits
-  unsigned lost, spec_total, pad0, pad1;       // speculative form: records dropped (overflow list full / plan did not fit); total capacity
-};
+  unsigned lost, spec_total, ticket, pad1;     // speculative form: records dropped (overflow list full / plan did not fit); total capacity;
+};                                             // ticket: workgroups of the call's last launch that are done
+constexpr int kAmaxSlotWord = 32;              // words [32, 32 + kAmaxSlots) of the header area: a producer's running maxima of |d_feat| (common.h),
+                                               // folded into amax_bits (and cleared) by the plan pass of the forms that do not count
+constexpr int kSpecStatusWord = 16;            // the speculative form's last launch publishes the header here (workspace + 64 bytes) ...
 struct BinItem {
   unsigned entry0, begin, end, atomic;         // first table entry of the slice, record range, flush: mode | live entries << 2
   unsigned bin;                                // the item's bin (speculative form: the range ends at the bin's cursor)
@@ -605,7 +613,7 @@ __device__ __forceinline__ int fixed_shift(unsigned amax_bits) {
 __global__ void __launch_bounds__(1024)
 hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, unsigned* __restrict__ cursor,
                      BinItem* __restrict__ items, BinHeader* __restrict__ header, int overwrite, unsigned chunk,
-                     unsigned* __restrict__ est, unsigned* __restrict__ start, unsigned spec_capacity) {
+                     unsigned* __restrict__ est, unsigned* __restrict__ start, unsigned spec_capacity, int fold_amax) {
   // est != null, spec_capacity == 0 (counted forms): the bins' true counts are also left in est for a later speculative call.
   // spec_capacity > 0 (speculative form): NO counts exist -- a bin's capacity is est + est / 8 + 64 (written to count[], which the
   // later passes read as the bin's size), its records start at start[bin]; the reduce pass reads the true fill from cursor[]
@@ -615,6 +623,14 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, u
   __shared__ unsigned carry_r, carry_i;
   const unsigned n_bins = plan.bin0[plan.count];
   if (threadIdx.x == 0) carry_r = carry_i = 0;
+  if (fold_amax && threadIdx.x < 64) {         // the producer's kAmaxSlots running maxima -> the call's amax_bits; slots cleared for the next call
+    unsigned* slots = reinterpret_cast<unsigned*>(header) + kAmaxSlotWord;
+    unsigned v = threadIdx.x < kAmaxSlots ? slots[threadIdx.x] : 0u;
+    if (threadIdx.x < kAmaxSlots) slots[threadIdx.x] = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+    if (threadIdx.x == 0) header->amax_bits = max(header->amax_bits, v);
+  }
   __syncthreads();
   for (unsigned base = 0; base < n_bins; base += 1024) {
     const unsigned b = base + threadIdx.x;
@@ -917,10 +933,13 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
   }
 }
 
-// speculative form: the records that did not fit their bins, added with float atomics (a handful per step in steady state)
+// speculative form: the records that did not fit their bins, added with float atomics (a handful per step in steady state).  The
+// call's LAST launch: the workgroup that finishes last publishes the header's eight status words (workspace + 64 bytes, and the
+// caller's host-mapped status block) and clears the header -- the next speculative call starts from a clean header with no fill
+// launch, and the host reads the status without a copy launch.
 __global__ void __launch_bounds__(256)
-hash_bin_overflow_kernel(const BinHeader* __restrict__ header, const BinRecord* __restrict__ overflow, const unsigned* __restrict__ overflow_bin,
-                         HashLevels L, BinPlan plan, float* __restrict__ d_table) {
+hash_bin_overflow_kernel(BinHeader* __restrict__ header, const BinRecord* __restrict__ overflow, const unsigned* __restrict__ overflow_bin,
+                         HashLevels L, BinPlan plan, float* __restrict__ d_table, unsigned* __restrict__ status_host) {
   const unsigned n = min(header->n_overflow, kMaxOverflow);
   const float inv_scale = __uint_as_float((unsigned)(127 - fixed_shift(header->amax_bits)) << 23);
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -934,6 +953,23 @@ hash_bin_overflow_kernel(const BinHeader* __restrict__ header, const BinRecord* 
     if (a0 != 0) atomicAdd(d_table + 2 * (size_t)entry + 0, __ll2float_rn(a0) * inv_scale);
     if (a1 != 0) atomicAdd(d_table + 2 * (size_t)entry + 1, __ll2float_rn(a1) * inv_scale);
   }
+  __syncthreads();                                               // every thread of this workgroup has read the header
+  __shared__ unsigned last;
+  if (threadIdx.x == 0) last = atomicAdd(&header->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (last == 0u || threadIdx.x >= 8) return;
+  unsigned* h = reinterpret_cast<unsigned*>(header);
+  const unsigned word = threadIdx.x >= 6 ? 0u : atomicOr(&h[threadIdx.x], 0u);     // the coherent copy (other launches' atomics)
+  if (threadIdx.x < 7) {
+    h[kSpecStatusWord + threadIdx.x] = word;
+    if (status_host != nullptr) status_host[threadIdx.x] = word;
+  }
+  __threadfence_system();
+  if (threadIdx.x == 7) {                        // word [7]: "published", written last (a host that cleared it before the call polls it)
+    h[kSpecStatusWord + 7] = 1u;
+    if (status_host != nullptr) status_host[7] = 1u;
+  }
+  atomicExch(&h[threadIdx.x], 0u);
 }
 
 static int fill_levels(HashLevels& L, int n_levels, const float* scale, const unsigned* res, const unsigned* size,
@@ -1008,9 +1044,9 @@ extern "C" int nerf_hash_encode_fwd_f16_hist(const float* pts, int64_t n, const 
 }
 
 extern "C" int nerf_hash_encode_bwd_ws_slots(void* workspace, int64_t n, int n_levels, void** amax_bits_out, void** grad_lm_out) {
-  NERF_REQUIRE(workspace && n > 0 && n_levels >= 1 && n_levels <= kMaxLevels && amax_bits_out && grad_lm_out, "nerf_hash_encode_bwd_ws_slots: bad arguments");
+  NERF_REQUIRE(workspace && n > 0 && n_levels >= 1 && n_levels <= kMaxPlanLevels && amax_bits_out && grad_lm_out, "nerf_hash_encode_bwd_ws_slots: bad arguments");
   const BinWorkspace w = carve(workspace, n, n_levels);
-  *amax_bits_out = &w.header->amax_bits;
+  *amax_bits_out = reinterpret_cast<unsigned*>(w.header) + kAmaxSlotWord;       // kAmaxSlots words (common.h::publish_amax_slots)
   *grad_lm_out = w.grad_lm;
   return NERF_OK;
 }
@@ -1077,7 +1113,7 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
                          int level0, int level1, nerf_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0,
-                         bool overwrite = false, int precounted = 0) {
+                         bool overwrite = false, int precounted = 0, void* status_host = nullptr) {
   // precounted: 0 the count pass runs here; 1 counts by the forward (nerf_hash_encode_fwd_f16_hist); 2 speculative: no counts at all
   // (capacities from the last call's true counts).  1 and 2: largest |gradient| and level-major gradients by nerf_imlp_bwd_lm
   const bool spec = precounted == 2;
@@ -1145,7 +1181,7 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
       NERF_REQUIRE(!spec || !any_direct, "nerf_hash_encode_bwd_ws_store_spec: a level with more than %u slices", kStagedBins);
       hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header,
                          overwrite ? 1 : 0, chunk, whole ? w.est : nullptr, spec ? w.start : nullptr,
-                         spec ? (unsigned)bin_record_capacity(n, n_levels) : 0u);
+                         spec ? (unsigned)bin_record_capacity(n, n_levels) : 0u, precounted != 0 ? 1 : 0);
       float* zero_table = overwrite ? d_table : nullptr;
       const unsigned* spec_start = spec ? w.start : nullptr;
       if (any_staged)
@@ -1162,7 +1198,7 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
                          d_table, table_entries, spec ? w.cursor : (const unsigned*)nullptr, spec_start, w.est);
       if (spec)
         hipLaunchKernelGGL(hash_bin_overflow_kernel, dim3(64), dim3(256), 0, as_stream(stream), w.header,
-                           w.records + bin_record_capacity(n, n_levels), w.overflow_bin, L, plan, d_table);
+                           w.records + bin_record_capacity(n, n_levels), w.overflow_bin, L, plan, d_table, static_cast<unsigned*>(status_host));
     }
   }
   if (options().deterministic && !binned && level0 < level1)
@@ -1253,11 +1289,11 @@ extern "C" size_t nerf_hash_encode_bwd_tables_workspace_bytes(int64_t n, int n_l
 
 // The overwrite-form scatter for n_tables tables of ONE level structure from the same points in one pass of count / plan /
 // scatter / reduce launches (Part 4's three deformation grids: three passes of four small launches otherwise).
-extern "C" int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n, int n_tables, int64_t table_stride, int n_levels,
-                                                    const float* scale_host, const unsigned* res_host, const unsigned* size_host,
-                                                    const unsigned* offset_host, const unsigned* dense_host, float bound,
-                                                    const float* d_feat, int64_t dfeat_stride, float* d_table, void* workspace,
-                                                    size_t workspace_bytes, nerf_stream_t stream) {
+static int hash_bwd_tables_impl(const float* pts, int64_t n, int n_tables, int64_t table_stride, int n_levels,
+                                const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                const float* d_feat, int64_t dfeat_stride, float* d_table, void* workspace,
+                                size_t workspace_bytes, nerf_stream_t stream, bool spec, void* status_host) {
   NERF_REQUIRE(n >= 0 && n_tables >= 1 && n_levels >= 1 && n_levels * n_tables <= kMaxPlanLevels && table_stride >= 0 && dfeat_stride >= 0,
                "nerf_hash_encode_bwd_ws_store_tables: n=%lld, %d tables of %d levels (at most %d virtual levels)", (long long)n, n_tables,
                n_levels, kMaxPlanLevels);
@@ -1273,7 +1309,7 @@ extern "C" int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n,
         return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws_store_tables: memset failed");
     return NERF_OK;
   }
-  NERF_REQUIRE(pts && d_feat && workspace && scale_host && res_host && dense_host, "nerf_hash_encode_bwd_ws_store_tables: NULL pointer");
+  NERF_REQUIRE(pts && (d_feat || spec) && workspace && scale_host && res_host && dense_host, "nerf_hash_encode_bwd_ws_store_tables: NULL pointer");
   HashLevels L;
   if (int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound); rc != NERF_OK) return rc;
   BinPlan plan;
@@ -1297,30 +1333,68 @@ extern "C" int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n,
   NERF_REQUIRE((size_t)n * 8 * (size_t)plan.count < 0xffffffffull, "nerf_hash_encode_bwd_ws_store_tables: n=%lld too large for 32-bit record offsets",
                (long long)n);
   const BinWorkspace w = carve(workspace, n, plan.count);
-  if (hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * n_bins, as_stream(stream)) != hipSuccess)
-    return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws_store_tables: memset failed");
-  int64_t bpm = (n + 255) / 256;
-  if (bpm > 1024) bpm = 1024;
-  const int per_row = pm_levels_per_row(n, plan.count);
-  hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm, (plan.count + per_row - 1) / per_row), dim3(256), 0, as_stream(stream), pts, n,
-                     L, plan, d_feat, w.count, w.header, w.grad_lm, per_row);
   const unsigned chunk = options().deterministic ? 0xffffffffu : kChunk;
+  const unsigned capacity = (unsigned)bin_record_capacity(n, plan.count);
+  const float2* grad_lm = w.grad_lm;
+  if (spec) {
+    // no count pass: capacities from the true counts the previous call on this workspace left in est[]; the chain's backward has
+    // max-accumulated the largest |gradient| into the header (nerf_hash_encode_bwd_ws_slots) and hands d_feat over row-major
+    NERF_REQUIRE(!any_direct && !options().deterministic, "nerf_hash_encode_bwd_ws_store_tables_spec: levels of at most %u slices, not with "
+                 "option \"deterministic\"", kStagedBins);
+    grad_lm = d_feat == nullptr ? w.grad_lm : nullptr;       // NULL d_feat: the producer wrote the level-major copy into the workspace
+  } else {
+    if (hipMemsetAsync(w.header, 0, 256 + sizeof(unsigned) * n_bins, as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_ws_store_tables: memset failed");
+    int64_t bpm = (n + 255) / 256;
+    if (bpm > 1024) bpm = 1024;
+    const int per_row = pm_levels_per_row(n, plan.count);
+    hipLaunchKernelGGL(hash_bin_count_pm_kernel, dim3((int)bpm, (plan.count + per_row - 1) / per_row), dim3(256), 0, as_stream(stream), pts, n,
+                       L, plan, d_feat, w.count, w.header, w.grad_lm, per_row);
+  }
+  // (the counted call leaves the bins' true counts in est[] for a later speculative one)
   hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header, 1, chunk,
-                     (unsigned*)nullptr, (unsigned*)nullptr, 0u);
+                     w.est, spec ? w.start : (unsigned*)nullptr, spec ? capacity : 0u, spec ? 1 : 0);
+  const unsigned* spec_start = spec ? w.start : nullptr;
   int64_t bx = (n + 511) / 512;
   const int64_t bx_scatter = bx > 128 ? 128 : bx;
   if (any_staged)
     hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
-                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0, chunk, (const unsigned*)nullptr, w.overflow_bin, w.header, 0u);
+                       d_feat, w.cursor, w.records, w.header, grad_lm, w.count, d_table, 0, chunk, spec_start, w.overflow_bin, w.header,
+                       spec ? capacity : 0u);
   if (any_direct)
     hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
-                       d_feat, w.cursor, w.records, w.header, w.grad_lm, w.count, d_table, 0, chunk, (const unsigned*)nullptr, w.overflow_bin, w.header, 0u);
+                       d_feat, w.cursor, w.records, w.header, grad_lm, w.count, d_table, 0, chunk, (const unsigned*)nullptr, w.overflow_bin, w.header, 0u);
   size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records, d_table,
-                     (unsigned)((uint64_t)(n_tables - 1) * (uint64_t)table_stride + entries), (const unsigned*)nullptr, (const unsigned*)nullptr,
-                     (unsigned*)nullptr);
+                     (unsigned)((uint64_t)(n_tables - 1) * (uint64_t)table_stride + entries), spec ? w.cursor : (const unsigned*)nullptr, spec_start,
+                     w.est);
+  if (spec)
+    hipLaunchKernelGGL(hash_bin_overflow_kernel, dim3(64), dim3(256), 0, as_stream(stream), w.header, w.records + capacity, w.overflow_bin, L,
+                       plan, d_table, static_cast<unsigned*>(status_host));
   return check_launch("nerf_hash_encode_bwd_ws_store_tables");
+}
+
+extern "C" int nerf_hash_encode_bwd_ws_store_tables(const float* pts, int64_t n, int n_tables, int64_t table_stride, int n_levels,
+                                                    const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                                    const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                                    const float* d_feat, int64_t dfeat_stride, float* d_table, void* workspace,
+                                                    size_t workspace_bytes, nerf_stream_t stream) {
+  return hash_bwd_tables_impl(pts, n, n_tables, table_stride, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat,
+                              dfeat_stride, d_table, workspace, workspace_bytes, stream, false, nullptr);
+}
+
+// ... its speculative form (see nerf_hash_encode_bwd_ws_store_spec): no count pass, capacities from the previous call's true counts
+// on this workspace; d_feat row-major, its largest magnitude max-accumulated into the slot nerf_hash_encode_bwd_ws_slots(workspace, n,
+// n_levels * n_tables, ...) names by the producer (nerf_p4_deform_bwd)
+extern "C" int nerf_hash_encode_bwd_ws_store_tables_spec(const float* pts, int64_t n, int n_tables, int64_t table_stride, int n_levels,
+                                                         const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                                         const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                                         const float* d_feat, int64_t dfeat_stride, float* d_table, void* workspace,
+                                                         size_t workspace_bytes, void* status_host, nerf_stream_t stream) {
+  NERF_REQUIRE(n > 0, "nerf_hash_encode_bwd_ws_store_tables_spec: n=%lld", (long long)n);
+  return hash_bwd_tables_impl(pts, n, n_tables, table_stride, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat,
+                              dfeat_stride, d_table, workspace, workspace_bytes, stream, true, status_host);
 }
 
 extern "C" int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_t n, int n_levels, const float* scale_host,
@@ -1339,7 +1413,7 @@ extern "C" int nerf_hash_encode_bwd_ws_store_precounted(const float* pts, int64_
 // added with a float atomic at the end; *header (nerf_hash_encode_bwd_spec_status) tells how many, and whether any was lost.
 extern "C" int nerf_hash_encode_bwd_spec_begin(void* workspace, nerf_stream_t stream) {
   NERF_REQUIRE(workspace != nullptr, "nerf_hash_encode_bwd_spec_begin: NULL workspace");
-  if (hipMemsetAsync(workspace, 0, sizeof(BinHeader), as_stream(stream)) != hipSuccess)
+  if (hipMemsetAsync(workspace, 0, 256, as_stream(stream)) != hipSuccess)        // header, status block, the producer's amax words
     return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_spec_begin: memset failed");
   return NERF_OK;
 }
@@ -1347,50 +1421,55 @@ extern "C" int nerf_hash_encode_bwd_spec_begin(void* workspace, nerf_stream_t st
 extern "C" int nerf_hash_encode_bwd_ws_store_spec(const float* pts, int64_t n, int n_levels, const float* scale_host,
                                                   const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                                                   const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
-                                                  void* workspace, size_t workspace_bytes, nerf_stream_t stream) {
+                                                  void* workspace, size_t workspace_bytes, void* status_host, nerf_stream_t stream) {
   NERF_REQUIRE(n > 0 && workspace != nullptr, "nerf_hash_encode_bwd_ws_store_spec: n=%lld, workspace %p", (long long)n, workspace);
   NERF_REQUIRE(!options().deterministic, "nerf_hash_encode_bwd_ws_store_spec: overflow records end in float atomics (option \"deterministic\" is set)");
   return hash_bwd_impl(pts, n, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat, d_table, 0, n_levels,
-                       stream, workspace, workspace_bytes, true, 2);
+                       stream, workspace, workspace_bytes, true, 2, status_host);
 }
 
-// device address of the workspace's 8-word status block: [0] items, [1] record capacity planned, [2] largest |gradient| bits,
-// [3] records that went to the overflow list, [4] != 0: records were LOST (the gradient of that call is incomplete: 1 the overflow list
-// was full, 2 the estimates did not fit the workspace), [5] capacity planned
-extern "C" const void* nerf_hash_encode_bwd_spec_status(const void* workspace) { return workspace; }
+// device address of the 8-word status block the LAST speculative call published: [0] items, [1] record capacity planned, [2] largest
+// |gradient| bits, [3] records that went to the overflow list, [4] != 0: records were LOST (the gradient of that call is incomplete: 1
+// the overflow list was full, 2 the estimates did not fit the workspace), [5] capacity planned.  The same eight words go to the
+// status_host block given to the call (host-mapped pinned memory: readable once an event recorded behind the call has completed).
+extern "C" const void* nerf_hash_encode_bwd_spec_status(const void* workspace) {
+  return workspace == nullptr ? nullptr : static_cast<const char*>(workspace) + sizeof(unsigned) * kSpecStatusWord;
+}
 
 static int hash_bwd_input_impl(const float* pts, int64_t n, const float* table, const void* table_f16, int n_levels,
                                const float* scale_host, const unsigned* res_host, const unsigned* size_host,
                                const unsigned* offset_host, const unsigned* dense_host, float bound,
-                               const float* d_feat, float* d_pts, nerf_stream_t stream) {
+                               const float* d_feat, float* d_pts, nerf_stream_t stream, int accumulate = 0,
+                               const float2* grad_lm = nullptr) {
   NERF_REQUIRE(n >= 0, "nerf_hash_encode_bwd_input: n=%lld", (long long)n);
   if (n == 0) return NERF_OK;
-  NERF_REQUIRE(pts && (table || table_f16) && d_feat && d_pts && scale_host && res_host && size_host && offset_host && dense_host,
+  NERF_REQUIRE(pts && (table || table_f16) && (d_feat || grad_lm) && d_pts && scale_host && res_host && size_host && offset_host && dense_host,
                "nerf_hash_encode_bwd_input: NULL pointer");
   HashLevels L;
   int rc = fill_levels(L, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound);
   if (rc != NERF_OK) return rc;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  NERF_REQUIRE(!(options().deterministic && grad_lm != nullptr), "nerf_hash_encode_bwd_input_lm: not with option \"deterministic\"");
   if (options().deterministic) {          // levels summed in order per point: no float atomics
     if (table_f16 != nullptr)
       hipLaunchKernelGGL(hash_bwd_input_ordered_kernel<half2_t>, dim3((int)blocks), dim3(256), 0, as_stream(stream), pts, n,
-                         static_cast<const half2_t*>(table_f16), L, d_feat, d_pts);
+                         static_cast<const half2_t*>(table_f16), L, d_feat, d_pts, accumulate);
     else
       hipLaunchKernelGGL(hash_bwd_input_ordered_kernel<float2>, dim3((int)blocks), dim3(256), 0, as_stream(stream), pts, n,
-                         reinterpret_cast<const float2*>(table), L, d_feat, d_pts);
+                         reinterpret_cast<const float2*>(table), L, d_feat, d_pts, accumulate);
     return check_launch("nerf_hash_encode_bwd_input (ordered)");
   }
-  if (hipMemsetAsync(d_pts, 0, sizeof(float) * 3 * (size_t)n, as_stream(stream)) != hipSuccess)
+  if (!accumulate && hipMemsetAsync(d_pts, 0, sizeof(float) * 3 * (size_t)n, as_stream(stream)) != hipSuccess)
     return fail(NERF_ELAUNCH, "nerf_hash_encode_bwd_input: memset failed");
   const bool xcd = options().hash_xcd != 0;
   const dim3 grid = level_chunk_grid(n_levels, blocks, xcd);
   if (table_f16 != nullptr)
     hipLaunchKernelGGL(hash_bwd_input_kernel<half2_t>, grid, dim3(256), 0, as_stream(stream), pts, n,
-                       static_cast<const half2_t*>(table_f16), L, d_feat, d_pts, xcd ? (int)blocks : 0);
+                       static_cast<const half2_t*>(table_f16), L, d_feat, d_pts, xcd ? (int)blocks : 0, grad_lm);
   else
     hipLaunchKernelGGL(hash_bwd_input_kernel<float2>, grid, dim3(256), 0, as_stream(stream), pts, n,
-                       reinterpret_cast<const float2*>(table), L, d_feat, d_pts, xcd ? (int)blocks : 0);
+                       reinterpret_cast<const float2*>(table), L, d_feat, d_pts, xcd ? (int)blocks : 0, grad_lm);
   return check_launch("nerf_hash_encode_bwd_input");
 }
 
@@ -1400,6 +1479,27 @@ extern "C" int nerf_hash_encode_bwd_input(const float* pts, int64_t n, const flo
                                           const float* d_feat, float* d_pts, nerf_stream_t stream) {
   return hash_bwd_input_impl(pts, n, table, nullptr, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound, d_feat,
                              d_pts, stream);
+}
+
+// the same, ADDED to d_pts (a gradient that reaches the positions by another path as well -- Part 4: the displacement regulariser's --
+// is already there: no zeroing launch, no separate add)
+extern "C" int nerf_hash_encode_bwd_input_f16_accum(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                                    const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                                    const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                                    const float* d_feat, float* d_pts, nerf_stream_t stream) {
+  return hash_bwd_input_impl(pts, n, nullptr, table_f16, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound,
+                             d_feat, d_pts, stream, 1);
+}
+
+// ... from LEVEL-MAJOR feature gradients [n_levels][n] float2 (what a producer writes into the hash backward's workspace for the
+// speculative scatter, nerf_hash_encode_bwd_ws_slots); accumulate != 0: added to d_pts
+extern "C" int nerf_hash_encode_bwd_input_lm_f16(const float* pts, int64_t n, const void* table_f16, int n_levels,
+                                                 const float* scale_host, const unsigned* res_host, const unsigned* size_host,
+                                                 const unsigned* offset_host, const unsigned* dense_host, float bound,
+                                                 const void* grad_lm, float* d_pts, int accumulate, nerf_stream_t stream) {
+  NERF_REQUIRE(n == 0 || grad_lm != nullptr, "nerf_hash_encode_bwd_input_lm_f16: grad_lm is NULL");
+  return hash_bwd_input_impl(pts, n, nullptr, table_f16, n_levels, scale_host, res_host, size_host, offset_host, dense_host, bound,
+                             nullptr, d_pts, stream, accumulate, static_cast<const float2*>(grad_lm));
 }
 
 extern "C" int nerf_hash_encode_bwd_input_f16(const float* pts, int64_t n, const void* table_f16, int n_levels,

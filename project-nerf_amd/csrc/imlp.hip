@@ -92,7 +92,8 @@ struct IArgs {
   __bf16* dzs1; __bf16* dzs2; __bf16* dzc1; __bf16* dzc2; __bf16* dsmall;
   float* d_feat;            // [n,32] fp32
   float2* grad_lm;          // instead of d_feat: level-major gradients [16][n] float2 (the binned hash backward's input)
-  unsigned* amax_bits;      // with grad_lm: running maximum of |d_feat| as fp32 bits (the scatter's fixed-point scale)
+  unsigned* amax_bits;      // kAmaxSlots words: running maxima of |d_feat| as fp32 bits (the scatter's fixed-point scale)
+  float* zero_grads;        // backward: the weight-gradient vector [kIParams], cleared here for the wgrad launch that follows and ADDS
 };
 
 template <int STEP, int KS, class Epi>
@@ -188,6 +189,8 @@ __global__ void __launch_bounds__(kIThreads) imlp_bwd_kernel(const IArgs a) {
   __syncthreads();
   const char* wbase = smem + lane * 16 - kIFwdFrags * 1024;   // istep().frag0 counts from the forward stream
   const int64_t n_tiles = a.n_pad / kITile;
+  if (a.zero_grads != nullptr)                                // instead of a fill launch before this one (4.5 us + its gap)
+    for (int i = blockIdx.x * kIThreads + tid; i < kIParams; i += gridDim.x * kIThreads) a.zero_grads[i] = 0.0f;
   float amax = 0.0f;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t wt = tile * 4 + wave, n = wt * 32 + col;
@@ -251,18 +254,9 @@ __global__ void __launch_bounds__(kIThreads) imlp_bwd_kernel(const IArgs a) {
       }
     });
   }
-  if (a.amax_bits != nullptr) {
-    // ONE global atomic per workgroup at most, none once a larger value is visible: same-address atomics retire one after the other
-    // (~20 ns each): one per wave -- 4096 of them -- doubled this kernel's time
-    __shared__ unsigned wg_amax;
-    if (threadIdx.x == 0) wg_amax = 0;
-    __syncthreads();
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-    if (lane == 0 && amax > 0.0f && amax <= 3.0e38f) atomicMax(&wg_amax, __builtin_bit_cast(unsigned, amax));
-    __syncthreads();
-    if (threadIdx.x == 0 && wg_amax > __hip_atomic_load(a.amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.amax_bits, wg_amax);
-  }
+  // one atomic per workgroup at most, spread over kAmaxSlots words (common.h): one per wave on ONE word -- 4096 of them -- doubled this
+  // kernel's time, one per workgroup on one word still cost ~8 us of queueing at the kernel's tail
+  if (a.amax_bits != nullptr) publish_amax_slots(amax, a.amax_bits);
 }
 
 struct ILayout {
@@ -389,12 +383,15 @@ static int imlp_bwd_impl(const void* packed, void* workspace, const float* rgb, 
                          const float* d_sigma, int64_t n, float* grads_f32, float* d_feat, float2* grad_lm, unsigned* amax_bits,
                          nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && grads_f32, "nerf_imlp_bwd: bad arguments");
-  if (hipMemsetAsync(grads_f32, 0, sizeof(float) * kIParams, as_stream(stream)) != hipSuccess)
-    return fail(NERF_ELAUNCH, "nerf_imlp_bwd: memset failed");
-  if (n == 0) return NERF_OK;
+  if (n == 0) {
+    if (hipMemsetAsync(grads_f32, 0, sizeof(float) * kIParams, as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_imlp_bwd: memset failed");
+    return NERF_OK;
+  }
   NERF_REQUIRE(packed && workspace && rgb && sigma && d_rgb && d_sigma && (d_feat || grad_lm), "nerf_imlp_bwd: NULL pointer");
   IArgs a = iargs(packed, workspace, nullptr, n, const_cast<float*>(rgb), const_cast<float*>(sigma));
   a.d_rgb = d_rgb; a.d_sigma = d_sigma; a.d_feat = d_feat; a.grad_lm = grad_lm; a.amax_bits = amax_bits;
+  a.zero_grads = grads_f32;            // the dgrad kernel clears the vector the wgrad launch behind it adds to
   const int grid = grid_for_tiles(a.n_pad / kITile);
   if (grid <= 0) return fail(NERF_ELAUNCH, "nerf_imlp_bwd: cannot query device");
   hipLaunchKernelGGL(imlp_bwd_kernel, dim3(grid), dim3(kIThreads), kIBwdFrags * 1024, as_stream(stream), a);

@@ -242,6 +242,9 @@ struct DeformArgs {
   float* d_feat[3];        // [n,24] fp32 gradients for the three grids' scatter
   float* g_scale;          // parameter-gradient slot of displacement_scale (accumulated)
   unsigned* sum_ws;        // non-null (option "deterministic"): workspace of common.h::ordered_block_sum for g_scale
+  unsigned* amax_bits;     // non-null: kAmaxSlots words that max-accumulate the largest |d_feat| as fp32 bits (common.h; the hash scatter's scale)
+  float2* grad_lm;         // non-null: INSTEAD of d_feat, level-major gradients [3 * 12][n] (virtual level = grid * 12 + level): the
+                           // layout the binned hash scatter reads coalesced (its count pass writes it otherwise)
 };
 
 __device__ __forceinline__ void triangle_weights(float t, float (&w)[3]) {
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(kThreads) deform_bwd_kernel(const DeformArgs a
   __syncthreads();
   const char* wbase = smem + lane * 16 - kDeformBwd0 * 1024;
   const float scale = a.params[kScale];
-  float gscale_local = 0.0f;
+  float gscale_local = 0.0f, amax = 0.0f;
   const int64_t n_tiles = a.n_pad / kTile;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t wt = tile * 4 + wave, n = wt * 32 + col;
@@ -423,8 +426,18 @@ __global__ void __launch_bounds__(kThreads) deform_bwd_kernel(const DeformArgs a
 #pragma unroll
           for (int q = 0; q < 3; ++q) {                              // rows 8q + 4 half + (0..3) < 24
             f32x4 v = {acc[4 * q] * w[k], acc[4 * q + 1] * w[k], acc[4 * q + 2] * w[k], acc[4 * q + 3] * w[k]};
-            *reinterpret_cast<f32x4*>(a.d_feat[k] + n * kHashDeform + 8 * q + 4 * half) = v;
+            if (a.grad_lm != nullptr) {                              // levels 4q + 2 half, + 1 of grid k
+              float2* lm = a.grad_lm + (int64_t)(k * (kHashDeform / 2) + 4 * q + 2 * half) * a.n + n;
+              lm[0] = make_float2(v[0], v[1]);
+              lm[a.n] = make_float2(v[2], v[3]);
+            } else *reinterpret_cast<f32x4*>(a.d_feat[k] + n * kHashDeform + 8 * q + 4 * half) = v;
           }
+        }
+        if (a.amax_bits != nullptr) {             // the largest STORED gradient (the scale the counting form would find)
+          float m = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 12; ++r) m = fmaxf(m, fabsf(acc[r]));
+          amax = fmaxf(amax, m * fmaxf(fmaxf(w[0], w[1]), w[2]));
         }
       }
     });
@@ -446,6 +459,7 @@ __global__ void __launch_bounds__(kThreads) deform_bwd_kernel(const DeformArgs a
     float* const out[1] = {a.g_scale};
     ordered_block_sum<1>(val, out, a.sum_ws);
   } else if (threadIdx.x == 0 && sum != 0.0f) atomicAdd(a.g_scale, sum);
+  if (a.amax_bits != nullptr) publish_amax_slots(amax, a.amax_bits);
 }
 
 // ------------------------------------------------------------------------------------------------ canonical chain
@@ -462,6 +476,8 @@ struct CanonArgs {
   const float* d_rgb; const float* d_sigma;
   __bf16* dzs1; __bf16* dzs2; __bf16* dzc1; __bf16* dzc2; __bf16* dsmall;
   float* d_feat;           // [n,32]
+  unsigned* amax_bits;     // non-null: kAmaxSlots words that max-accumulate the largest |d_feat| as fp32 bits (common.h; the hash scatter's scale)
+  float2* grad_lm;         // non-null: INSTEAD of d_feat, level-major gradients [16][n]
 };
 
 template <bool TRAIN>
@@ -557,6 +573,7 @@ __global__ void __launch_bounds__(kThreads) canon_bwd_kernel(const CanonArgs a) 
   __syncthreads();
   const char* wbase = smem + lane * 16 - kCanonBwd0 * 1024;
   const int64_t n_tiles = a.n_pad / kTile;
+  float amax = 0.0f;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t wt = tile * 4 + wave, n = wt * 32 + col;
     const bool live = n < a.n;
@@ -598,11 +615,20 @@ __global__ void __launch_bounds__(kThreads) canon_bwd_kernel(const CanonArgs a) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-          *reinterpret_cast<f32x4*>(a.d_feat + n * 32 + 8 * q + 4 * half) = v;
+          if (a.grad_lm != nullptr) {                                // levels 4q + 2 half, + 1
+            float2* lm = a.grad_lm + (int64_t)(4 * q + 2 * half) * a.n + n;
+            lm[0] = make_float2(v[0], v[1]);
+            lm[a.n] = make_float2(v[2], v[3]);
+          } else *reinterpret_cast<f32x4*>(a.d_feat + n * 32 + 8 * q + 4 * half) = v;
+        }
+        if (a.amax_bits != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(acc[r]));
         }
       }
     });
   }
+  if (a.amax_bits != nullptr) publish_amax_slots(amax, a.amax_bits);
 }
 
 // ------------------------------------------------------------------------------------------------ per-sample inputs
@@ -790,12 +816,13 @@ static WgradJob make_job(const char* w, size_t a_off, int a_bytes, int mt_a, siz
 // ACCUMULATED into grads_f32 (the caller zeroes the vector once per step: several passes -- data batch, regulariser
 // probes -- add into it)
 extern "C" int nerf_p4_canon_bwd(const void* packed, void* workspace, const float* rgb, const float* sigma, const float* d_rgb,
-                                 const float* d_sigma, int64_t n, float* grads_f32, nerf_stream_t stream) {
+                                 const float* d_sigma, int64_t n, float* grads_f32, void* amax_bits, void* grad_lm, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && grads_f32, "nerf_p4_canon_bwd: bad arguments");
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(packed && workspace && rgb && sigma && d_rgb && d_sigma, "nerf_p4_canon_bwd: NULL pointer");
   CanonArgs a = canon_args(packed, workspace, n);
   a.rgb = const_cast<float*>(rgb); a.sigma = const_cast<float*>(sigma); a.d_rgb = d_rgb; a.d_sigma = d_sigma;
+  a.amax_bits = static_cast<unsigned*>(amax_bits); a.grad_lm = static_cast<float2*>(grad_lm);
   const int grid = grid_for(a.n_pad / kTile);
   if (grid <= 0) return fail(NERF_ELAUNCH, "nerf_p4_canon_bwd: cannot query device");
   hipLaunchKernelGGL(p4::canon_bwd_kernel, dim3(grid), dim3(kThreads), kCanonBwdN * 1024, as_stream(stream), a);
@@ -818,12 +845,13 @@ extern "C" int nerf_p4_canon_bwd(const void* packed, void* workspace, const floa
 // multiplied by the blend weights), the time-modulation and displacement-decoder weight gradients and the gradient of
 // displacement_scale ACCUMULATED into grads_f32
 extern "C" int nerf_p4_deform_bwd(const void* packed, const float* params_f32, void* workspace, const float* d_delta_x, int64_t n,
-                                  float* grads_f32, nerf_stream_t stream) {
+                                  float* grads_f32, void* amax_bits, void* grad_lm, nerf_stream_t stream) {
   NERF_REQUIRE(n >= 0 && grads_f32, "nerf_p4_deform_bwd: bad arguments");
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(packed && params_f32 && workspace && d_delta_x, "nerf_p4_deform_bwd: NULL pointer");
   DeformArgs a = deform_args(packed, params_f32, workspace, n);
-  a.d_dx = d_delta_x; a.g_scale = grads_f32 + kScale;
+  a.d_dx = d_delta_x; a.g_scale = grads_f32 + kScale; a.amax_bits = static_cast<unsigned*>(amax_bits);
+  a.grad_lm = static_cast<float2*>(grad_lm);
   const int grid = grid_for(a.n_pad / kTile);
   if (grid <= 0) return fail(NERF_ELAUNCH, "nerf_p4_deform_bwd: cannot query device");
   const bool det = options().deterministic != 0;

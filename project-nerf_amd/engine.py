@@ -272,9 +272,8 @@ class InstantNgpEngine:
         # previous step's call; records that do not fit are added with atomics by a last small launch, a lost record (never seen in
         # training; the status block is read back one step late) switches the form off.  Used when the occupancy grid is the one
         # the estimates were taken on and the active-sample count is within 10 % of that call's
-        self.spec_bwd = bool(cfg.get("speculative_hash_backward", True)) and not os.environ.get("NERF_NO_SPECULATIVE_BWD")   # env: A/B aid
-        self._spec_from = None          # (workspace address, occupancy-grid identity, point count) of the call that left the estimates
-        self._spec_pending = None       # (pinned status words, event) of the last speculative call
+        from .specbwd import SpeculativeScatter
+        self.spec = SpeculativeScatter(bool(cfg.get("speculative_hash_backward", True)) and not os.environ.get("NERF_NO_SPECULATIVE_BWD"))  # env: A/B aid
         self._table_h_buf = torch.zeros(n_pad, device=self.device, dtype=torch.float16) if self.half_table else None
         self.table_h = self._table_h_buf[:n_tab] if self.half_table else None
         self._table_version = None
@@ -292,7 +291,7 @@ class InstantNgpEngine:
         self.step_count, self.world_size = 0, world_size
         self._scratch = ops.normsq_ws(self.device)
         self._net_scratch = ops.normsq_ws(self.device)
-        self._loss_ring = torch.zeros(1024, device=self.device)
+        self._loss_ring = torch.zeros(65536, device=self.device)      # a step's loss is a VIEW of its slot: valid for the next 32768 steps
 
     def lr(self) -> float:
         import math
@@ -416,16 +415,18 @@ class InstantNgpEngine:
             precount = sync_grads_async is None and self.half_table and self.precount
             hws = self._hash_bwd_workspace(n)
             grid_id = (self.binary_grid.data_ptr(), self.binary_grid._version)
-            spec = self._speculative_ok(hws, grid_id, n) and sync_grads_async is None and not precount
+            spec = sync_grads_async is None and not precount and self.half_table and self.spec.ok(hws.data_ptr(), grid_id, n)
             if spec:
-                ops._lib.check(lib.nerf_hash_encode_bwd_spec_begin(hws.data_ptr(), ops._stream()), "nerf_hash_encode_bwd_spec_begin")
+                self.spec.begin(hws)               # (a launch only after a counted call: a speculative call leaves the header clean)
             rgb, sigma, ws = self._field(pts, dirs, True, hist_ws=hws if precount else None)
             P = lambda t: t.data_ptr()
-            # a fresh zeroed loss slot per step out of a ring cleared once per lap (no fill launch per step)
+            # a fresh zeroed loss slot per step out of a ring cleared half a lap ahead (no fill launch, no copy launch per step: the
+            # returned loss is a view of the slot)
             self._grad_calls = getattr(self, "_grad_calls", -1) + 1
-            slot = self._grad_calls % self._loss_ring.numel()
-            if slot == 0:
-                self._loss_ring.zero_()
+            ring = self._loss_ring.numel()
+            slot = self._grad_calls % ring
+            if slot % (ring // 2) == 0 and self._grad_calls > 0:
+                self._loss_ring[slot:slot + ring // 2].zero_()
             loss = self._loss_ring[slot:slot + 1]
             d_rgb, d_sigma, _ = ops.composite_mse_bwd(rgb, sigma, z, rays_d, self.bg, target, loss, slots=slots)
             if precount or spec:
@@ -437,21 +438,17 @@ class InstantNgpEngine:
                 ops._lib.check(lib.nerf_imlp_bwd_lm(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(self.g_net),
                                                     lm_p, amax_p, ops._stream()), "nerf_imlp_bwd_lm")
                 if spec:                           # no count pass: capacities from the last call's true counts
+                    status = self.spec.status_block()
                     ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_spec(P(pts), n, self.levels.n_levels, *self.levels.host_args(),
                                                                           float(self.bound), None, P(self.g_table), P(hws), hws.numel(),
-                                                                          ops._stream()), "nerf_hash_encode_bwd_ws_store_spec")
+                                                                          status.data_ptr(), ops._stream()), "nerf_hash_encode_bwd_ws_store_spec")
+                    self.spec.issued(hws, grid_id, n, status)
                 else:
                     ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_precounted(P(pts), n, self.levels.n_levels, *self.levels.host_args(),
                                                                                 float(self.bound), P(self.g_table), P(hws), hws.numel(),
                                                                                 ops._stream()), "nerf_hash_encode_bwd_ws_store_precounted")
-                self._spec_from = (hws.data_ptr(), grid_id, n)
-                if spec:                           # status words read back without waiting: checked before the next speculative call
-                    status = torch.empty(8, dtype=torch.int32, pin_memory=True)
-                    status.copy_(hws[:32].view(torch.int32), non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    self._spec_pending = (status, ev)
-                return loss[0].clone()
+                    self.spec.counted(hws, grid_id, n)
+                return loss[0]
             d_feat = torch.empty(n, 2 * self.levels.n_levels, device=self.device)
             ops._lib.check(lib.nerf_imlp_bwd(P(self.packed), P(ws), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n,
                                              P(self.g_net), P(d_feat), ops._stream()), "nerf_imlp_bwd")
@@ -459,35 +456,19 @@ class InstantNgpEngine:
             # overwrite form: the table gradient is stored slice by slice -- no 52 MB memset, no read-back
             if sync_grads_async is None:
                 ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, workspace=hws, overwrite=True)
-                self._spec_from = (hws.data_ptr(), grid_id, n)      # the counted call left the bins' true counts in the workspace
+                self.spec.counted(hws, grid_id, n)                  # the counted call left the bins' true counts in the workspace
             else:
                 for lo, hi in self.level_groups():
                     ops.hash_encode_bwd(pts, self.levels, self.bound, d_feat, self.g_table, level_range=(lo, hi), workspace=hws, overwrite=True)
                     reduce(table_slice(lo, hi))
-            loss = loss[0].clone()
+                self.spec.invalidate()                              # level-range calls: no estimates for all levels
+            loss = loss[0]
         for h, wire, view in handles:
             if h is not None:
                 h.wait()
             if wire is not None:
                 view.copy_(wire)
         return loss
-
-    def _speculative_ok(self, hws: Tensor, grid_id, n: int) -> bool:
-        """may this step's hash backward trust the record counts the last call left in the workspace?"""
-        if not (self.spec_bwd and self.half_table) or ops.deterministic() or self._spec_from is None:
-            return False
-        if self._spec_pending is not None:
-            status, ev = self._spec_pending
-            if ev.query():
-                self._spec_pending = None
-                if int(status[4]) != 0:
-                    import warnings
-                    warnings.warn(f"speculative hash backward: records were lost (status {status.tolist()}): one step's table gradient was "
-                                  "incomplete; the counted form is used from here on")
-                    self.spec_bwd = False
-                    return False
-        ws_ptr, last_grid, n_last = self._spec_from
-        return ws_ptr == hws.data_ptr() and last_grid == grid_id and 0.5 * n_last <= n <= 1.1 * n_last
 
     def _hash_bwd_workspace(self, n: int) -> Tensor:
         """Workspace of the binned hash-gradient scatter, grown to the largest point count seen (8 B per corner
@@ -528,8 +509,7 @@ class InstantNgpEngine:
             # for the table's squared norm; the tiny MLPs (their own clip, reference run.py:624-627) stepped on every rank
             import torch.distributed as dist
             normsq = self._scratch
-            normsq[:2].zero_()
-            self.shard.accumulate_normsq(normsq, scale)
+            self.shard.accumulate_normsq(normsq, scale, first=True)
             if self.world_size > 1:
                 dist.all_reduce(normsq[0:1], op=dist.ReduceOp.SUM)
             self.shard.adamw(normsq, self.step_count, lr, self.wd, 1.0, scale)

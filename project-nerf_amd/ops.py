@@ -162,10 +162,27 @@ def normsq_ws(device) -> Tensor:
     return torch.zeros(_lib.NORMSQ_WS_FLOATS, device=device)
 
 
+_COMPACT_CHAIN = {}
+
+
 def _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, count):
-    """the compaction launch of sample_compact / sample_compact_async: ordered slots when deterministic"""
+    """the compaction launch of sample_compact / sample_compact_async: ordered slots when deterministic.  ``count`` None (the
+    asynchronous path with in-kernel jitter): two counters per (device, stream) used alternately, each call's kernel clearing the
+    next call's (nerf_sample_compact_jitter_chain: no fill launch per call); returns the counter the call used."""
     draw = u is None and jitter is not None
     seed, counter = (int(jitter[0]), int(jitter[1]) & 0xFFFFFF) if draw else (0, 0)
+    if count is None:
+        if draw and not deterministic():
+            key = (rays_o.device, _stream())
+            pair, turn = _COMPACT_CHAIN.get(key, (None, 0))
+            if pair is None:
+                pair = torch.zeros(2, device=rays_o.device, dtype=torch.int32)
+            _COMPACT_CHAIN[key] = (pair, turn ^ 1)
+            _lib.check(lib.nerf_sample_compact_jitter_chain(_p(rays_o), _p(rays_d), seed, counter, int(first_ray), R, n_samples, near, far,
+                                                            _p(grid), grid.shape[0], float(bound), _p(z), _p(slots), _p(pts), _p(dirs),
+                                                            _p(pair[turn:]), _p(pair[turn ^ 1:]), _stream()), "nerf_sample_compact_jitter_chain")
+            return pair[turn:turn + 1]
+        count = torch.empty(1, device=rays_o.device, dtype=torch.int32)          # cleared by the library call itself
     if deterministic():
         scratch = torch.empty(max(lib.nerf_sample_compact_ordered_scratch_bytes(R, n_samples), 4), dtype=torch.uint8, device=rays_o.device)
         _lib.check(lib.nerf_sample_compact_ordered(_p(rays_o), _p(rays_d), _p(u), 1 if draw else 0, seed, counter, int(first_ray), R, n_samples,
@@ -179,6 +196,7 @@ def _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, nea
         _lib.check(lib.nerf_sample_compact(_p(rays_o), _p(rays_d), _p(u), R, n_samples, near, far, _p(grid), grid.shape[0],
                                            float(bound), _p(z), _p(slots), _p(pts), _p(dirs), _p(count), _stream()),
                    "nerf_sample_compact")
+    return count
 
 
 # --------------------------------------------------------------------------- a1-a4 fused
@@ -198,7 +216,7 @@ def sample_compact(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_sa
     slots = torch.empty(n, device=rays_o.device, dtype=torch.int32)
     pts = torch.empty(max(n, 1), 3, device=rays_o.device)
     dirs = torch.empty(max(n, 1), 3, device=rays_o.device)
-    count = torch.zeros(1, device=rays_o.device, dtype=torch.int32)
+    count = torch.empty(1, device=rays_o.device, dtype=torch.int32)          # the call clears it
     _compact_launch(lib, rays_o, rays_d, u, None, 0, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, count)
     n_act = int(count.item())
     return z, slots, pts[:n_act], dirs[:n_act]
@@ -237,8 +255,7 @@ def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float
     z = torch.empty(R, n_samples, device=dev)
     slots = torch.empty(n, device=dev, dtype=torch.int32)
     pts, dirs = torch.empty(max(n, 1), 3, device=dev), torch.empty(max(n, 1), 3, device=dev)
-    count = torch.empty(1, device=dev, dtype=torch.int32)          # zeroed by the library call itself
-    _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, count)
+    count = _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, None)
     count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     count_host.copy_(count, non_blocking=True)
     event = torch.cuda.Event()
@@ -735,10 +752,13 @@ def hash_encode_bwd(pts: Tensor, levels: HashLevelTable, bound: float, d_feat: T
                    "nerf_hash_encode_bwd_ws")
 
 
-def hash_encode_bwd_tables(pts: Tensor, levels: HashLevelTable, bound: float, d_feats, d_tables, workspace_of) -> bool:
+def hash_encode_bwd_tables(pts: Tensor, levels: HashLevelTable, bound: float, d_feats, d_tables, workspace_of,
+                           spec_status: Optional[Tensor] = None, spec_lm: bool = False) -> bool:
     """The overwrite-form scatter of several tables of ONE level structure from the same points in one pass of launches, when
     the tables' gradients and their feature gradients are equally spaced in memory (views of flat buffers).  ``workspace_of(n,
-    n_levels, n_tables)`` returns the uint8 workspace.  False: not the case, nothing was launched."""
+    n_levels, n_tables)`` returns the uint8 workspace.  False: not the case, nothing was launched.  ``spec_status`` (a host-mapped
+    int32 [8] block): the speculative form (nerf_hash_encode_bwd_ws_store_tables_spec; project-nerf_amd/specbwd.py); ``spec_lm``: the
+    producer wrote the level-major gradients into the workspace (d_feats only give the layout check its strides)."""
     k = len(d_tables)
     if k < 2 or any(t.dtype != torch.float32 or not t.is_contiguous() for t in list(d_tables) + list(d_feats)):
         return False
@@ -755,10 +775,25 @@ def hash_encode_bwd_tables(pts: Tensor, levels: HashLevelTable, bound: float, d_
     pts = _dev(pts, "pts")
     n = pts.shape[0]
     ws = workspace_of(n, levels.n_levels, k)
+    if spec_status is not None:
+        _lib.check(lib.nerf_hash_encode_bwd_ws_store_tables_spec(_p(pts), n, k, t_step // 8, levels.n_levels, *levels.host_args(), float(bound),
+                                                                 None if spec_lm else _p(d_feats[0]), f_step // 4, _p(d_tables[0]), _p(ws), ws.numel(),
+                                                                 spec_status.data_ptr(), _stream()), "nerf_hash_encode_bwd_ws_store_tables_spec")
+        return True
     _lib.check(lib.nerf_hash_encode_bwd_ws_store_tables(_p(pts), n, k, t_step // 8, levels.n_levels, *levels.host_args(), float(bound),
                                                         _p(d_feats[0]), f_step // 4, _p(d_tables[0]), _p(ws), ws.numel(), _stream()),
                "nerf_hash_encode_bwd_ws_store_tables")
     return True
+
+
+def hash_bwd_slots(workspace: Tensor, n: int, n_levels: int) -> Tuple[int, int]:
+    """device addresses of the hash backward workspace's slots a producer fills for the forms that do not count: (the
+    NERF_AMAX_WORDS words for the largest |d feature|, the level-major gradients float2 [n_levels][n])"""
+    import ctypes
+    amax_p, lm_p = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(_lib.load().nerf_hash_encode_bwd_ws_slots(workspace.data_ptr(), n, n_levels, ctypes.byref(amax_p), ctypes.byref(lm_p)),
+               "nerf_hash_encode_bwd_ws_slots")
+    return amax_p.value, lm_p.value
 
 
 IMLP_PARAM_COUNT = 11264
@@ -831,13 +866,31 @@ class _HashEncode(torch.autograd.Function):
         return g, d_pts, None, None
 
 
-def hash_encode_bwd_input(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: float, d_feat: Tensor) -> Tensor:
+def hash_encode_bwd_input(pts: Tensor, table: Tensor, levels: HashLevelTable, bound: float, d_feat: Optional[Tensor],
+                          add_to: Optional[Tensor] = None, grad_lm: Optional[int] = None) -> Tensor:
     """d_pts [n,3]: gradient of the features w.r.t. the encoded positions (dynamic fields); ``table`` fp32 [E,2] or the fp16
-    copy the forward evaluated."""
+    copy the forward evaluated.  ``add_to`` (fp16 table): a contiguous fp32 [n,3] tensor the gradient is ADDED to in place (and
+    which is returned) -- a gradient reaching the positions by another path is already there.  ``grad_lm`` (fp16 table; instead of
+    ``d_feat``): device address of the level-major gradients float2 [L][n] a producer left in the hash backward's workspace."""
     lib = _lib.load()
     if not isinstance(table, Tensor) or table.dtype not in (torch.float32, torch.float16):
         raise TypeError("hash_encode_bwd_input: table must be an fp32 or fp16 tensor")
-    pts, table, d_feat = _dev(pts, "pts"), _dev(table, "table", table.dtype), _dev(d_feat, "d_feat")
+    pts, table = _dev(pts, "pts"), _dev(table, "table", table.dtype)
+    if grad_lm is not None:
+        if table.dtype != torch.float16 or (add_to is not None and (add_to.shape != pts.shape or _dev(add_to, "add_to") is not add_to)):
+            raise ValueError("hash_encode_bwd_input(grad_lm=...): fp16 table; add_to a contiguous fp32 tensor of the points' shape")
+        out = add_to if add_to is not None else torch.empty_like(pts)
+        _lib.check(lib.nerf_hash_encode_bwd_input_lm_f16(_p(pts), pts.shape[0], _p(table), levels.n_levels, *levels.host_args(), float(bound),
+                                                         grad_lm, _p(out), 1 if add_to is not None else 0, _stream()),
+                   "nerf_hash_encode_bwd_input_lm_f16")
+        return out
+    d_feat = _dev(d_feat, "d_feat")
+    if add_to is not None:
+        if table.dtype != torch.float16 or add_to.shape != pts.shape or _dev(add_to, "add_to") is not add_to:
+            raise ValueError("hash_encode_bwd_input(add_to=...): fp16 table and a contiguous fp32 tensor of the points' shape")
+        _lib.check(lib.nerf_hash_encode_bwd_input_f16_accum(_p(pts), pts.shape[0], _p(table), levels.n_levels, *levels.host_args(), float(bound),
+                                                            _p(d_feat), _p(add_to), _stream()), "nerf_hash_encode_bwd_input_f16_accum")
+        return add_to
     d_pts = torch.empty_like(pts)
     fn = lib.nerf_hash_encode_bwd_input_f16 if table.dtype == torch.float16 else lib.nerf_hash_encode_bwd_input
     _lib.check(fn(_p(pts), pts.shape[0], _p(table), levels.n_levels, *levels.host_args(), float(bound), _p(d_feat), _p(d_pts), _stream()),
@@ -916,6 +969,9 @@ def adam_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor
                "nerf_adam_step")
 
 
+SMALL_GROUP = 65536        # nerf_clip_adamw_small's limit
+
+
 def tv_clip_adamw_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
                        tv_weight: float = 0.0, max_norm: float = 0.0, weight_decay: float = 0.0,
                        beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0,
@@ -941,8 +997,13 @@ def tv_clip_adamw_step(params: Tensor, grads: Tensor, exp_avg: Tensor, exp_avg_s
             tv_codes = torch.empty((n + 3) // 4, dtype=torch.uint8, device=params.device)
     else:
         tv_codes = None
-    normsq[:2].zero_()
-    _lib.check(lib.nerf_tv_normsq_codes(_p(params), _p(grads), n, 1, tv_weight, grad_scale, _p(normsq), _p(tv_codes), _stream()),
+    if tv_codes is None and shadow_f16 is None and n <= SMALL_GROUP:
+        # a tiny MLP's weights: norm + clip + AdamW in one launch of one workgroup (normsq[0] receives the squared norm)
+        _lib.check(lib.nerf_clip_adamw_small(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, step, lr, beta1, beta2, eps, weight_decay,
+                                             max_norm, grad_scale, _p(normsq), 0, _stream()), "nerf_clip_adamw_small")
+        return
+    # the call STORES the squared norm (accumulate 0): no zeroing launch
+    _lib.check(lib.nerf_tv_normsq_codes(_p(params), _p(grads), n, 1, tv_weight, grad_scale, _p(normsq), 0, _p(tv_codes), _stream()),
                "nerf_tv_normsq_codes")
     _lib.check(lib.nerf_adamw_clip_step_tv(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, step, lr, beta1, beta2, eps, weight_decay,
                                            _p(normsq), max_norm, grad_scale, _p(tv_codes), n, tv_weight, n, 0.0, 0, 0, 0.0, _p(shadow_f16),

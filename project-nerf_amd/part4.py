@@ -13,6 +13,7 @@ Two entry points over the same kernels:
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -129,40 +130,82 @@ def forward_chain(packed, params, tables, levels_d, levels_c, bound, pts, x_def,
 
 
 def backward_chain(packed, params, table_c, levels_d, levels_c, bound, x_in, xc, ws: Workspace, rgb, sigma, d_rgb, d_sigma,
-                   d_dx_extra, g_net, g_tables, hash_ws=None, after_canonical=None, after_grid=None, overwrite=False, tables_ws=None):
+                   d_dx_extra, g_net, g_tables, hash_ws=None, after_canonical=None, after_grid=None, overwrite=False, tables_ws=None,
+                   extra_in_place=False, spec=None):
     """Adds the gradients of one batch into ``g_net`` [30145] and ``g_tables`` (4 tensors [E*2]); ``overwrite`` (needs
     ``hash_ws``): the table gradients are STORED instead (no zeroing by the caller, no read-back -- the engine's data batch);
     ``tables_ws(n, n_levels, n_tables)``: workspace for scattering to the three deformation grids in one pass.  ``d_dx_extra`` [n,3] or
     None: gradient reaching delta_x directly (displacement regulariser, a caller's loss on delta_x); rgb None: the
-    deformation chain alone (regulariser probes).  ``after_*`` callbacks: data-parallel hooks (ranges that are final)."""
+    deformation chain alone (regulariser probes).  ``after_*`` callbacks: data-parallel hooks (ranges that are final).
+    ``extra_in_place`` (fp16 canonical table): d_dx_extra is the caller's scratch -- the gradient through x_canonical is added INTO it
+    (no zeroing launch, no separate add).  ``spec`` = (SpeculativeScatter of the canonical grid's workspace, of the deformation grids',
+    occupancy-grid identity): the engine's steady state -- both scatters skip their count passes when the estimates hold."""
     lib = _lib.load()
     n = x_in.shape[0]
     d_dx = d_dx_extra
+    # the engine's steady state: the scatters skip their count passes (specbwd.py) -- capacities from the last call's true counts
+    spec_c = spec_d = None
+    use_c = use_d = False
+    hws_c = hws_d = None
+    if spec is not None and overwrite and tables_ws is not None and hash_ws is not None and rgb is not None:
+        spec_c, spec_d, grid_id = spec
+        hws_c, hws_d = hash_ws(n, levels_c.n_levels), tables_ws(n, levels_d.n_levels, 3)
+        use_c = table_c.dtype == torch.float16 and spec_c.ok(hws_c.data_ptr(), grid_id, n)
+        use_d = spec_d.ok(hws_d.data_ptr(), grid_id, n)
     if rgb is not None:
-        _lib.check(lib.nerf_p4_canon_bwd(P(packed), P(ws.buf), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(g_net), ops._stream()),
+        amax_c = lm_c = None
+        if use_c:                                # the chain hands its d features over level-major, inside the scatter's workspace
+            spec_c.begin(hws_c)
+            amax_c, lm_c = ops.hash_bwd_slots(hws_c, n, levels_c.n_levels)
+        _lib.check(lib.nerf_p4_canon_bwd(P(packed), P(ws.buf), P(rgb), P(sigma), P(d_rgb), P(d_sigma), n, P(g_net), amax_c, lm_c, ops._stream()),
                    "nerf_p4_canon_bwd")
         d_feat_c = ws.d_feat(3)
-        d_xc = ops.hash_encode_bwd_input(xc, table_c.view(-1, 2), levels_c, bound, d_feat_c)
-        ops.hash_encode_bwd(xc, levels_c, bound, d_feat_c, g_tables[3], workspace=hash_ws(n, levels_c.n_levels) if hash_ws else None,
-                            overwrite=overwrite)
+        in_place = extra_in_place and d_dx_extra is not None and table_c.dtype == torch.float16 and d_dx_extra.is_contiguous()
+        d_xc = ops.hash_encode_bwd_input(xc, table_c.view(-1, 2), levels_c, bound, None if use_c else d_feat_c,
+                                         add_to=d_dx_extra if in_place else None, grad_lm=lm_c)
+        if use_c:
+            status = spec_c.status_block()
+            _lib.check(lib.nerf_hash_encode_bwd_ws_store_spec(P(xc), n, levels_c.n_levels, *levels_c.host_args(), float(bound), None,
+                                                              P(g_tables[3]), P(hws_c), hws_c.numel(), status.data_ptr(), ops._stream()),
+                       "nerf_hash_encode_bwd_ws_store_spec")
+            spec_c.issued(hws_c, grid_id, n, status)
+        else:
+            ops.hash_encode_bwd(xc, levels_c, bound, d_feat_c, g_tables[3], workspace=hash_ws(n, levels_c.n_levels) if hash_ws else None,
+                                overwrite=overwrite)
+            if spec_c is not None:
+                spec_c.counted(hws_c, grid_id, n)
         if after_grid is not None:
             after_grid(3)
-        d_dx = d_xc if d_dx_extra is None else d_xc.add_(d_dx_extra)
-    _lib.check(lib.nerf_p4_deform_bwd(P(packed), P(params), P(ws.buf), P(d_dx.contiguous()), n, P(g_net), ops._stream()), "nerf_p4_deform_bwd")
+        d_dx = d_xc if (d_dx_extra is None or in_place) else d_xc.add_(d_dx_extra)
+    amax_d = lm_d = None
+    if use_d:
+        spec_d.begin(hws_d)
+        amax_d, lm_d = ops.hash_bwd_slots(hws_d, n, 3 * levels_d.n_levels)
+    _lib.check(lib.nerf_p4_deform_bwd(P(packed), P(params), P(ws.buf), P(d_dx.contiguous()), n, P(g_net), amax_d, lm_d, ops._stream()),
+               "nerf_p4_deform_bwd")
     if after_canonical is not None:
         after_canonical()
     # the engine's overwrite form: the three deformation grids (views of one flat gradient buffer) in one pass of launches
+    status = spec_d.status_block() if use_d else None
     if overwrite and tables_ws is not None and ops.hash_encode_bwd_tables(x_in, levels_d, bound, [ws.d_feat(k) for k in range(3)], g_tables[:3],
-                                                                          tables_ws):
+                                                                          tables_ws, spec_status=status, spec_lm=use_d):
+        if use_d:
+            spec_d.issued(hws_d, grid_id, n, status)
+        elif spec_d is not None:
+            spec_d.counted(hws_d, grid_id, n)
         if after_grid is not None:
             for k in range(3):
                 after_grid(k)
         return
+    if use_d:         # (cannot happen: the estimates come from a call that took the one-pass form on the same buffers)
+        raise RuntimeError("Part 4 backward: the deformation grids' gradients were handed over level-major but their one-pass scatter is unavailable")
     for k in range(3):
         ops.hash_encode_bwd(x_in, levels_d, bound, ws.d_feat(k), g_tables[k], workspace=hash_ws(n, levels_d.n_levels) if hash_ws else None,
                             overwrite=overwrite)
         if after_grid is not None:
             after_grid(k)
+    if spec_c is not None:                       # the per-grid calls went through the canonical grid's workspace
+        spec_c.invalidate()
 
 
 # --------------------------------------------------------------------------------------------------- module path
@@ -280,12 +323,17 @@ class DualHashEngine:
         self.binary_grid = torch.ones(res, res, res, dtype=torch.bool, device=self.device)
         self.step_count = 0
         self._scalars = self._g_net_scalars[N_PARAMS:]
+        self._loss_ring, self._grad_calls = torch.zeros(32768, 2, device=self.device), -1
         self._normsq_ws = ops.normsq_ws(self.device)
         assert (3 * nd) % 4 == 0
         self._tv_codes = torch.empty((total + 3) // 4, dtype=torch.uint8, device=self.device)   # two-bit signs of the TV terms
         self._ws: Dict[str, Tensor] = {}
         self._hash_ws = None
         self._hash_ws_tables = None
+        self._hash_ws_probes = None
+        from .specbwd import SpeculativeScatter
+        on = bool(cfg.get("speculative_hash_backward", True)) and not os.environ.get("NERF_NO_SPECULATIVE_BWD")      # env: A/B aid
+        self.spec_c, self.spec_d = SpeculativeScatter(on), SpeculativeScatter(on)
         self._counter = 0
         self.repack()
 
@@ -340,6 +388,14 @@ class DualHashEngine:
             self._hash_ws_tables = torch.empty(int(need * 1.25), dtype=torch.uint8, device=self.device)
         return self._hash_ws_tables
 
+    def _hash_scratch_probes(self, n: int, n_levels: int) -> Tensor:
+        """the probes' (accumulating, counted) scatters: their own workspace -- the data batch's keep their bin estimates"""
+        need = ops.hash_encode_bwd_workspace_bytes(n, n_levels)
+        if self._hash_ws_probes is None or self._hash_ws_probes.numel() < need:
+            self._hash_ws_probes = None
+            self._hash_ws_probes = torch.empty(int(need * 1.25), dtype=torch.uint8, device=self.device)
+        return self._hash_ws_probes
+
     def _hash_scratch(self, n: int, n_levels: int) -> Tensor:
         need = ops.hash_encode_bwd_workspace_bytes(n, n_levels)
         if self._hash_ws is None or self._hash_ws.numel() < need:
@@ -368,7 +424,15 @@ class DualHashEngine:
         n = pts.shape[0]
         bg = self.bg if bg is None else bg
         self._g_net_scalars.zero_()
-        loss, reg = self._scalars[0:1], self._scalars[1:2]
+        # a fresh zeroed (loss, regulariser) slot per step out of a ring cleared half a lap ahead: the returned loss is a VIEW of its
+        # slot (valid for the next 16384 steps) -- no copy launch per step
+        self._grad_calls += 1
+        ring = self._loss_ring.shape[0]
+        slot = self._grad_calls % ring
+        if slot % (ring // 2) == 0 and self._grad_calls > 0:
+            self._loss_ring[slot:slot + ring // 2].zero_()
+        loss, reg = self._loss_ring[slot, 0:1], self._loss_ring[slot, 1:2]
+        self.last_reg = reg[0]                 # displacement regulariser of this batch (before its weight), a view like the loss
         handles = []
         reduce = (lambda view: handles.append(sync_grads_async(view))) if sync_grads_async is not None else (lambda view: None)
         if n == 0:
@@ -387,7 +451,8 @@ class DualHashEngine:
                        "nerf_composite_mse_reg_bwd")
             g_tabs = [self.g_table(k) for k in range(4)]
             backward_chain(self.packed, self.net, self.table(3, half=True), self.levels_d, self.levels_c, self.bound, pts if x_def is None else x_def,
-                           xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch, overwrite=True, tables_ws=self._hash_scratch_tables,
+                           xc, ws, rgb, sigma, d_rgb, d_sigma, d_extra, self.g_net, g_tabs, hash_ws=self._hash_scratch, overwrite=True, tables_ws=self._hash_scratch_tables, extra_in_place=True,
+                           spec=(self.spec_c, self.spec_d, (self.binary_grid.data_ptr(), self.binary_grid._version)),
                            after_grid=(lambda k: reduce(g_tabs[k])) if (sync_grads_async is not None and probes is None and not shard_grads) else None)
         if probes is not None:
             self._probe_regularisers(probes)
@@ -406,7 +471,7 @@ class DualHashEngine:
             for h in handles:
                 if h is not None:
                     h.wait()
-        return loss[0].clone()
+        return loss[0]
 
     def _probe_regularisers(self, probes) -> None:
         """Temporal smoothness, unsupervised consistency and tri-grid anchor terms of the reference's loop (run.py:1861-1938)
@@ -459,7 +524,7 @@ class DualHashEngine:
             g[sl("a_start")] += 2 * w * 0.1 * (a1 - a2) / a1.numel()
             g[sl("a_mid")] -= 2 * w * 0.1 * (a1 - a2) / a1.numel()
         backward_chain(self.packed, self.net, self.table(3), self.levels_d, self.levels_c, self.bound, X, None, ws, None, None, None, None,
-                       g, self.g_net, [self.g_table(k) for k in range(4)], hash_ws=self._hash_scratch)
+                       g, self.g_net, [self.g_table(k) for k in range(4)], hash_ws=self._hash_scratch_probes)
 
     def enable_sharded_optimizer(self, rank: int) -> None:
         """Data parallelism as SURVEY 8(e) specifies for the big tables (project-nerf_amd/sharded.py): the table gradient is
@@ -483,10 +548,10 @@ class DualHashEngine:
         lib, st, sh = _lib.load(), ops._stream(), self.shard
         scale = 1.0 / self.world_size
         normsq = self._normsq_ws
-        normsq[:2].zero_()
-        sh.accumulate_normsq(normsq, scale)
+        sh.accumulate_normsq(normsq, scale, first=True)         # the first piece stores the norm: no zeroing launch
         if sh.rank == 0:
-            _lib.check(lib.nerf_tv_normsq_codes(P(self.net), P(self.g_net), N_PARAMS, 1, 0.0, scale, P(normsq), None, st), "nerf_tv_normsq_codes")
+            _lib.check(lib.nerf_tv_normsq_codes(P(self.net), P(self.g_net), N_PARAMS, 1, 0.0, scale, P(normsq), 1 if sh.pieces else 0, None, st),
+                       "nerf_tv_normsq_codes")
         if self.world_size > 1:
             dist.all_reduce(normsq[0:1], op=dist.ReduceOp.SUM)      # every rank: the same bits, hence the same clip coefficient
         lr_t, lr_n, lr_s = self.lr(2.0), self.lr(1.0), self.lr(5.0)
@@ -510,17 +575,16 @@ class DualHashEngine:
         st = ops._stream()
         scale = 1.0 / self.world_size
         normsq = self._normsq_ws                 # [0] the squared norm of ALL groups, [1] ticket, [2:] partials (include/nerf_hip.h)
-        normsq[:2].zero_()
         # pass 1 (three launches): ONE squared norm over all groups; the TV terms' signs go to a two-bit code per table entry instead
         # of into the gradient (38.5 instead of 42 bytes per parameter).  The three deformation grids (equal sizes, back to back in
         # the flat buffer) in one launch, each with its own total variation
         n_def, n_can, total = self.table_sizes[0], self.table_sizes[3], self.tables.numel()
         codes = self._tv_codes
-        _lib.check(lib.nerf_tv_normsq_codes(P(self.table(0)), P(self.g_table(0)), 3 * n_def, 3, self.tv_disp, scale, P(normsq), P(codes), st),
-                   "nerf_tv_normsq_codes")
-        _lib.check(lib.nerf_tv_normsq_codes(P(self.table(3)), P(self.g_table(3)), n_can, 1, self.tv_canon, scale, P(normsq),
+        _lib.check(lib.nerf_tv_normsq_codes(P(self.table(0)), P(self.g_table(0)), 3 * n_def, 3, self.tv_disp, scale, P(normsq), 0, P(codes), st),
+                   "nerf_tv_normsq_codes")          # the first group STORES the norm (no zeroing launch), the others add
+        _lib.check(lib.nerf_tv_normsq_codes(P(self.table(3)), P(self.g_table(3)), n_can, 1, self.tv_canon, scale, P(normsq), 1,
                                             P(codes[3 * n_def // 4:]), st), "nerf_tv_normsq_codes")
-        _lib.check(lib.nerf_tv_normsq_codes(P(self.net), P(self.g_net), N_PARAMS, 1, 0.0, scale, P(normsq), None, st), "nerf_tv_normsq_codes")
+        _lib.check(lib.nerf_tv_normsq_codes(P(self.net), P(self.g_net), N_PARAMS, 1, 0.0, scale, P(normsq), 1, None, st), "nerf_tv_normsq_codes")
         lr_t, lr_n, lr_s = self.lr(2.0), self.lr(1.0), self.lr(5.0)      # the rates of THIS step: scheduler.step() follows optimizer.step()
         self.step_count += 1
         step = self.step_count

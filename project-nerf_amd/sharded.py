@@ -69,12 +69,16 @@ class ShardedTableOptimizer:
         """grads[lo:hi] <- sum over ranks of grads[lo:hi] (the other slices are left as they are: never read afterwards)"""
         reduce_scatter_sum_(self.grads, self.per, self.rank, self.world)
 
-    def accumulate_normsq(self, normsq_ws: Tensor, grad_scale: float) -> None:
-        """adds this rank's part of the squared norm of (grads * grad_scale + TV terms) to normsq_ws[0]; leaves the TV sign codes"""
+    def accumulate_normsq(self, normsq_ws: Tensor, grad_scale: float, first: bool = False) -> None:
+        """adds this rank's part of the squared norm of (grads * grad_scale + TV terms) to normsq_ws[0] (``first``: the first piece
+        STORES it, a rank without pieces stores zero -- no zeroing launch); leaves the TV sign codes"""
         lib, st = _lib.load(), ops._stream()
-        for a, cnt, table_elems, tv_w, halo in self.pieces:
+        if first and not self.pieces:
+            normsq_ws[:1].zero_()
+        for i, (a, cnt, table_elems, tv_w, halo) in enumerate(self.pieces):
             _lib.check(lib.nerf_tv_normsq_codes_piece(P(self.params[a:]), P(self.grads[a:]), cnt, table_elems, halo, tv_w, grad_scale,
-                                                      P(normsq_ws), P(self.codes[16 + (a - self.lo) // 4:]), st), "nerf_tv_normsq_codes_piece")
+                                                      P(normsq_ws), 0 if (first and i == 0) else 1, P(self.codes[16 + (a - self.lo) // 4:]), st),
+                       "nerf_tv_normsq_codes_piece")
 
     def adamw(self, normsq_ws: Tensor, step: int, lr: float, weight_decay: float, max_norm: float, grad_scale: float,
               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:

@@ -683,22 +683,30 @@ def test_hash_backward_tables_form_equals_one_pass_per_table(ops, n=9000):
     assert torch.equal(img, one)
 
 
-def _spec_call(ops, lib, pts, levels, d_feat, g_table, ws, row_major=True):
-    """nerf_hash_encode_bwd_spec_begin -> the producer's outputs (largest |gradient| bits, level-major gradients) written into the
-    workspace's slots the way nerf_imlp_bwd_lm does -> nerf_hash_encode_bwd_ws_store_spec; returns the status words"""
+def _spec_call(ops, lib, pts, levels, d_feat, g_table, ws, row_major=True, begin=True):
+    """[nerf_hash_encode_bwd_spec_begin: after a counted call] -> the producer's outputs (largest |gradient| bits, level-major
+    gradients) written into the workspace's slots the way nerf_imlp_bwd_lm does -> nerf_hash_encode_bwd_ws_store_spec; returns the
+    status words the call's last launch published (device block and host-mapped block: the same)"""
     import ctypes
     n, L = pts.shape[0], levels.n_levels
     st = torch.cuda.current_stream().cuda_stream
-    ops._lib.check(lib.nerf_hash_encode_bwd_spec_begin(ws.data_ptr(), st), "spec_begin")
+    if begin:
+        ops._lib.check(lib.nerf_hash_encode_bwd_spec_begin(ws.data_ptr(), st), "spec_begin")
+    else:
+        assert ws[:32].view(torch.int32).cpu().tolist() == [0] * 8, "a speculative call must leave the header clean"
     amax_p, lm_p = ctypes.c_void_p(), ctypes.c_void_p()
     ops._lib.check(lib.nerf_hash_encode_bwd_ws_slots(ws.data_ptr(), n, L, ctypes.byref(amax_p), ctypes.byref(lm_p)), "slots")
     a_off, l_off = amax_p.value - ws.data_ptr(), lm_p.value - ws.data_ptr()
     ws[a_off:a_off + 4].view(torch.float32).copy_(d_feat.abs().max().reshape(1))            # fp32 bits of the largest |gradient|
     ws[l_off:l_off + n * L * 8].view(torch.float32).view(L, n, 2).copy_(d_feat.view(n, L, 2).permute(1, 0, 2))
     # level-major gradients in the workspace (d_feat NULL) or row-major ones handed over: both forms
+    host = torch.full((8,), -1, dtype=torch.int32).pin_memory()
     ops._lib.check(lib.nerf_hash_encode_bwd_ws_store_spec(pts.data_ptr(), n, L, *levels.host_args(), 1.5, d_feat.data_ptr() if row_major else None,
-                                                          g_table.data_ptr(), ws.data_ptr(), ws.numel(), st), "store_spec")
-    return ws[:32].view(torch.int32).cpu().tolist()
+                                                          g_table.data_ptr(), ws.data_ptr(), ws.numel(), host.data_ptr(), st), "store_spec")
+    off = lib.nerf_hash_encode_bwd_spec_status(ws.data_ptr()) - ws.data_ptr()
+    status = ws[off:off + 32].view(torch.int32).cpu().tolist()        # (synchronises)
+    assert host.tolist() == status, (host.tolist(), status)
+    return status
 
 
 @pytest.mark.gpu
@@ -740,7 +748,7 @@ def test_hash_backward_speculative_form(ops):
     assert status[4] == 0 and bool(torch.isfinite(out2).all())
     assert float((out2 - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max())
     # ... and that call left ITS counts: the same batch again overflows nothing (level-major gradients this time)
-    status = _spec_call(ops, lib, pts2, t, d_feat2, out2, ws, row_major=False)
+    status = _spec_call(ops, lib, pts2, t, d_feat2, out2, ws, row_major=False, begin=False)
     assert status[3] == 0 and status[4] == 0 and float((out2 - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max())
     # estimates from a much smaller batch: heavy overflow
     pts3, d_feat3 = batch(8000, 3)
@@ -782,18 +790,17 @@ def test_instant_engine_speculative_backward_equals_counted_backward():
         eng.net[2048:2048 + 64] *= 20.0
         ops_mod.imlp_pack(eng.net, eng.packed)
         eng.binary_grid = grid
-        rec, used = [], 0
+        rec = []
         for step in range(4):
             u = torch.rand(R, S, generator=torch.Generator().manual_seed(100 + step)).cuda()
             eng.g_table.fill_(float("nan"))
             loss = float(eng.compute_gradients(o, d, target, S, u=u))
-            used += eng._spec_pending is not None and spec
             rec.append((loss, eng.g_net.clone(), eng.g_table.clone()))
         runs.append(rec)
         if spec:
-            assert eng._spec_from is not None and used >= 2, used                 # steps 2.. took the speculative form
+            assert eng.spec.calls >= 3, eng.spec.calls                            # steps 2.. took the speculative form
             torch.cuda.synchronize()
-            assert int(eng._spec_pending[0][4]) == 0
+            assert int(eng.spec.last_status[7]) == 1 and int(eng.spec.last_status[4]) == 0
     for (l1, n1, t1), (l0, n0, t0) in zip(*runs):
         assert abs(l1 - l0) < 1e-6 * max(l0, 1.0) and bool(torch.isfinite(t1).all())
         assert float((n1 - n0).abs().max()) <= 1e-5 * float(n0.abs().max())
