@@ -528,6 +528,9 @@ def test_engine_speculative_scatters_equal_counted_scatters(smooth_pair):
     worst = spread(runs[0], runs[1])
     print("[part4 speculative scatters] largest |speculative - counted| / max |counted| per grid (start, mid, end, canonical): "
           + ", ".join(f"{w:.2e}" for w in worst) + "; counted against counted: " + ", ".join(f"{w:.2e}" for w in own))
-    # (both columns are samples of the same noise: measured 6e-5 / 4e-5 / 8e-8 / 9e-8 against 6e-5 / 1e-5 / 2e-7 / 9e-8 -- on this small
-    # configuration the deformation grids' entries are sums with heavy cancellation, and the cut bins' float atomics show)
-    assert all(w <= max(10.0 * o, 2e-6) for w, o in zip(worst, own)), (worst, own)
+    # Both columns are samples of the same noise: a bin that was cut into several work items (the coarse dense levels) is flushed with
+    # float atomics in either form, and on this small configuration the deformation grids' entries are sums with heavy cancellation --
+    # an entry then takes one of a few roundings depending on the order (the SAME 6.38e-05 / 1.23e-05 appear between two counted runs
+    # in one launch of this test and between the speculative and a counted run in another).  Bounds: 3x that for the deformation
+    # grids; the canonical grid (no such cancellation) to 2e-6.
+    assert max(worst[:3]) <= 2e-4 and worst[3] <= 2e-6, (worst, own)
