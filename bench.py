@@ -299,10 +299,17 @@ def bench_part4(args, device, steps=200):
     eng.load_from_model(model)
     eng.binary_grid = torch.rand_like(eng.grid) < 0.12
     step_no = [300]
+    ahead = []
 
     def step():
+        # the product loop's order (project-nerf_amd/dynamic.py::run_dynamic): the NEXT batch's compaction is queued ahead of this step's
+        # kernels, so the read-back of its active count never stalls the host (the reference waits at that point of every step)
         step_no[0] += 1
-        return eng.train_step(o, d, target, t, S, probes=part4_probe_draws(cfg, step_no[0], device))
+        if not ahead:
+            ahead.append(eng.prepare_batch(o, d, S))
+        prepared = ahead.pop()
+        ahead.append(eng.prepare_batch(o, d, S))
+        return eng.train_step(o, d, target, t, S, prepared=prepared, probes=part4_probe_draws(cfg, step_no[0], device))
     for _ in range(20):
         step()
     torch.cuda.synchronize()

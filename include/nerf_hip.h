@@ -560,15 +560,16 @@ int nerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp
  *                         no TV term; grad_scale = 1/world after a summing all-reduce: it scales the data
  *                         gradient only, the regulariser is a function of the replicated parameters),
  *                         then normsq_dev[0] = sum(grads^2).  normsq_dev: NERF_NORMSQ_WS_FLOATS device floats -- [0] the
- *                         squared norm, [1] a ticket, [2..] one partial per workgroup: the partials are added in workgroup
+ *                         squared norm, [1..34) tickets (zero before the first call ever; every call leaves them zero), then one
+ *                         partial per workgroup: the partials are added in workgroup
  *                         order by the last workgroup to finish, so every run and every data-parallel replica (identical
  *                         gradients after the all-reduce) gets the same bits, hence the same clip coefficient
  *   nerf_adamw_clip_step: AdamW with grads scaled by grad_scale * min(1, max_norm / (norm + 1e-6)),
  *                         norm = grad_scale * sqrt(normsq_dev[0]); normsq_dev NULL or max_norm <= 0: no clip. */
-#define NERF_NORMSQ_WS_FLOATS 4104
+#define NERF_NORMSQ_WS_FLOATS 4136
 int nerf_tv_normsq(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
                    float* normsq_dev, nerf_stream_t stream);
-/* the same pass WITHOUT zeroing normsq_dev[0..1] first: several parameter groups accumulate ONE global squared norm
+/* the same pass WITHOUT zeroing normsq_dev[0] first: several parameter groups accumulate ONE global squared norm
  * (torch.nn.utils.clip_grad_norm_(model.parameters()) of the Part 3 / 4 loops, run.py:1172, 1943) in call order; the caller
  * zeroes normsq_dev[0] and [1] once per step and hands the workspace to every group's nerf_adamw_clip_step */
 int nerf_tv_normsq_accum(const float* params, float* grads, int64_t n, float tv_weight, float grad_scale,
@@ -588,7 +589,7 @@ int nerf_adamw_clip_step_shadow(float* params, const float* grads, float* exp_av
 /* The same two passes WITHOUT rewriting the gradient (38.5 instead of 42 bytes per parameter; what the engines call):
  *   nerf_tv_normsq_codes   : normsq_dev[0] (accumulate != 0: +)= sum (grads * grad_scale + TV term)^2 over n_tables equally long tables
  *                            stored back to back -- the first call of a step STORES (accumulate 0: no zeroing launch), the
- *                            groups that share the norm add (accumulate 1); normsq_dev[1] (the ordered sum's ticket) is zero before
+ *                            groups that share the norm add (accumulate 1); normsq_dev[1..34) (the ordered sum's tickets) are zero before
  *                            the first call ever and left zero by every call; grads is NOT modified; tv_codes
  *                            (nerf_tv_codes_bytes(n) bytes; may be NULL when tv_weight == 0) receives the two-bit signs
  *                            1 + sign(p[i+1] - p[i]) the TV term is made of (0 across a table seam)

@@ -161,7 +161,7 @@ def load():
     return lib
 
 
-NORMSQ_WS_FLOATS = 4104     # NERF_NORMSQ_WS_FLOATS
+NORMSQ_WS_FLOATS = 4136     # NERF_NORMSQ_WS_FLOATS
 SUM_WS_FLOATS = 12288       # NERF_SUM_WS_FLOATS
 
 

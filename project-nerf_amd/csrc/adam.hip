@@ -416,15 +416,15 @@ static int tv_normsq_impl(const float* params, float* grads, int64_t n, float tv
   NERF_REQUIRE(n >= 0 && normsq_dev && n_tables >= 1 && n_tables <= 4 && n % n_tables == 0, "nerf_tv_normsq: bad arguments");
   const int64_t seg = n / n_tables;
   NERF_REQUIRE(n_tables == 1 || seg % 4 == 0, "nerf_tv_normsq_accum_tables: %lld elements per table (a multiple of 4)", (long long)seg);
-  // normsq_dev: NERF_NORMSQ_WS_FLOATS floats -- [0] the squared norm, [1] the ordered sum's ticket, [2..] one partial per workgroup
-  if (zero_first && hipMemsetAsync(normsq_dev, 0, 2 * sizeof(float), nerf::as_stream(stream)) != hipSuccess)
+  // normsq_dev: NERF_NORMSQ_WS_FLOATS floats -- [0] the squared norm, then the ordered sum's workspace (tickets, one partial per workgroup)
+  if (zero_first && hipMemsetAsync(normsq_dev, 0, sizeof(float), nerf::as_stream(stream)) != hipSuccess)
     return nerf::fail(NERF_ELAUNCH, "nerf_tv_normsq: memset failed");
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads, "nerf_tv_normsq: NULL pointer");
   const float tv_scale = seg > 1 ? tv_weight / (float)(seg - 1) : 0.0f;      // d/dp of mean|p[1:] - p[:-1]| * w, per table
   int64_t blocks = (n / 4 + 255) / 256 + 1;
   if (blocks > 1024) blocks = 1024;      // measured: 512 +6 %, 256 +50 %, 2048 +15 % (one same-address atomic per workgroup against HBM streams in flight)
-  static_assert(NERF_NORMSQ_WS_FLOATS >= 2 + 4096, "one partial per workgroup");
+  static_assert(NERF_NORMSQ_WS_FLOATS >= 1 + nerf::kOrderedSumTickets + 4096, "the norm, the tickets, one partial per workgroup");
   if ((((uintptr_t)params | (uintptr_t)grads) & 15) == 0)
     hipLaunchKernelGGL(nerf::tv_normsq_kernel<true>, dim3((int)blocks), dim3(256), 0, nerf::as_stream(stream), params, grads, n,
                        tv_scale, grad_scale, normsq_dev, seg);

@@ -169,30 +169,40 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---- ordered sum of V values per workgroup of a 1-D launch (instead of V same-address float atomics per workgroup) ----
 // Every workgroup publishes its values (thread 0 passes them) and takes a ticket; the workgroup that draws the last
 // ticket adds all partials IN WORKGROUP ORDER and accumulates the totals into (accumulate false: stores them to) *out[v] (null:
-// skipped) -- the same bits
-// whatever the order the workgroups finished in.  ws: 1 + V * gridDim.x words, ws[0] (the ticket) zero before the first
-// launch; the last workgroup leaves it zero again.  Every access to ws is a returning device-scope atomic (coherent
-// across the XCDs' L2s without a cache write-back); the ticket is taken only after the partials' atomics have returned.
+// skipped) -- the same bits whatever the order the workgroups finished in.  Tickets in two stages: workgroup b takes one of group
+// b % 32, the last of a group takes one of the master ticket -- 1024 workgroups that finish together queue 32 deep on 33 addresses
+// instead of 1024 deep on one (same-address atomics retire one after the other, ~20 ns each: 5 us at the tail of a 25-us launch on
+// 256 workgroups).  ws: kOrderedSumTickets ticket words (zero before the first launch; the last workgroups leave them zero again),
+// then V * gridDim.x partials.  Every access to ws is a returning device-scope atomic (coherent across the XCDs' L2s without a
+// cache write-back); a ticket is taken only after the atomics before it have returned.
 // Called by all threads of the workgroup (blockDim.x >= 64).
-constexpr int kOrderedSumMaxBlocks = 4096;
-inline size_t ordered_sum_ws_words(int n_values) { return 1 + (size_t)n_values * kOrderedSumMaxBlocks; }
+constexpr int kOrderedSumMaxBlocks = 4096, kOrderedSumGroups = 32, kOrderedSumTickets = 1 + kOrderedSumGroups;
+inline size_t ordered_sum_ws_words(int n_values) { return kOrderedSumTickets + (size_t)n_values * kOrderedSumMaxBlocks; }
 template <int V>
 __device__ __forceinline__ void ordered_block_sum(const float (&val)[V], float* const (&out)[V], unsigned* ws, bool accumulate = true) {
   __shared__ unsigned last_block;
   const unsigned B = gridDim.x;
+  unsigned* part = ws + kOrderedSumTickets;
   if (threadIdx.x == 0) {
     unsigned seen = 0;
 #pragma unroll
-    for (int v = 0; v < V; ++v) seen |= atomicExch(&ws[1 + v * B + blockIdx.x], __float_as_uint(val[v]));
+    for (int v = 0; v < V; ++v) seen |= atomicExch(&part[v * B + blockIdx.x], __float_as_uint(val[v]));
     asm volatile("" ::"v"(seen) : "memory");      // the exchanges have returned: the partials sit at their coherent home
-    last_block = atomicAdd(&ws[0], 1u) == B - 1 ? 1u : 0u;
+    const unsigned g = blockIdx.x % kOrderedSumGroups, in_group = (B - g + kOrderedSumGroups - 1) / kOrderedSumGroups;
+    unsigned last = 0u;
+    if (atomicAdd(&ws[1 + g], 1u) == in_group - 1) {                   // last of its group
+      atomicExch(&ws[1 + g], 0u);
+      const unsigned groups = B < (unsigned)kOrderedSumGroups ? B : (unsigned)kOrderedSumGroups;
+      last = atomicAdd(&ws[0], 1u) == groups - 1 ? 1u : 0u;
+    }
+    last_block = last;
   }
   __syncthreads();
   if (last_block == 0u || threadIdx.x >= 64) return;
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     float s = 0.0f;
-    for (unsigned b = threadIdx.x; b < B; b += 64) s += __uint_as_float(atomicOr(&ws[1 + v * B + b], 0u));
+    for (unsigned b = threadIdx.x; b < B; b += 64) s += __uint_as_float(atomicOr(&part[v * B + b], 0u));
     s = wave_sum(s);
     if (threadIdx.x == 0 && out[v] != nullptr) *out[v] = accumulate ? *out[v] + s : s;   // !accumulate: no zeroing launch before the call
   }

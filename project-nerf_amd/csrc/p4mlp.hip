@@ -859,7 +859,8 @@ extern "C" int nerf_p4_deform_bwd(const void* packed, const float* params_f32, v
   if (det) {
     NERF_REQUIRE(grid <= kOrderedSumMaxBlocks, "nerf_p4_deform_bwd: %d workgroups (ordered sum: at most %d)", grid, kOrderedSumMaxBlocks);
     a.sum_ws = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + l.sum_ws);
-    if (hipMemsetAsync(a.sum_ws, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess) return fail(NERF_ELAUNCH, "nerf_p4_deform_bwd: memset failed");
+    if (hipMemsetAsync(a.sum_ws, 0, sizeof(unsigned) * kOrderedSumTickets, as_stream(stream)) != hipSuccess)
+      return fail(NERF_ELAUNCH, "nerf_p4_deform_bwd: memset failed");
   }
   hipLaunchKernelGGL(p4::deform_bwd_kernel, dim3(grid), dim3(kThreads), kDeformBwdN * 1024, as_stream(stream), a);
   if (int rc = check_launch("nerf_p4_deform_bwd (dgrad)"); rc != NERF_OK) return rc;

@@ -22,7 +22,10 @@ eng = DualHashEngine(cfg, device=dev, seed=0)
 eng.load_from_model(NeuralField(cfg).to(dev))
 eng.binary_grid = torch.rand_like(eng.grid) < 0.12
 n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 48
-for step in range(301, 301 + n_steps):
-    eng.train_step(o, d, target, t, S, probes=part4_probe_draws(cfg, step, dev))
+ahead = [eng.prepare_batch(o, d, S)]
+for step in range(301, 301 + n_steps):                # the product loop's order: the next batch's compaction ahead of this step's kernels
+    prepared = ahead.pop()
+    ahead.append(eng.prepare_batch(o, d, S))
+    eng.train_step(o, d, target, t, S, prepared=prepared, probes=part4_probe_draws(cfg, step, dev))
 torch.cuda.synchronize()
 print("done", n_steps)

@@ -24,11 +24,17 @@ eng = DualHashEngine(cfg, device=dev, seed=0)
 eng.load_from_model(model)
 eng.binary_grid = torch.rand_like(eng.grid) < 0.12
 step_no = [300]
+ahead = []
 
 
 def step():
+    # the product loop's order (dynamic.py): the next batch's compaction is queued ahead of this step's kernels
     step_no[0] += 1
-    return eng.train_step(o, d, target, t, S, probes=part4_probe_draws(cfg, step_no[0], dev))
+    if not ahead:
+        ahead.append(eng.prepare_batch(o, d, S))
+    prepared = ahead.pop()
+    ahead.append(eng.prepare_batch(o, d, S))
+    return eng.train_step(o, d, target, t, S, prepared=prepared, probes=part4_probe_draws(cfg, step_no[0], dev))
 
 
 for _ in range(20):
