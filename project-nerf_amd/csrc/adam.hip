@@ -417,7 +417,7 @@ static int tv_normsq_impl(const float* params, float* grads, int64_t n, float tv
   const int64_t seg = n / n_tables;
   NERF_REQUIRE(n_tables == 1 || seg % 4 == 0, "nerf_tv_normsq_accum_tables: %lld elements per table (a multiple of 4)", (long long)seg);
   // normsq_dev: NERF_NORMSQ_WS_FLOATS floats -- [0] the squared norm, then the ordered sum's workspace (tickets, one partial per workgroup)
-  if (zero_first && hipMemsetAsync(normsq_dev, 0, sizeof(float), nerf::as_stream(stream)) != hipSuccess)
+  if (zero_first && hipMemsetAsync(normsq_dev, 0, sizeof(float) * (1 + nerf::kOrderedSumTickets), nerf::as_stream(stream)) != hipSuccess)   // the norm and the tickets
     return nerf::fail(NERF_ELAUNCH, "nerf_tv_normsq: memset failed");
   if (n == 0) return NERF_OK;
   NERF_REQUIRE(params && grads, "nerf_tv_normsq: NULL pointer");

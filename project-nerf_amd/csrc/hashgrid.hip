@@ -621,7 +621,10 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, u
   // flushed with float atomics; the coarse dense levels' bins then serialise on one workgroup each
   __shared__ unsigned scan_r[1024], scan_i[1024], wave_r[16], wave_i[16];
   __shared__ unsigned carry_r, carry_i;
+  __shared__ unsigned s_bin0[kMaxPlanLevels + 1], s_size[kMaxLevels], s_offset[kMaxLevels], s_dense[kMaxLevels];
   const unsigned n_bins = plan.bin0[plan.count];
+  if (threadIdx.x <= (unsigned)plan.count) s_bin0[threadIdx.x] = plan.bin0[threadIdx.x];
+  if (threadIdx.x < (unsigned)L.n_levels) { s_size[threadIdx.x] = L.size[threadIdx.x]; s_offset[threadIdx.x] = L.offset[threadIdx.x]; s_dense[threadIdx.x] = L.dense[threadIdx.x]; }
   if (threadIdx.x == 0) carry_r = carry_i = 0;
   if (fold_amax && threadIdx.x < 64) {         // the producer's kAmaxSlots running maxima -> the call's amax_bits; slots cleared for the next call
     unsigned* slots = reinterpret_cast<unsigned*>(header) + kAmaxSlotWord;
@@ -632,9 +635,14 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, u
     if (threadIdx.x == 0) header->amax_bits = max(header->amax_bits, v);
   }
   __syncthreads();
+  // the first four rounds' counts are loaded before the first scan (one global-load latency instead of one per round)
+  const unsigned* src = spec_capacity ? est : count;
+  unsigned pre[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const unsigned b = r * 1024 + threadIdx.x; pre[r] = b < n_bins ? src[b] : 0u; }
   for (unsigned base = 0; base < n_bins; base += 1024) {
-    const unsigned b = base + threadIdx.x;
-    unsigned c = b < n_bins ? (spec_capacity ? est[b] : count[b]) : 0u;
+    const unsigned b = base + threadIdx.x, round = base >> 10;
+    unsigned c = round == 0 ? pre[0] : round == 1 ? pre[1] : round == 2 ? pre[2] : round == 3 ? pre[3] : (b < n_bins ? src[b] : 0u);
     if (b < n_bins) {
       if (spec_capacity) {
         c = c + (c >> 3) + 64u;
@@ -659,25 +667,39 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, u
     scan_r[threadIdx.x] = sr + before_r;
     scan_i[threadIdx.x] = si + before_i;
     __syncthreads();
-    const unsigned r0 = carry_r + scan_r[threadIdx.x] - c, i0 = carry_i + scan_i[threadIdx.x] - it;
+    const unsigned r0 = carry_r + scan_r[threadIdx.x] - c;
     if (b < n_bins) {
       cursor[b] = r0;
       if (start != nullptr) start[b] = r0;
-      int li = 0;
-      while (li + 1 < plan.count && plan.bin0[li + 1] <= b) ++li;
-      const unsigned first = (b - plan.bin0[li]) << kSliceLog2;
-      const int tbl = (plan.first + li) / L.n_levels, lvl = plan.first + li - tbl * L.n_levels;
-      const unsigned entry0 = tbl * plan.table_stride + L.offset[lvl] + first;
-      const unsigned live = min(kSlice, L.size[lvl] - first);      // the level's last slice may be partial
-      for (unsigned j = 0; j < it; ++j) {
-        BinItem item;
-        item.entry0 = entry0;
-        item.begin = r0 + j * chunk;
-        item.end = r0 + (unsigned)min((unsigned long long)c, (unsigned long long)(j + 1) * chunk);
-        item.atomic = (it > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) | (L.dense[lvl] ? kItemRuns : 0u);
-        item.bin = b;
-        items[i0 + j] = item;
+    }
+    // the round's work items, written by ALL threads (item k belongs to the bin whose inclusive item scan first exceeds k): a bin of a
+    // coarse dense level is cut into a few hundred items, which ONE thread used to write one after the other -- most of this
+    // launch's time, and the launch sits alone on the pass's critical path
+    const unsigned round_items = scan_i[1023];
+    for (unsigned k = threadIdx.x; k < round_items; k += 1024) {
+      unsigned lo = 0, hi = 1023;
+      while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (scan_i[mid] > k) hi = mid; else lo = mid + 1;
       }
+      const unsigned t = lo, bb = base + t;
+      const unsigned it_t = scan_i[t] - (t ? scan_i[t - 1] : 0u), c_t = scan_r[t] - (t ? scan_r[t - 1] : 0u);
+      const unsigned j = k - (scan_i[t] - it_t), rb = carry_r + scan_r[t] - c_t;
+      int li = 0, hi_l = plan.count - 1;          // the bin's virtual level: last li with s_bin0[li] <= bb (binary search in LDS: a walk
+      while (li < hi_l) {                          // over the kernel argument's array costs a dependent scalar load per step)
+        const int mid = (li + hi_l + 1) >> 1;
+        if (s_bin0[mid] <= bb) li = mid; else hi_l = mid - 1;
+      }
+      const unsigned first = (bb - s_bin0[li]) << kSliceLog2;
+      const int tbl = (plan.first + li) / L.n_levels, lvl = plan.first + li - tbl * L.n_levels;
+      const unsigned live = min(kSlice, s_size[lvl] - first);      // the level's last slice may be partial
+      BinItem item;
+      item.entry0 = tbl * plan.table_stride + s_offset[lvl] + first;
+      item.begin = rb + j * chunk;
+      item.end = rb + (unsigned)min((unsigned long long)c_t, (unsigned long long)(j + 1) * chunk);
+      item.atomic = (it_t > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) | (s_dense[lvl] ? kItemRuns : 0u);
+      item.bin = bb;
+      items[carry_i + k] = item;
     }
     __syncthreads();
     if (threadIdx.x == 1023) {
