@@ -60,12 +60,15 @@ int nerf_abi_version(void);
  *   - compaction: use nerf_sample_compact_ordered (slots in sample order) instead of nerf_sample_compact*;
  *   - nerf_imlp_bwd / nerf_p4_canon_bwd / nerf_p4_deform_bwd: weight gradients through partial tiles summed in workgroup order
  *     (inside the workspace), the displacement-scale gradient through an ordered sum;
- *   - nerf_hash_encode_bwd_ws*: no bin is cut into several work items (nothing is flushed with float atomics); the forms without a
- *     workspace return NERF_EINVAL;
+ *   - nerf_hash_encode_bwd_ws*: a bin that is cut into several work items (the coarse dense levels) is summed with 64-bit INTEGER
+ *     atomics on the records' fixed-point terms in a staging array inside the workspace (integer addition commutes: any order gives
+ *     the same bits) and converted by a last small launch; no float atomics anywhere.  The forms without a workspace return
+ *     NERF_EINVAL;
  *   - nerf_hash_encode_bwd_input*: point on the thread, levels summed in order;
  *   - nerf_composite_mse*_bwd: pass `sum_ws` (the loss and regulariser sums; they do not enter the gradients; the engines always do).
- * Always ordered, option or not: the vanilla decoder's weight gradients, nerf_tv_normsq*.  Measured cost per step: Part 4 0.3 ms,
- * Instant 0.8 ms (uncut bins of the coarse dense levels serialise on one workgroup each; profiles/r04_deterministic_cost.txt). */
+ * Always ordered, option or not: the vanilla decoder's weight gradients, nerf_tv_normsq*.  Measured cost per step: Instant +0.085 ms
+ * (0.514 -> 0.599), Part 4 +0.10 ms (0.730 -> 0.832): ordered compaction (three launches), partial tiles of the tiny-MLP weight
+ * gradients, the staging pass (profiles/r04_deterministic_cost.txt). */
 int nerf_set_option(const char* name, int value);
 int nerf_get_option(const char* name, int* value_out);
 

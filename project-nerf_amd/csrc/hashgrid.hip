@@ -419,6 +419,7 @@ constexpr int kSpecStatusWord = 16;            // the speculative form's last la
 struct BinItem {
   unsigned entry0, begin, end, atomic;         // first table entry of the slice, record range, flush: mode | live entries << 2
   unsigned bin;                                // the item's bin (speculative form: the range ends at the bin's cursor)
+  unsigned stage0;                             // kFlushInt: first entry of the slice in the integer staging array
 };
 // Speculative form (nerf_hash_encode_bwd_ws_store_spec): NO count pass.  The bins' capacities come from the previous call's true
 // counts (kept in the workspace) + 1/8 + 64; a record that does not fit its bin goes to an overflow list that a last small launch
@@ -428,6 +429,13 @@ constexpr unsigned kMaxOverflow = 1u << 20;    // overflow records live behind t
 // contributions: the accumulate form), float atomics (the bin was cut into several items), plain STORE of the whole slice
 // (the overwrite form: d_table needs no zeroing and is not read back)
 constexpr unsigned kFlushRmw = 0, kFlushAtomic = 1, kFlushStore = 2;
+// option "deterministic": a cut bin's items add their 64-bit FIXED-POINT sums with integer atomics into a staging array (two words
+// per table entry of the coarse dense levels -- the only bins worth cutting: a few MB in the slack of the record area); integer
+// addition commutes, so the result does not depend on the order, and a last small launch converts the staged sums to floats.
+// Without it a deterministic call could not cut bins at all: the two bins of Instant-NGP's level 0 -- hundreds of thousands of
+// records each -- were then summed by one workgroup each (0.79 ms instead of 0.06 for the reduce launch).
+constexpr unsigned kFlushInt = 3;
+constexpr unsigned kItemFirstOfBin = 1u << 17;
 // items of the dense (coarse) levels: consecutive samples of a ray sit in the same cell, so a bin's records come in runs of equal
 // slots (16 at the coarsest level) -- read lane-adjacent, a wave's 64 adds pile up on a few LDS addresses (level 0 alone: 51 us of
 // the reduce launch's 70).  For these items every lane takes EIGHT CONSECUTIVE records, sums equal neighbours in registers
@@ -613,7 +621,9 @@ __device__ __forceinline__ int fixed_shift(unsigned amax_bits) {
 __global__ void __launch_bounds__(1024)
 hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, unsigned* __restrict__ cursor,
                      BinItem* __restrict__ items, BinHeader* __restrict__ header, int overwrite, unsigned chunk,
-                     unsigned* __restrict__ est, unsigned* __restrict__ start, unsigned spec_capacity, int fold_amax) {
+                     unsigned* __restrict__ est, unsigned* __restrict__ start, unsigned spec_capacity, int fold_amax,
+                     unsigned dense_entries, int det_int) {
+  // det_int (option "deterministic" with a staging array): only the bins of DENSE levels are cut (chunk), the others never
   // est != null, spec_capacity == 0 (counted forms): the bins' true counts are also left in est for a later speculative call.
   // spec_capacity > 0 (speculative form): NO counts exist -- a bin's capacity is est + est / 8 + 64 (written to count[], which the
   // later passes read as the bin's size), its records start at start[bin]; the reduce pass reads the true fill from cursor[]
@@ -649,8 +659,14 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, u
         count[b] = c;
       } else if (est != nullptr) est[b] = c;
     }
+    unsigned chunk_b = chunk;
+    if (det_int && b < n_bins) {
+      int li = 0, hi_l = plan.count - 1;
+      while (li < hi_l) { const int mid = (li + hi_l + 1) >> 1; if (s_bin0[mid] <= b) li = mid; else hi_l = mid - 1; }
+      if (!s_dense[(plan.first + li) % L.n_levels]) chunk_b = 0xffffffffu;
+    }
     // overwrite form: every bin gets an item (an empty bin's item stores a slice of zeros)
-    const unsigned it = c == 0 ? ((b < n_bins && overwrite) ? 1u : 0u) : (unsigned)(((unsigned long long)c + chunk - 1) / chunk);
+    const unsigned it = c == 0 ? ((b < n_bins && overwrite) ? 1u : 0u) : (unsigned)(((unsigned long long)c + chunk_b - 1) / chunk_b);
     // inclusive scan of both columns: within the wave by shuffles, the sixteen wave totals through LDS (two barriers per round
     // instead of twenty: the launch sits alone on the pass's critical path)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -695,10 +711,12 @@ hash_bin_plan_kernel(HashLevels L, BinPlan plan, unsigned* __restrict__ count, u
       const unsigned live = min(kSlice, s_size[lvl] - first);      // the level's last slice may be partial
       BinItem item;
       item.entry0 = tbl * plan.table_stride + s_offset[lvl] + first;
-      item.begin = rb + j * chunk;
-      item.end = rb + (unsigned)min((unsigned long long)c_t, (unsigned long long)(j + 1) * chunk);
-      item.atomic = (it_t > 1 ? kFlushAtomic : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) | (s_dense[lvl] ? kItemRuns : 0u);
+      item.begin = rb + j * chunk;                                 // (j > 0 only in bins that are cut by `chunk`)
+      item.end = it_t > 1 ? rb + (unsigned)min((unsigned long long)c_t, (unsigned long long)(j + 1) * chunk) : rb + c_t;
+      item.atomic = (it_t > 1 ? (det_int ? kFlushInt : kFlushAtomic) : (overwrite ? kFlushStore : kFlushRmw)) | (live << 2) |
+                    (s_dense[lvl] ? kItemRuns : 0u) | (j == 0 ? kItemFirstOfBin : 0u);
       item.bin = bb;
+      item.stage0 = tbl * dense_entries + s_offset[lvl] + first;
       items[carry_i + k] = item;
     }
     __syncthreads();
@@ -733,7 +751,10 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
                         unsigned* __restrict__ cursor, BinRecord* __restrict__ records, const BinHeader* __restrict__ header,
                         const float2* __restrict__ grad_lm, const unsigned* __restrict__ count, float* __restrict__ zero_table,
                         int all_live, unsigned chunk, const unsigned* __restrict__ spec_start, unsigned* __restrict__ overflow_bin,
-                        BinHeader* __restrict__ header_rw, unsigned overflow_base) {
+                        BinHeader* __restrict__ header_rw, unsigned overflow_base, unsigned long long* __restrict__ istage,
+                        unsigned dense_entries) {
+  // istage != null (option "deterministic"): the cut bins (dense levels only) are summed in the integer staging array: their slices
+  // of THAT are zeroed here, d_table is written by the convert launch
   // spec_start != null (speculative form, staged levels only): bin b holds count[b] records from spec_start[b] on; a record past
   // that goes to the overflow list (records[overflow_base + o], its bin in overflow_bin[o])
   constexpr unsigned kBins = STAGED ? kStagedBins : kMaxSlices;
@@ -747,7 +768,15 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
   const unsigned bins = plan.bin0[blockIdx.y + 1] - plan.bin0[blockIdx.y], offset = L.offset[lvl];
   if (STAGED != (bins <= kStagedBins)) return;                 // the other instantiation owns this level
   d_feat += tbl * plan.dfeat_stride;
-  if (zero_table != nullptr) {
+  if (istage != nullptr) {
+    if (L.dense[lvl])
+      for (unsigned b = blockIdx.x; b < bins; b += gridDim.x) {
+        if (count[plan.bin0[blockIdx.y] + b] <= chunk) continue;
+        const unsigned first = b << kSliceLog2, live = min(kSlice, L.size[lvl] - first);
+        unsigned long long* dst = istage + 2 * ((size_t)tbl * dense_entries + offset + first);
+        for (unsigned i = threadIdx.x; i < 2 * live; i += blockDim.x) dst[i] = 0ull;
+      }
+  } else if (zero_table != nullptr) {
     // overwrite form: a bin that was cut into several items is flushed with atomics by the reduce pass (a later launch),
     // so its slice is zeroed here -- the coarse dense levels in steady state, 1.8 MB of a 52 MB table
     for (unsigned b = blockIdx.x; b < bins; b += gridDim.x) {
@@ -864,7 +893,7 @@ hash_bin_scatter_kernel(const float* __restrict__ pts, int64_t n, HashLevels L, 
 __global__ void __launch_bounds__(512)
 hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __restrict__ items, const BinRecord* __restrict__ records,
                        float* __restrict__ d_table, unsigned table_entries, const unsigned* __restrict__ spec_cursor,
-                       const unsigned* __restrict__ spec_start, unsigned* __restrict__ est) {
+                       const unsigned* __restrict__ spec_start, unsigned* __restrict__ est, unsigned long long* __restrict__ istage) {
   // spec_cursor != null (speculative form): an item's range was planned from the bin's CAPACITY; what was written ends at the
   // bin's cursor.  The bin's true count (cursor - start, overflow included) is left in est for the next call.
   __shared__ unsigned long long acc[2 * kSlice];            // 64 KiB of 64-bit fixed-point sums
@@ -933,6 +962,10 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
         if (a0 != 0) atomicAdd(&dst[i].x, __ll2float_rn(a0) * inv_scale);
         if (a1 != 0) atomicAdd(&dst[i].y, __ll2float_rn(a1) * inv_scale);
       }
+    } else if (mode == kFlushInt) {             // integer sums: the same total in any order (option "deterministic")
+      unsigned long long* sdst = istage + 2 * (size_t)item.stage0;
+      for (unsigned i = threadIdx.x; i < 2 * live; i += blockDim.x)
+        if (acc[i] != 0ull) atomicAdd(&sdst[i], acc[i]);
     } else {
       // the slice belongs to this workgroup for the whole launch: plain read-modify-write, all loads first
       static_assert(kSlice % 512 == 0, "flush");
@@ -952,6 +985,25 @@ hash_bin_reduce_kernel(const BinHeader* __restrict__ header, const BinItem* __re
       }
     }
     __syncthreads();
+  }
+}
+
+// option "deterministic": the cut bins' staged integer sums -> d_table (stored, or added to what is there: the accumulating form);
+// one workgroup per first item of a cut bin
+__global__ void __launch_bounds__(256)
+hash_bin_stage_convert_kernel(const BinHeader* __restrict__ header, const BinItem* __restrict__ items, const unsigned long long* __restrict__ istage,
+                              float* __restrict__ d_table, unsigned table_entries, int accumulate) {
+  const float inv_scale = __uint_as_float((unsigned)(127 - fixed_shift(header->amax_bits)) << 23);
+  for (unsigned item_id = blockIdx.x; item_id < header->n_items; item_id += gridDim.x) {
+    const BinItem item = items[item_id];
+    if ((item.atomic & 3u) != kFlushInt || !(item.atomic & kItemFirstOfBin)) continue;
+    const unsigned live = min((item.atomic >> 2) & kItemLiveMask, table_entries - item.entry0);
+    float2* dst = reinterpret_cast<float2*>(d_table) + item.entry0;
+    const unsigned long long* src = istage + 2 * (size_t)item.stage0;
+    for (unsigned i = threadIdx.x; i < live; i += blockDim.x) {
+      const float2 v = make_float2(__ll2float_rn((long long)src[2 * i]) * inv_scale, __ll2float_rn((long long)src[2 * i + 1]) * inv_scale);
+      dst[i] = accumulate ? make_float2(dst[i].x + v.x, dst[i].y + v.y) : v;
+    }
   }
 }
 
@@ -1131,6 +1183,25 @@ static int hash_fwd_impl(const float* pts, int64_t n, const float* table, const 
   return check_launch("nerf_hash_encode_fwd");
 }
 
+// option "deterministic": the integer staging array of the cut bins (kFlushInt) lives in the slack of the record area -- a counted call
+// writes at most n * 8 * levels records of a capacity 1.25 x that + 64 per bin.  dense_entries: entries of the leading dense levels
+// (the only levels whose bins are cut then).  ptr NULL: no room (or no dense level): no bin is cut at all, as before.
+struct DetStage { unsigned long long* ptr; unsigned dense_entries; };
+static DetStage det_stage(const BinWorkspace& w, int64_t n, int plan_levels, int n_levels, int n_tables, const unsigned* size_host,
+                          const unsigned* dense_host) {
+  DetStage d{nullptr, 0};
+  if (!options().deterministic) return d;
+  unsigned dense = 0;
+  for (int i = 0; i < n_levels && dense_host[i]; ++i) dense += size_host[i];
+  const size_t used = (size_t)n * 8 * (size_t)plan_levels, cap = bin_record_capacity(n, plan_levels);
+  const size_t need = (size_t)n_tables * dense * 2;            // 64-bit words, one BinRecord's size each
+  if (dense == 0 || used + need > cap) return d;
+  static_assert(sizeof(BinRecord) == sizeof(unsigned long long), "staging words");
+  d.ptr = reinterpret_cast<unsigned long long*>(w.records + used);
+  d.dense_entries = dense;
+  return d;
+}
+
 static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float* scale_host,
                          const unsigned* res_host, const unsigned* size_host, const unsigned* offset_host,
                          const unsigned* dense_host, float bound, const float* d_feat, float* d_table,
@@ -1197,27 +1268,31 @@ static int hash_bwd_impl(const float* pts, int64_t n, int n_levels, const float*
         hipLaunchKernelGGL(hash_bin_count_kernel, dim3((int)bx_count, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan, d_feat,
                            w.count, w.header);
       const float2* grad_lm = point_major ? w.grad_lm : nullptr;
-      const unsigned chunk = options().deterministic ? 0xffffffffu : kChunk;
+      const DetStage ds = det_stage(w, n, n_levels, n_levels, 1, size_host, dense_host);
+      const unsigned chunk = (options().deterministic && ds.ptr == nullptr) ? 0xffffffffu : kChunk;
       bool any_staged = false, any_direct = false;
       for (int i = 0; i < plan.count; ++i) (plan.bin0[i + 1] - plan.bin0[i] <= kStagedBins ? any_staged : any_direct) = true;
       NERF_REQUIRE(!spec || !any_direct, "nerf_hash_encode_bwd_ws_store_spec: a level with more than %u slices", kStagedBins);
       hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header,
                          overwrite ? 1 : 0, chunk, whole ? w.est : nullptr, spec ? w.start : nullptr,
-                         spec ? (unsigned)bin_record_capacity(n, n_levels) : 0u, precounted != 0 ? 1 : 0);
+                         spec ? (unsigned)bin_record_capacity(n, n_levels) : 0u, precounted != 0 ? 1 : 0, ds.dense_entries, ds.ptr != nullptr);
       float* zero_table = overwrite ? d_table : nullptr;
       const unsigned* spec_start = spec ? w.start : nullptr;
       if (any_staged)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
                            plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted == 1 ? 1 : 0, chunk,
-                           spec_start, w.overflow_bin, w.header, (unsigned)bin_record_capacity(n, n_levels));
+                           spec_start, w.overflow_bin, w.header, (unsigned)bin_record_capacity(n, n_levels), ds.ptr, ds.dense_entries);
       if (any_direct)
         hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L,
                            plan, d_feat, w.cursor, w.records, w.header, grad_lm, w.count, zero_table, precounted == 1 ? 1 : 0, chunk,
-                           (const unsigned*)nullptr, w.overflow_bin, w.header, 0u);
+                           (const unsigned*)nullptr, w.overflow_bin, w.header, 0u, ds.ptr, ds.dense_entries);
       size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
       if (grid > 4096) grid = 4096;             // persistent beyond that: items are taken round-robin
       hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records,
-                         d_table, table_entries, spec ? w.cursor : (const unsigned*)nullptr, spec_start, w.est);
+                         d_table, table_entries, spec ? w.cursor : (const unsigned*)nullptr, spec_start, w.est, ds.ptr);
+      if (ds.ptr != nullptr)
+        hipLaunchKernelGGL(hash_bin_stage_convert_kernel, dim3(256), dim3(256), 0, as_stream(stream), w.header, w.items, ds.ptr, d_table,
+                           table_entries, overwrite ? 0 : 1);
       if (spec)
         hipLaunchKernelGGL(hash_bin_overflow_kernel, dim3(64), dim3(256), 0, as_stream(stream), w.header,
                            w.records + bin_record_capacity(n, n_levels), w.overflow_bin, L, plan, d_table, static_cast<unsigned*>(status_host));
@@ -1355,7 +1430,8 @@ static int hash_bwd_tables_impl(const float* pts, int64_t n, int n_tables, int64
   NERF_REQUIRE((size_t)n * 8 * (size_t)plan.count < 0xffffffffull, "nerf_hash_encode_bwd_ws_store_tables: n=%lld too large for 32-bit record offsets",
                (long long)n);
   const BinWorkspace w = carve(workspace, n, plan.count);
-  const unsigned chunk = options().deterministic ? 0xffffffffu : kChunk;
+  const DetStage ds = det_stage(w, n, plan.count, n_levels, n_tables, size_host, dense_host);
+  const unsigned chunk = (options().deterministic && ds.ptr == nullptr) ? 0xffffffffu : kChunk;
   const unsigned capacity = (unsigned)bin_record_capacity(n, plan.count);
   const float2* grad_lm = w.grad_lm;
   if (spec) {
@@ -1375,22 +1451,26 @@ static int hash_bwd_tables_impl(const float* pts, int64_t n, int n_tables, int64
   }
   // (the counted call leaves the bins' true counts in est[] for a later speculative one)
   hipLaunchKernelGGL(hash_bin_plan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), L, plan, w.count, w.cursor, w.items, w.header, 1, chunk,
-                     w.est, spec ? w.start : (unsigned*)nullptr, spec ? capacity : 0u, spec ? 1 : 0);
+                     w.est, spec ? w.start : (unsigned*)nullptr, spec ? capacity : 0u, spec ? 1 : 0, ds.dense_entries, ds.ptr != nullptr);
   const unsigned* spec_start = spec ? w.start : nullptr;
   int64_t bx = (n + 511) / 512;
   const int64_t bx_scatter = bx > 128 ? 128 : bx;
   if (any_staged)
     hipLaunchKernelGGL(hash_bin_scatter_kernel<true>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
                        d_feat, w.cursor, w.records, w.header, grad_lm, w.count, d_table, 0, chunk, spec_start, w.overflow_bin, w.header,
-                       spec ? capacity : 0u);
+                       spec ? capacity : 0u, ds.ptr, ds.dense_entries);
   if (any_direct)
     hipLaunchKernelGGL(hash_bin_scatter_kernel<false>, dim3((int)bx_scatter, plan.count), dim3(512), 0, as_stream(stream), pts, n, L, plan,
-                       d_feat, w.cursor, w.records, w.header, grad_lm, w.count, d_table, 0, chunk, (const unsigned*)nullptr, w.overflow_bin, w.header, 0u);
+                       d_feat, w.cursor, w.records, w.header, grad_lm, w.count, d_table, 0, chunk, (const unsigned*)nullptr, w.overflow_bin, w.header, 0u,
+                       ds.ptr, ds.dense_entries);
   size_t grid = (size_t)n * 8 * plan.count / kChunk + n_bins;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(hash_bin_reduce_kernel, dim3((unsigned)grid), dim3(512), 0, as_stream(stream), w.header, w.items, w.records, d_table,
                      (unsigned)((uint64_t)(n_tables - 1) * (uint64_t)table_stride + entries), spec ? w.cursor : (const unsigned*)nullptr, spec_start,
-                     w.est);
+                     w.est, ds.ptr);
+  if (ds.ptr != nullptr)
+    hipLaunchKernelGGL(hash_bin_stage_convert_kernel, dim3(256), dim3(256), 0, as_stream(stream), w.header, w.items, ds.ptr, d_table,
+                       (unsigned)((uint64_t)(n_tables - 1) * (uint64_t)table_stride + entries), 0);
   if (spec)
     hipLaunchKernelGGL(hash_bin_overflow_kernel, dim3(64), dim3(256), 0, as_stream(stream), w.header, w.records + capacity, w.overflow_bin, L,
                        plan, d_table, static_cast<unsigned*>(status_host));
