@@ -159,14 +159,18 @@ int nerf_sample_compact_jitter_shard(const float* rays_o, const float* rays_d, u
                                      const uint8_t* binary_grid, int resolution, float bound, float* z_out,
                                      int* slot_of_sample, float* pts_compact, float* dirs_compact,
                                      unsigned* active_count, nerf_stream_t stream);
-/* ... as a link of a CHAIN of calls on one stream: active_count is NOT cleared by the call (the previous link cleared it, the caller
- * clears it before the first link) and the kernel clears *next_count, the counter the caller hands to the next link.  Two counters
- * used alternately need no fill launch per call; read call k's count before call k + 2 is queued. */
+/* ... as a link of a CHAIN of calls on one stream.  chain_state: NERF_COMPACT_CHAIN_WORDS device u32 words, zeroed ONCE by the caller:
+ * two counters used alternately (this call counts in word `turn` (0 / 1) and its kernel clears word `turn ^ 1` for the next link: no
+ * fill launch per call) and the tickets of the workgroup that finishes last, which writes the count to count_host[0] and then `seq` to
+ * count_host[1] (two u32 of host-mapped pinned memory; NULL: no publication).  No copy launch and no event behind the kernel: the
+ * host polls count_host[1] for its seq.  A host that queues batch k + 1 before it runs step k reads word `turn` of call k before
+ * call k + 2 is queued. */
+#define NERF_COMPACT_CHAIN_WORDS 40
 int nerf_sample_compact_jitter_chain(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,
                                      int64_t first_ray, int64_t n_rays, int n_samples, float near_plane, float far_plane,
                                      const uint8_t* binary_grid, int resolution, float bound, float* z_out,
                                      int* slot_of_sample, float* pts_compact, float* dirs_compact,
-                                     unsigned* active_count, unsigned* next_count, nerf_stream_t stream);
+                                     unsigned* chain_state, int turn, unsigned* count_host, unsigned seq, nerf_stream_t stream);
 
 /* the same compaction with the slots in SAMPLE ORDER (option "deterministic": the single-pass kernels reserve slots with a returning
  * atomic per 4096 samples, so the order of the compact arrays -- and with it the order of every later sum over samples -- depends

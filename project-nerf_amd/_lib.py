@@ -38,7 +38,7 @@ PROTOTYPES = {
     "nerf_sample_compact_jitter_shard": (i32, [c_ptr, c_ptr, ctypes.c_uint64, ctypes.c_uint64, i64, i64, i32, f32, f32, c_ptr, i32, f32,
                                                c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_sample_compact_jitter_chain": (i32, [c_ptr, c_ptr, ctypes.c_uint64, ctypes.c_uint64, i64, i64, i32, f32, f32, c_ptr, i32, f32,
-                                               c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+                                               c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i32, c_ptr, ctypes.c_uint32, c_ptr]),
     "nerf_composite_fwd_indexed": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, i64, i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "nerf_composite_bwd_indexed": (i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, i64, c_ptr, c_ptr, c_ptr, i64, i32, c_ptr, c_ptr, c_ptr]),
     "nerf_sample_pdf": (i32, [c_ptr, c_ptr, c_ptr, i64, i32, i32, c_ptr, c_ptr]),
@@ -161,7 +161,8 @@ def load():
     return lib
 
 
-NORMSQ_WS_FLOATS = 4136     # NERF_NORMSQ_WS_FLOATS
+NORMSQ_WS_FLOATS = 4136
+COMPACT_CHAIN_WORDS = 40     # NERF_COMPACT_CHAIN_WORDS     # NERF_NORMSQ_WS_FLOATS
 SUM_WS_FLOATS = 12288       # NERF_SUM_WS_FLOATS
 
 

@@ -33,7 +33,8 @@ sample_compact_kernel(const float* __restrict__ rays_o, const float* __restrict_
                       const uint8_t* __restrict__ grid, int res, float bound, float scale,
                       float* __restrict__ z_out, int* __restrict__ slot_of_sample,
                       float* __restrict__ pts_c, float* __restrict__ dirs_c, unsigned* __restrict__ count,
-                      uint64_t key, uint64_t counter, int draw, uint64_t first_sample, unsigned* __restrict__ zero_out) {
+                      uint64_t key, uint64_t counter, int draw, uint64_t first_sample, unsigned* __restrict__ zero_out,
+                      unsigned* __restrict__ tickets, unsigned* __restrict__ count_host, unsigned seq) {
   if (zero_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_out = 0u;      // the NEXT call's counter (chained form)
   const int64_t total = n_rays * (int64_t)S;
   const int64_t span = (int64_t)kCompactThreads * kCompactPer;
@@ -106,6 +107,22 @@ sample_compact_kernel(const float* __restrict__ rays_o, const float* __restrict_
       }
     }
     __syncthreads();                                    // seg is rewritten by the next pass
+  }
+  // chained form: the workgroup that finishes last hands the count to the host -- two words of host-mapped pinned memory, the call's
+  // sequence number written last behind a system-scope fence -- instead of a copy launch and an event behind the kernel (each of those
+  // packets cost the stream a ~5-us gap of its own).  Tickets in two stages (32 groups: same-address atomics retire serially).
+  if (tickets != nullptr && threadIdx.x == 0) {       // (this workgroup's atomics on *count have returned: their values were used)
+    const unsigned B = gridDim.x, g = blockIdx.x % 32u, in_group = (B - g + 31u) / 32u;
+    if (atomicAdd(&tickets[1 + g], 1u) == in_group - 1) {
+      atomicExch(&tickets[1 + g], 0u);
+      if (atomicAdd(&tickets[0], 1u) == (B < 32u ? B : 32u) - 1) {
+        atomicExch(&tickets[0], 0u);
+        volatile unsigned* host = count_host;
+        host[0] = atomicOr(count, 0u);
+        __threadfence_system();
+        host[1] = seq;
+      }
+    }
   }
 }
 
@@ -225,19 +242,20 @@ static int sample_compact_impl(const float* rays_o, const float* rays_d, const f
                                int resolution, float bound, float* z_out, int* slot_of_sample, float* pts_compact,
                                float* dirs_compact, unsigned* active_count, nerf_stream_t stream,
                                uint64_t key, uint64_t counter, int draw, uint64_t first_sample = 0, void* scratch = nullptr,
-                               size_t scratch_bytes = 0, unsigned* next_count = nullptr) {
+                               size_t scratch_bytes = 0, unsigned* next_count = nullptr, unsigned* tickets = nullptr,
+                               unsigned* count_host = nullptr, unsigned seq = 0) {
   NERF_REQUIRE(n_rays >= 0 && n_samples >= 2 && resolution > 0 && resolution <= 32768 && bound > 0.0f, "nerf_sample_compact: bad sizes");
   NERF_REQUIRE(active_count != nullptr, "nerf_sample_compact: active_count is NULL");
   // chained form (next_count): active_count was cleared by the previous call of the chain (or by the caller), this call's kernel
   // clears *next_count -- no fill launch per call
   if (next_count == nullptr && hipMemsetAsync(active_count, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
     return fail(NERF_ELAUNCH, "nerf_sample_compact: memset failed");
-  if (n_rays == 0) {
+  if (n_rays == 0 && tickets == nullptr) {
     if (next_count != nullptr && hipMemsetAsync(next_count, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
       return fail(NERF_ELAUNCH, "nerf_sample_compact: memset failed");
     return NERF_OK;
-  }
-  NERF_REQUIRE(rays_o && rays_d && binary_grid && z_out && slot_of_sample && pts_compact && dirs_compact,
+  }                                                    // (publishing form with no rays: one workgroup that publishes a count of zero)
+  NERF_REQUIRE(n_rays == 0 || (rays_o && rays_d && binary_grid && z_out && slot_of_sample && pts_compact && dirs_compact),
                "nerf_sample_compact: NULL pointer");
   const float step = 1.0f / (float)(n_samples - 1);
   const float scale = (float)((double)resolution / (2.0 * (double)bound));
@@ -245,6 +263,7 @@ static int sample_compact_impl(const float* rays_o, const float* rays_d, const f
   int64_t blocks = (n_rays * n_samples + span - 1) / span;
   const int64_t n_seg = blocks * 64;                     // before the cap: one (k, wave) segment per 64 samples of every pass
   if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
   if (scratch != nullptr) {                              // ordered form: slots in sample order
     NERF_REQUIRE(scratch_bytes >= (size_t)n_seg * sizeof(unsigned) && ((uintptr_t)scratch & 3) == 0,
                  "nerf_sample_compact_ordered: scratch of %zu bytes, %zu needed", scratch_bytes, (size_t)n_seg * sizeof(unsigned));
@@ -259,7 +278,7 @@ static int sample_compact_impl(const float* rays_o, const float* rays_d, const f
   }
   hipLaunchKernelGGL(sample_compact_kernel, dim3((int)blocks), dim3(kCompactThreads), 0, as_stream(stream), rays_o, rays_d, u, n_rays,
                      n_samples, near_plane, far_plane, step, binary_grid, resolution, bound, scale, z_out, slot_of_sample,
-                     pts_compact, dirs_compact, active_count, key, counter, draw, first_sample, next_count);
+                     pts_compact, dirs_compact, active_count, key, counter, draw, first_sample, next_count, tickets, count_host, seq);
   return check_launch("nerf_sample_compact");
 }
 
@@ -283,20 +302,22 @@ extern "C" int nerf_sample_compact_jitter_shard(const float* rays_o, const float
                              (uint64_t)first_ray * (uint64_t)n_samples);
 }
 
-// The same call as a link of a CHAIN of calls on one stream: active_count is NOT cleared here (it was cleared by the previous link, or
-// by the caller before the first), and the kernel clears *next_count, the counter the caller passes to the next link -- two counters
-// used alternately need no fill launch per call (4.3 us + its launch gap in a 0.5-ms step).
+// The same call as a link of a CHAIN of calls on one stream.  chain_state: NERF_COMPACT_CHAIN_WORDS device words, zeroed ONCE by the
+// caller: two counters used alternately (this call counts in word `turn` and its kernel clears word `turn ^ 1` for the next link: no
+// fill launch per call) and the tickets of the workgroup that finishes last, which writes the count to count_host[0] and then
+// `seq` to count_host[1] (host-mapped pinned memory; NULL: no publication): no copy launch, no event -- the host polls for its seq.
 extern "C" int nerf_sample_compact_jitter_chain(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,
                                                 int64_t first_ray, int64_t n_rays, int n_samples, float near_plane, float far_plane,
                                                 const uint8_t* binary_grid, int resolution, float bound, float* z_out,
                                                 int* slot_of_sample, float* pts_compact, float* dirs_compact,
-                                                unsigned* active_count, unsigned* next_count, nerf_stream_t stream) {
+                                                unsigned* chain_state, int turn, unsigned* count_host, unsigned seq, nerf_stream_t stream) {
   NERF_REQUIRE(first_ray >= 0 && counter < ((uint64_t)1 << 24) && (first_ray + n_rays) * (int64_t)n_samples < ((int64_t)1 << 40),
                "nerf_sample_compact_jitter_chain: counter / batch out of range");
-  NERF_REQUIRE(next_count != nullptr && next_count != active_count, "nerf_sample_compact_jitter_chain: next_count NULL or equal to active_count");
+  NERF_REQUIRE(chain_state != nullptr && (turn == 0 || turn == 1), "nerf_sample_compact_jitter_chain: chain_state NULL or turn not 0 / 1");
   return sample_compact_impl(rays_o, rays_d, nullptr, n_rays, n_samples, near_plane, far_plane, binary_grid, resolution, bound,
-                             z_out, slot_of_sample, pts_compact, dirs_compact, active_count, stream, squares_key(seed), counter, 1,
-                             (uint64_t)first_ray * (uint64_t)n_samples, nullptr, 0, next_count);
+                             z_out, slot_of_sample, pts_compact, dirs_compact, chain_state + turn, stream, squares_key(seed), counter, 1,
+                             (uint64_t)first_ray * (uint64_t)n_samples, nullptr, 0, chain_state + (turn ^ 1),
+                             count_host != nullptr ? chain_state + 2 : nullptr, count_host, seq);
 }
 
 extern "C" int nerf_sample_compact_jitter(const float* rays_o, const float* rays_d, uint64_t seed, uint64_t counter,

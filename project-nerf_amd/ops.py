@@ -165,23 +165,43 @@ def normsq_ws(device) -> Tensor:
 _COMPACT_CHAIN = {}
 
 
+class _CompactChain:
+    """per (device, stream): the chained compaction's device state (two counters used alternately + tickets) and a ring of
+    host-mapped pinned (count, seq) pairs the kernels publish their counts into"""
+    RING = 16
+
+    def __init__(self, device):
+        self.state = torch.zeros(_lib.COMPACT_CHAIN_WORDS, device=device, dtype=torch.int32)
+        self.host = torch.zeros(self.RING, 2, dtype=torch.int32).pin_memory()
+        self.host_np = self.host.numpy()          # polled without tensor overhead
+        self.turn, self.seq = 0, 0
+
+    def next(self):
+        self.seq += 1
+        turn, self.turn = self.turn, self.turn ^ 1
+        slot = self.seq % self.RING
+        self.host_np[slot, 1] = 0                 # (a seq is never 0)
+        return turn, slot, self.seq & 0x7FFFFFFF or 1
+
+
 def _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, count):
     """the compaction launch of sample_compact / sample_compact_async: ordered slots when deterministic.  ``count`` None (the
-    asynchronous path with in-kernel jitter): two counters per (device, stream) used alternately, each call's kernel clearing the
-    next call's (nerf_sample_compact_jitter_chain: no fill launch per call); returns the counter the call used."""
+    asynchronous path with in-kernel jitter): nerf_sample_compact_jitter_chain -- no fill launch, no copy launch, no event: returns
+    (host block as numpy [2], seq) to poll; otherwise returns the device counter the call used."""
     draw = u is None and jitter is not None
     seed, counter = (int(jitter[0]), int(jitter[1]) & 0xFFFFFF) if draw else (0, 0)
     if count is None:
         if draw and not deterministic():
             key = (rays_o.device, _stream())
-            pair, turn = _COMPACT_CHAIN.get(key, (None, 0))
-            if pair is None:
-                pair = torch.zeros(2, device=rays_o.device, dtype=torch.int32)
-            _COMPACT_CHAIN[key] = (pair, turn ^ 1)
+            chain = _COMPACT_CHAIN.get(key)
+            if chain is None:
+                chain = _COMPACT_CHAIN[key] = _CompactChain(rays_o.device)
+            turn, slot, seq = chain.next()
             _lib.check(lib.nerf_sample_compact_jitter_chain(_p(rays_o), _p(rays_d), seed, counter, int(first_ray), R, n_samples, near, far,
                                                             _p(grid), grid.shape[0], float(bound), _p(z), _p(slots), _p(pts), _p(dirs),
-                                                            _p(pair[turn:]), _p(pair[turn ^ 1:]), _stream()), "nerf_sample_compact_jitter_chain")
-            return pair[turn:turn + 1]
+                                                            _p(chain.state), turn, chain.host[slot].data_ptr(), seq, _stream()),
+                       "nerf_sample_compact_jitter_chain")
+            return chain.host_np[slot], seq
         count = torch.empty(1, device=rays_o.device, dtype=torch.int32)          # cleared by the library call itself
     if deterministic():
         scratch = torch.empty(max(lib.nerf_sample_compact_ordered_scratch_bytes(R, n_samples), 4), dtype=torch.uint8, device=rays_o.device)
@@ -223,17 +243,25 @@ def sample_compact(rays_o: Tensor, rays_d: Tensor, near: float, far: float, n_sa
 
 
 class CompactedSamples:
-    """Result of ``sample_compact_async``: the kernel and the read-back of the active count are queued, nothing
-    has been waited for.  ``get()`` waits for the count alone (a 4-byte copy into pinned memory, queued right
-    behind the kernel) and returns (z, slots, pts[:n], dirs[:n]) -- by then usually long done, because the caller
-    queued this batch's compaction ahead of the previous step's kernels."""
+    """Result of ``sample_compact_async``: the kernel is queued, nothing has been waited for.  ``get()`` waits for the active count
+    alone and returns (z, slots, pts[:n], dirs[:n]) -- by then usually long there, because the caller queued this batch's
+    compaction ahead of the previous step's kernels.  The count arrives either in a host-mapped block the kernel's last workgroup
+    writes (chained form: polled) or through a 4-byte copy + event queued behind the kernel."""
 
-    def __init__(self, z, slots, pts, dirs, count_host, event):
-        self.z, self.slots, self._pts, self._dirs, self._count, self._event = z, slots, pts, dirs, count_host, event
+    def __init__(self, z, slots, pts, dirs, count_host, event, seq=None):
+        self.z, self.slots, self._pts, self._dirs, self._count, self._event, self._seq = z, slots, pts, dirs, count_host, event, seq
 
     def get(self):
-        self._event.synchronize()
-        n = int(self._count[0])
+        if self._seq is not None:
+            block, spins = self._count, 0
+            while int(block[1]) != self._seq:         # host-mapped (count, seq): seq is written last, behind a system-scope fence
+                spins += 1
+                if spins > 20_000_000:
+                    raise _lib.NerfHipError("sample_compact_async: the compaction kernel never published its count")
+            n = int(block[0])
+        else:
+            self._event.synchronize()
+            n = int(self._count[0])
         return self.z, self.slots, self._pts[:n], self._dirs[:n]
 
 
@@ -256,6 +284,8 @@ def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float
     slots = torch.empty(n, device=dev, dtype=torch.int32)
     pts, dirs = torch.empty(max(n, 1), 3, device=dev), torch.empty(max(n, 1), 3, device=dev)
     count = _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, None)
+    if isinstance(count, tuple):                                       # chained form: (host block, seq) to poll
+        return CompactedSamples(z, slots, pts, dirs, count[0], None, seq=count[1])
     count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     count_host.copy_(count, non_blocking=True)
     event = torch.cuda.Event()
