@@ -163,6 +163,7 @@ def normsq_ws(device) -> Tensor:
 
 
 _COMPACT_CHAIN = {}
+_NO_CHAIN = bool(__import__("os").environ.get("NERF_NO_COMPACT_CHAIN"))      # A/B aid: the copy + event form instead
 
 
 class _CompactChain:
@@ -191,7 +192,7 @@ def _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, nea
     draw = u is None and jitter is not None
     seed, counter = (int(jitter[0]), int(jitter[1]) & 0xFFFFFF) if draw else (0, 0)
     if count is None:
-        if draw and not deterministic():
+        if draw and not deterministic() and not _NO_CHAIN:
             key = (rays_o.device, _stream())
             chain = _COMPACT_CHAIN.get(key)
             if chain is None:
