@@ -585,6 +585,23 @@ def test_sample_compact_jitter_draws_in_the_kernel(ops):
     z_again = run(7, 3)[0]
     assert torch.equal(z, z_again)
     assert not torch.equal(z, run(7, 4)[0]) and not torch.equal(z, run(8, 3)[0])
+    # the asynchronous path is the CHAINED form (nerf_sample_compact_jitter_chain: two counters used alternately, the count published
+    # into host-mapped memory by the kernel's last workgroup): against the plain entry point with its own cleared counter and a
+    # device-to-host copy, over several consecutive links
+    lib = ops._lib.load()
+    for counter in (3, 4, 5, 6, 7):
+        zc, slots_c, pts_cc, _ = run(7, counter)
+        zp = torch.empty_like(zc)
+        slots_p = torch.empty_like(slots_c)
+        pts_p, dirs_p = torch.empty(R * S, 3, device="cuda"), torch.empty(R * S, 3, device="cuda")
+        count = torch.full((1,), 12345, dtype=torch.int32, device="cuda")
+        ops._lib.check(lib.nerf_sample_compact_jitter_shard(o.data_ptr(), d.data_ptr(), 7, counter, 0, R, S, 2.0, 6.0, bits.data_ptr(), 128, 1.5,
+                                                            zp.data_ptr(), slots_p.data_ptr(), pts_p.data_ptr(), dirs_p.data_ptr(), count.data_ptr(),
+                                                            torch.cuda.current_stream().cuda_stream), "nerf_sample_compact_jitter_shard")
+        assert torch.equal(zc, zp) and torch.equal(slots_c >= 0, slots_p >= 0)
+        assert int(count) == pts_cc.shape[0] == int((slots_c >= 0).sum())
+        act = slots_c >= 0
+        assert torch.equal(pts_cc[slots_c[act].long()], pts_p[slots_p[act].long()])      # the same sample -> the same point, whatever its slot
 
 
 def test_composite_indexed_equals_zero_filled_scatter(ops):

@@ -72,6 +72,16 @@ def test_hash_input_gradient_vs_oracle_autograd():
     d_half = ops.hash_encode_bwd_input(pts.cuda(), half.cuda(), t, 1.5, d_feat.cuda())
     d_round = ops.hash_encode_bwd_input(pts.cuda(), half.float().cuda(), t, 1.5, d_feat.cuda())
     np.testing.assert_allclose(d_half.cpu().numpy(), d_round.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))   # float atomics: order
+    # the accumulating form and the LEVEL-MAJOR source (what Part 4's chains leave in the scatter's workspace): the same gradient
+    # added to what the buffer held
+    extra = torch.randn(3000, 3, generator=gen).cuda()
+    acc = ops.hash_encode_bwd_input(pts.cuda(), half.cuda(), t, 1.5, d_feat.cuda(), add_to=extra.clone())
+    np.testing.assert_allclose((acc - extra).cpu().numpy(), d_half.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+    lm = d_feat.view(3000, 12, 2).permute(1, 0, 2).contiguous().cuda()                       # float2 [levels][n]
+    from_lm = ops.hash_encode_bwd_input(pts.cuda(), half.cuda(), t, 1.5, None, grad_lm=lm.data_ptr())
+    np.testing.assert_allclose(from_lm.cpu().numpy(), d_half.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    both = ops.hash_encode_bwd_input(pts.cuda(), half.cuda(), t, 1.5, None, add_to=extra.clone(), grad_lm=lm.data_ptr())
+    np.testing.assert_allclose((both - extra).cpu().numpy(), d_half.cpu().numpy(), rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
 
 
 def test_part4_forward_vs_reference_golden(model):
