@@ -176,11 +176,15 @@ class _CompactChain:
         self.host = torch.zeros(self.RING, 2, dtype=torch.int32).pin_memory()
         self.host_np = self.host.numpy()          # polled without tensor overhead
         self.turn, self.seq = 0, 0
+        self.owner = [None] * self.RING           # weak references to the results whose counts sit in the ring's slots
 
     def next(self):
         self.seq += 1
         turn, self.turn = self.turn, self.turn ^ 1
         slot = self.seq % self.RING
+        prev = self.owner[slot]() if self.owner[slot] is not None else None
+        if prev is not None and not prev._read:
+            raise _lib.NerfHipError(f"sample_compact_async: more than {self.RING} batches prepared ahead without reading their counts")
         self.host_np[slot, 1] = 0                 # (a seq is never 0)
         return turn, slot, self.seq & 0x7FFFFFFF or 1
 
@@ -202,7 +206,7 @@ def _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, nea
                                                             _p(grid), grid.shape[0], float(bound), _p(z), _p(slots), _p(pts), _p(dirs),
                                                             _p(chain.state), turn, chain.host[slot].data_ptr(), seq, _stream()),
                        "nerf_sample_compact_jitter_chain")
-            return chain.host_np[slot], seq
+            return chain.host_np[slot], seq, chain, slot
         count = torch.empty(1, device=rays_o.device, dtype=torch.int32)          # cleared by the library call itself
     if deterministic():
         scratch = torch.empty(max(lib.nerf_sample_compact_ordered_scratch_bytes(R, n_samples), 4), dtype=torch.uint8, device=rays_o.device)
@@ -251,8 +255,11 @@ class CompactedSamples:
 
     def __init__(self, z, slots, pts, dirs, count_host, event, seq=None):
         self.z, self.slots, self._pts, self._dirs, self._count, self._event, self._seq = z, slots, pts, dirs, count_host, event, seq
+        self._read, self._n = False, None
 
     def get(self):
+        if self._n is not None:
+            return self.z, self.slots, self._pts[:self._n], self._dirs[:self._n]
         if self._seq is not None:
             block, spins = self._count, 0
             while int(block[1]) != self._seq:         # host-mapped (count, seq): seq is written last, behind a system-scope fence
@@ -263,6 +270,7 @@ class CompactedSamples:
         else:
             self._event.synchronize()
             n = int(self._count[0])
+        self._read, self._n = True, n             # (the ring slot may be reused from here on)
         return self.z, self.slots, self._pts[:n], self._dirs[:n]
 
 
@@ -286,7 +294,10 @@ def sample_compact_async(rays_o: Tensor, rays_d: Tensor, near: float, far: float
     pts, dirs = torch.empty(max(n, 1), 3, device=dev), torch.empty(max(n, 1), 3, device=dev)
     count = _compact_launch(lib, rays_o, rays_d, u, jitter, first_ray, R, n_samples, near, far, grid, bound, z, slots, pts, dirs, None)
     if isinstance(count, tuple):                                       # chained form: (host block, seq) to poll
-        return CompactedSamples(z, slots, pts, dirs, count[0], None, seq=count[1])
+        import weakref
+        out = CompactedSamples(z, slots, pts, dirs, count[0], None, seq=count[1])
+        count[2].owner[count[3]] = weakref.ref(out)
+        return out
     count_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
     count_host.copy_(count, non_blocking=True)
     event = torch.cuda.Event()
