@@ -523,6 +523,10 @@ def test_engine_speculative_scatters_equal_counted_scatters(smooth_pair):
             for k, (a, b) in enumerate(zip(t1, t0)):
                 assert bool(torch.isfinite(a).all())
                 worst[k] = max(worst[k], float((a - b).abs().max()) / float(b.abs().max()))
+                # conservation: the trilinear weights of a point sum to one, so a table's gradient sums to the sum of the feature
+                # gradients whatever the binning did.  A LOST record would move the sum by a whole term (thousands of times an
+                # entry here, the entries being what is left after cancellation); a rounding alternative moves it by an entry's ulp
+                assert abs(float(a.double().sum() - b.double().sum())) <= 1e-5 * float(b.double().abs().sum()), k
         return worst
     own = spread(runs[1], runs[2])            # the counting form against itself: what its own float atomics (cut bins) leave open
     worst = spread(runs[0], runs[1])
