@@ -51,7 +51,7 @@ int nerf_abi_version(void);
  * environment ONCE per process (NERF_CHAIN_LEGACY, NERF_FWD_CYCLES, NERF_WGRAD_OVH,
  * NERF_WGRAD_DEBUG, NERF_WGRAD_ONLY, NERF_HASH_BWD_ONLY_LEVEL, NERF_STASH_FP8); afterwards they
  * change only through nerf_set_option.  Names: "chain_legacy", "fwd_cycles", "wgrad_overhead",
- * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "wgrad_atomic", "wgrad_k16", "wgrad_big_only", "stash_fp8", "infer_shape32", "wgrad_bw_x16", "wgrad_fixed", "chain_grid", "wgrad_grid", "hash_fwd_lds_kb",
+ * "wgrad_debug", "wgrad_only", "hash_bwd_only_level", "hash_bwd_atomic", "wgrad_atomic", "wgrad_k16", "wgrad_big_only", "stash_fp8", "infer_shape32", "infer64", "wgrad_bw_x16", "wgrad_fixed", "chain_grid", "wgrad_grid", "hash_fwd_lds_kb",
  * "hash_xcd", "composite_wgs_per_cu", "deterministic".  No hot-path launch reads the environment.
  *
  * "deterministic" (NERF_DETERMINISTIC; default 0).  The reference's gradients are plain sums (loss.backward(), run.py:1941-1944);

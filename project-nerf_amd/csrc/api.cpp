@@ -34,6 +34,7 @@ static const OptionSlot kSlots[] = {
     {"wgrad_k16", "NERF_WGRAD_K16", &Options::wgrad_k16},
     {"wgrad_big_only", "NERF_WGRAD_BIG_ONLY", &Options::wgrad_big_only},
     {"infer_shape32", "NERF_INFER_SHAPE32", &Options::infer_shape32},
+    {"infer64", "NERF_INFER64", &Options::infer64},
     {"stash_fp8", "NERF_STASH_FP8", &Options::stash_fp8},
     {"chain_grid", "NERF_CHAIN_GRID", &Options::chain_grid},
     {"wgrad_grid", "NERF_WGRAD_GRID", &Options::wgrad_grid},

@@ -38,6 +38,7 @@ struct Options {
   int wgrad_atomic = 0;          // 1: flush the split-K partial sums with float atomics at every size (A/B)
   int hash_bwd_atomic = 0;       // 1: the atomic form of the hash scatter even when a workspace is given (A/B)
   int infer_shape32 = 0;         // inference on the 32x32x16 MFMA stream instead of the 16x16x32 one (A/B)
+  int infer64 = 1;               // inference with 64 samples per wave, four waves per workgroup (activations in AGPRs): +2 %, the same bits; 0: A/B
   int stash_fp8 = 0;             // 1: 8-bit training images (e4m3 / e5m2) in the asm-stream family instead of bf16
   int chain_grid = 0;            // > 0: cap the chain kernels' workgroup count (timing below the power limit; CU partition with wgrad_grid)
   int wgrad_grid = 0;            // > 0: cap the decoder weight-gradient kernel's workgroup count (two half-batches in flight)

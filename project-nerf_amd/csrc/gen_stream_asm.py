@@ -41,6 +41,11 @@ import sys
 from collections import deque
 
 D = int(os.environ.get("GEN_D", 4))                 # A-fragment prefetch depth (window registers)
+D_DEFAULT, D64 = D, int(os.environ.get("GEN_D64", 4))   # infer64 has VGPRs to spare for a deeper window (measured: no effect)
+# infer64: epilogue instructions dealt out per fragment.  6 = two whole units (cvt, max, accvgpr_write) per fragment, two instructions
+# behind each of the fragment's first three MFMAs: measured best (tools/sweep_infer64.sh: 3 -> -1.5 %, 9 -> -1.7 %, 12+ -> -3.5 % against 6)
+S64_MIN = int(os.environ.get("GEN_S64_MIN", 6))
+S64_ORDER = int(os.environ.get("GEN_S64_ORDER", 1))      # the two units of a fragment interleaved (cvt cvt | max max | write write): +0.15 %
 EPI_START = int(os.environ.get("GEN_EPI", 3))     # first gap (after MFMA k) that may carry epilogue work
 # timing ablations (results are wrong with any of these set): GEN_NO=dma,epi,bar,read,store,stinst,vmwait,maskwait,oneimage
 ABLATE = set(filter(None, os.environ.get("GEN_NO", "").split(",")))
@@ -58,8 +63,21 @@ def vr(a, n=1):
     return f"v{a}" if n == 1 else f"v[{a}:{a + n - 1}]"
 
 
+def ar(a, n=1):
+    return f"a{a}" if n == 1 else f"a[{a}:{a + n - 1}]"
+
+
+# infer64: 64 samples per wave (four 16-sample halves g = 0..3), four waves per workgroup.  Every A fragment read from LDS feeds
+# FOUR MFMAs instead of two: half the fragment reads per sample (11 % of the inference pass on the whole chip, ablation NO=read).
+# Registers: accumulator tiles X64 / Y64 = 32 VGPRs each (a(t, g) = T + 4 (4 t + g)); the activation buffers live in AGPRs
+# (P64 = a[0:127], Q64 = a[128:255]: [k-step kk][half g][4 registers]) -- MFMA reads its B operand from them directly, the
+# epilogue's packed pairs go there through v_accvgpr_write_b32.
+X64, Y64, P64, Q64 = 96, 128, 0, 128
+BIAS64 = 160      # v[160:167] / v[168:175]: the bias rows of the current / next group (t = 0, 1), the C operand of an accumulator's first MFMA
+
+
 # ---------------------------------------------------------------- plans
-def fwd_groups(s16=False):
+def fwd_groups(s16=False, s64=False):
     """s16: the 16x16x32 MFMA shape (inference).  A group is still one 32-row output tile of a step, now held as
     FOUR 16x16 accumulators a(t, g) = T + 4 (2 t + g): t = 16-row half of the tile, g = 16-sample half of the
     wave's 32 samples.  Fragment k of a group feeds t = k & 1 at k-step kk = k >> 1 (32 deep) with both halves
@@ -67,15 +85,19 @@ def fwd_groups(s16=False):
     has exactly the chunking of the 32x32x16 stream."""
     steps = [("PTS0", 8, 0, 4, 0)] + [(f"PTS{l}", 8, 16, 4 if l == 4 else 0, 256 * l) for l in range(1, 8)] + [
         ("HEAD", 9, 16, 0, 2048), ("VIEW", 4, 16, 2, 2048 + 288), ("RGB", 1, 8, 0, 2048 + 288 + 128)]
-    src = {"PTS0": None, "PTS1": P, "PTS2": Q, "PTS3": P, "PTS4": Q, "PTS5": P, "PTS6": Q, "PTS7": P,
-           "HEAD": Q, "VIEW": P, "RGB": Q}
-    dst = {"PTS0": P, "PTS1": Q, "PTS2": P, "PTS3": Q, "PTS4": P, "PTS5": Q, "PTS6": P, "PTS7": Q,
-           "HEAD": P, "VIEW": Q}
+    Pb, Qb = (P64, Q64) if s64 else (P, Q)
+    src = {"PTS0": None, "PTS1": Pb, "PTS2": Qb, "PTS3": Pb, "PTS4": Qb, "PTS5": Pb, "PTS6": Qb, "PTS7": Pb,
+           "HEAD": Qb, "VIEW": Pb, "RGB": Qb}
+    dst = {"PTS0": Pb, "PTS1": Qb, "PTS2": Pb, "PTS3": Qb, "PTS4": Pb, "PTS5": Qb, "PTS6": Pb, "PTS7": Qb,
+           "HEAD": Pb, "VIEW": Qb}
     groups = []
     for li, (name, mt, ks_acc, ks_nat, boff) in enumerate(steps):
         for m in range(mt):
             code = "x" if name in ("PTS0", "PTS4") else "d"
-            if s16:
+            if s64:
+                bops = [tuple(ar(src[name] + 16 * (k >> 1) + 4 * g, 4) for g in range(4)) for k in range(ks_acc)]
+                bops += [tuple(f"%[{code}{k >> 1}{'abcd'[g]}]" for g in range(4)) for k in range(ks_nat)]
+            elif s16:
                 bops = [(vr(src[name] + 4 * (2 * (k >> 1)), 4), vr(src[name] + 4 * (2 * (k >> 1) + 1), 4)) for k in range(ks_acc)]
                 bops += [(f"%[{code}{k >> 1}a]", f"%[{code}{k >> 1}b]") for k in range(ks_nat)]
             else:
@@ -127,9 +149,13 @@ def chunk_groups(groups):
 # ---------------------------------------------------------------- stream
 def generate(mode):
     img16 = mode in ("train16", "bwd16")          # bf16 training images (two 16-byte stores per lane and m-tile)
-    bwd, train, s16 = mode in ("bwd", "bwd16"), mode in ("train", "train16"), mode == "infer16"
+    bwd, train, s64 = mode in ("bwd", "bwd16"), mode in ("train", "train16"), mode == "infer64"
+    s16 = mode == "infer16" or s64                 # the 16x16x32 shape; s64: four sample halves per wave instead of two
     stash = bwd or train
-    groups = bwd_groups() if bwd else fwd_groups(s16)
+    groups = bwd_groups() if bwd else fwd_groups(s16, s64)
+    WAVES = 4 if s64 else 8                        # waves of a workgroup: each issues 1 KiB of a DMA piece
+    NG = 4 if s64 else 2                           # sample halves per wave (16x16x32 shape)
+    XT, YT = (X64, Y64) if s64 else (X, Y)
     chunks = chunk_groups(groups)
     n_groups, n_chunks = len(groups), len(chunks)
     assert n_groups % 2 == 0 and n_chunks % 2 == 0
@@ -184,14 +210,14 @@ def generate(mode):
         if "dma" in ABLATE:
             return
         c = chunks[cc % n_chunks]
-        emit(f"v_add_u32 {vr(VA)}, {hex((c['frag0'] + 8 * p) * 1024)}, %[voff]")
-        emit(f"s_add_u32 m0, %[ldsw], {hex((cc & 1) * CHUNK * 1024 + 8 * p * 1024)}")
+        emit(f"v_add_u32 {vr(VA)}, {hex((c['frag0'] + WAVES * p) * 1024)}, %[voff]")
+        emit(f"s_add_u32 m0, %[ldsw], {hex((cc & 1) * CHUNK * 1024 + WAVES * p * 1024)}")
         emit("s_nop 0")
         emit(f"global_load_lds_dwordx4 {vr(VA)}, %[src]")
         vm_q.append(("dma", cc))
 
     def dma_pieces(cc):
-        return [(cc, p) for p in range((chunks[cc % n_chunks]["count"] + 7) // 8)]
+        return [(cc, p) for p in range((chunks[cc % n_chunks]["count"] + WAVES - 1) // WAVES)]
 
     cur_image = [None]
 
@@ -229,15 +255,34 @@ def generate(mode):
         """gap-sized units of group gi's epilogue (its accumulators are tile T)"""
         g = groups[gi]
         e = g["epi"]
-        T = X if gi % 2 == 0 else Y
+        T = XT if gi % 2 == 0 else YT
         units = []
         if e["kind"] == "sigma":
+            if s64:
+                return [[f"v_mov_b32 %[sg{g}], {vr(T + 4 * g)}" for g in range(4)]]
             if s16:
                 return [[f"v_mov_b32 %[sg0], {vr(T)}", f"v_mov_b32 %[sg1], {vr(T + 4)}"]]
             return [[f"v_mov_b32 %[sg], {vr(T)}"]]
         if e["kind"] != "cvt":
             return []
         r0 = e["dst"] + 8 * e["m"]
+        if s64:
+            # B operand of k-step m for sample half g = AGPRs r0 + 4g .. +3: [t0 rows 4q..4q+3 | t1 rows 16+4q..]; the packed pair
+            # is formed in a scratch VGPR (VALU cannot write AGPRs) and moved over
+            r0 = e["dst"] + 16 * e["m"]
+            n = 0
+            for gsel in range(4):
+                for t in range(2):
+                    a = T + 4 * (4 * t + gsel)
+                    for h in range(2):
+                        tmp = 89 + n % 7                              # v89..v95: scratch (v88 is the DMA address)
+                        n += 1
+                        u = [f"v_cvt_pk_bf16_f32 {vr(tmp)}, {vr(a + 2 * h)}, {vr(a + 2 * h + 1)}"]
+                        if e["relu"]:
+                            u.append(f"v_pk_max_i16 {vr(tmp)}, {vr(tmp)}, 0")
+                        u.append(f"v_accvgpr_write_b32 {ar(r0 + 4 * gsel + 2 * t + h)}, {vr(tmp)}")
+                        units.append(u)
+            return units
         if s16:
             # B operand of k-step m for sample half g = registers r0 + 4g .. +3: [t0 rows 4q..4q+3 | t1 rows 16+4q..]
             for gsel in range(2):
@@ -311,6 +356,10 @@ def generate(mode):
         g = groups[gi_next]
         if g["bias"] is None:
             return []
+        if s64:   # bias rows 16 t + 4 q .. +3 (bb carries 16 q) into the group's bias registers: all four sample halves of a tile
+            #           start from them (C operand of the first MFMA into each accumulator) -- two reads instead of eight
+            Bn = BIAS64 + 8 * (gi_next % 2)
+            return [(f"ds_read_b128 {vr(Bn + 4 * t, 4)}, %[bb] offset:{g['bias'] + 64 * t}", ("b", gi_next, t)) for t in range(2)]
         if s16:   # a(t, g) <- bias rows 16 t + 4 q .. +3 (bb carries 16 q); both sample halves start from the same bias
             return [(f"ds_read_b128 {vr(T + 4 * q, 4)}, %[bb] offset:{g['bias'] + 64 * (q >> 1)}", ("b", gi_next, q)) for q in range(4)]
         return [(f"ds_read_b128 {vr(T + 4 * q, 4)}, %[bb] offset:{g['bias'] + 32 * q}", ("b", gi_next, q)) for q in range(4)]
@@ -337,7 +386,7 @@ def generate(mode):
             emit_unit(mask_load(gi))
         emit(".Lwarm%=:")
         del vm_q[:]                                                  # conditional: treat as issued before the pass
-    for line, tag in bias_reads(0, X):
+    for line, tag in bias_reads(0, XT):
         emit(line)
         lds_q.append(tag)
     for j in range(min(D, n_frags)):
@@ -346,12 +395,15 @@ def generate(mode):
     pending_dma = deque()
     for gi, g in enumerate(groups):
         ks = len(g["bops"])
-        T = X if gi % 2 == 0 else Y
-        Tprev = Y if gi % 2 == 0 else X
+        T = XT if gi % 2 == 0 else YT
+        Tprev = YT if gi % 2 == 0 else XT
         j0 = sum(len(x["bops"]) for x in groups[:gi])
         first_of_chunk = g["off"] == 0
         units = epi_units(gi - 1) if gi > 0 else []
         if "epi" in ABLATE:
+            units = []
+        epi_instrs = [line for u in units for line in u] if s64 else []      # s64: dealt out instruction by instruction
+        if s64:
             units = []
         if bwd and gi == 0 and "store" not in ABLATE:
             units = [mask_load(3)]                                   # groups 0..2 were prefetched by the previous pass
@@ -366,10 +418,40 @@ def generate(mode):
             j = j0 + k
             need = {("w", j)}
             if k == 0:
-                need |= {("b", gi, q) for q in range(4)} & set(lds_q)
+                need |= {("b", gi, q) for q in range(8)} & set(lds_q)
             wait_lds(need)
             c_in = vr(T, 16) if (k > 0 or g["bias"] is not None) else "0"
-            if s16:
+            if s64:
+                # One wave per SIMD: nothing else fills this wave's MFMA gaps, and a 16x16x32 MFMA leaves about two simple
+                # instructions' worth of free issue behind it (MI355X_MICROARCH.md) -- so the epilogue of the previous group
+                # (16 units of cvt / max / accvgpr_write), then the next group's bias reads, are dealt out evenly over the gaps
+                # behind this group's MFMAs, to be done one fragment before the group (or the consumer's deadline) ends.  The
+                # previous tile's last MFMA has left the pipe after fragment 0 (64 matrix cycles).  The window refill and the DMA
+                # piece follow the fragment's fourth MFMA (a refill between MFMAs that still read the window raced them: round 2).
+                fill = []
+                flush = k == ks - 1 or (kd is not None and k >= kd - 2)
+                if k >= 1 or flush:
+                    last = min(ks - 2, kd - 3) if kd is not None else ks - 2
+                    per_frag = max(S64_MIN, -(-len(epi_instrs) // max(1, last - k + 1)))
+                    take = len(epi_instrs) if flush else min(per_frag, len(epi_instrs))
+                    fill += [epi_instrs.pop(0) for _ in range(take)]
+                    if S64_ORDER and take == 6 and all(isinstance(x, str) for x in fill) and fill[0].startswith("v_cvt") and fill[3].startswith("v_cvt"):
+                        fill = [fill[0], fill[3], fill[1], fill[4], fill[2], fill[5]]      # two units interleaved: cvt cvt | max max | write write
+                if k == 0:                         # the NEXT group's bias rows into its own registers: nothing waits on the epilogue
+                    fill += [("lds", line, tag) for line, tag in bias_next]
+                    bias_done = True
+                per_gap = -(-len(fill) // 4)
+                for gsel in range(4):
+                    acc = vr(T + 4 * (4 * (k & 1) + gsel), 4)
+                    c_op = vr(BIAS64 + 8 * (gi % 2) + 4 * k, 4) if k < 2 else acc      # an accumulator's first MFMA starts from the bias rows
+                    emit(f"v_mfma_f32_16x16x32_bf16 {acc}, %[w{j % D}], {g['bops'][k][gsel]}, {c_op}")
+                    for item in fill[gsel * per_gap:(gsel + 1) * per_gap]:
+                        if isinstance(item, tuple):
+                            emit(item[1])
+                            lds_q.append(item[2])
+                        else:
+                            emit(item)
+            elif s16:
                 a0, a1 = vr(T + 4 * (2 * (k & 1)), 4), vr(T + 4 * (2 * (k & 1) + 1), 4)
                 emit(f"v_mfma_f32_16x16x32_bf16 {a0}, %[w{j % D}], {g['bops'][k][0]}, {a0}")
                 # the window register is refilled only AFTER both MFMAs of the pair have issued: a ds_read placed
@@ -397,6 +479,8 @@ def generate(mode):
                 issue_read(jn)
             if pending_dma and not (first_of_chunk and k == 0):
                 dma_piece(*pending_dma.popleft())
+            if s64:
+                continue                                             # (epilogue and bias reads were dealt out above)
             if k >= EPI_START or k == ks - 1:
                 n_units = 1
                 if k == ks - 1 or (kd is not None and k >= kd - 2):
@@ -412,14 +496,18 @@ def generate(mode):
                         emit(line)
                         lds_q.append(tag)
                     bias_done = True
-        assert not units and bias_done
+        assert not units and bias_done and not epi_instrs
     while pending_dma:
         dma_piece(*pending_dma.popleft())
     # ---- pass end ----
-    T = X if (n_groups - 1) % 2 == 0 else Y
+    T = XT if (n_groups - 1) % 2 == 0 else YT
     emit("s_nop 15")
     emit("s_nop 3")
-    if s16:
+    if s64:
+        for gsel in range(4):
+            for c in range(3):
+                emit(f"v_mov_b32 %[c{3 * gsel + c}], {vr(T + 4 * gsel + c)}")
+    elif s16:
         for c in range(3):
             emit(f"v_mov_b32 %[c{c}], {vr(T + c)}")
             emit(f"v_mov_b32 %[c{3 + c}], {vr(T + 4 + c)}")
@@ -448,6 +536,9 @@ SIGS = {
     "infer16": ("fwd_stream16_pass",
                 "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
                 "    unsigned voff, unsigned ldsw, float (&sg)[2], float (&c)[6]"),
+    "infer64": ("fwd_stream64_pass",
+                "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[8], const bf16x8 (&d)[4], const char* src,\n"
+                "    unsigned voff, unsigned ldsw, float (&sg)[4], float (&c)[12]"),
     "train": ("fwd_train_stream_pass",
               "unsigned ab0, unsigned ab1, unsigned bb, const bf16x8 (&x)[4], const bf16x8 (&d)[2], const char* src,\n"
               "    unsigned voff, unsigned ldsw, unsigned so8, unsigned so4, unsigned mo0, const void* karg, float scale,\n"
@@ -466,6 +557,8 @@ SIGS = {
 
 
 def emit_function(mode, p):
+    global D
+    D = D64 if mode == "infer64" else D_DEFAULT
     groups, chunks, lines = generate(mode)
     if "bar" in ABLATE:
         lines = [l for l in lines if l != "s_barrier"]
@@ -488,16 +581,21 @@ def emit_function(mode, p):
     ins = ['[ab0] "v"(ab0)', '[ab1] "v"(ab1)', '[src] "s"(src)', '[voff] "v"(voff)', '[ldsw] "s"(ldsw)']
     if mode in ("bwd", "bwd16"):
         ins += ['[g0] "v"(g0)', '[gs] "v"(gs)', '[mo0n] "v"(mo0n)', '[first] "s"(first)']
+    elif mode == "infer64":
+        outs += [f'[sg{i}] "=&v"(sg[{i}])' for i in range(4)] + [f'[c{i}] "=&v"(c[{i}])' for i in range(12)]
+        ins += ['[bb] "v"(bb)'] + [f'[x{i >> 2}{"abcd"[i & 3]}] "v"(x[{i}])' for i in range(8)] + [f'[d0{"abcd"[i]}] "v"(d[{i}])' for i in range(4)]
     elif mode == "infer16":
         outs += ['[sg0] "=&v"(sg[0])', '[sg1] "=&v"(sg[1])'] + [f'[c{i}] "=&v"(c[{i}])' for i in range(6)]
         ins += ['[bb] "v"(bb)'] + [f'[x{i >> 1}{"ab"[i & 1]}] "v"(x[{i}])' for i in range(4)] + [f'[d0{"ab"[i]}] "v"(d[{i}])' for i in range(2)]
     else:
         outs += ['[sg] "=&v"(sg)', '[cr] "=&v"(cr)', '[cg] "=&v"(cg)', '[cb] "=&v"(cb)']
         ins += ['[bb] "v"(bb)'] + [f'[x{i}] "v"(x[{i}])' for i in range(4)] + [f'[d{i}] "v"(d[{i}])' for i in range(2)]
-    if mode not in ("infer", "infer16"):
+    if mode not in ("infer", "infer16", "infer64"):
         ins += ['[so8] "v"(so8)', '[so4] "v"(so4)', '[mo0] "v"(mo0)', '[karg] "s"(karg)', '[scale] "s"(scale)']
     clob = [f'"v{i}"' for i in range(FIRST_LITERAL_VGPR, 256)]
-    if mode not in ("infer", "infer16"):
+    if mode == "infer64":       # accumulators v96..v159, scratch v88..v95; the activation buffers are all 256 AGPRs
+        clob = [f'"v{i}"' for i in range(FIRST_LITERAL_VGPR, BIAS64 + 16)] + [f'"a{i}"' for i in range(256)]
+    if mode not in ("infer", "infer16", "infer64"):
         clob += [f'"s{i}"' for i in SGPR_LITERALS]
     p("      : " + ", ".join(outs))
     p("      : " + ", ".join(ins))
@@ -510,7 +608,8 @@ def emit_function(mode, p):
 def main():
     p = print
     p("// GENERATED by gen_stream_asm.py -- do not edit.  See that file for the design.")
-    p(f"// GEN_CONFIG D={D} NO={','.join(sorted(ABLATE))}" + (f" EPI={EPI_START}" if EPI_START != 3 else ""))
+    p(f"// GEN_CONFIG D={D_DEFAULT} NO={','.join(sorted(ABLATE))}" + (f" EPI={EPI_START}" if EPI_START != 3 else "")
+      + (f" D64={D64}" if D64 != 4 else "") + (f" S64MIN={S64_MIN}" if S64_MIN != 6 else "") + (f" S64ORDER={S64_ORDER}" if S64_ORDER != 1 else ""))
     p("#pragma once\n")
     p("namespace nerf {\n")
     p(f"static_assert(plan::kChunkFrags == {CHUNK}, \"stream plan\");")
@@ -519,7 +618,7 @@ def main():
     p("// so8/so4 = wave_tile*MT*1024 + block8_lane_offset(col, half) for MT = 8/4 (8-bit images; bf16 images:")
     p("// wave_tile*MT*2048 + block_lane_offset(col, half)); mo0 = (tile*72*512 + tid)*2;")
     p("// karg = kernarg segment.\n")
-    for mode in os.environ.get("GEN_MODES", "infer,infer16,train,bwd,train16,bwd16").split(","):
+    for mode in os.environ.get("GEN_MODES", "infer,infer16,infer64,train,bwd,train16,bwd16").split(","):
         emit_function(mode, p)
     p("}  // namespace nerf")
 

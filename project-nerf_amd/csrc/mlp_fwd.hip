@@ -404,6 +404,89 @@ __global__ void __launch_bounds__(kChainThreads, 2) mlp_fwd_stream16_kernel(cons
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last pass's look-ahead DMA must not outlive the wave
 }
 
+// 64 samples per wave, four waves per workgroup, one wave per SIMD (gen_stream_asm.py mode infer64): every A fragment read from
+// LDS feeds four 16x16x32 MFMAs (sample halves g = 0..3) instead of two -- half the fragment reads, half the barrier partners per
+// sample; the activation buffers are the wave's 256 AGPRs.  Lane (q = lane >> 4, c = lane & 15) serves samples c + 16 g.
+constexpr int kChain64Threads = 256;
+__global__ void __launch_bounds__(kChain64Threads, 1) mlp_fwd_stream64_kernel(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* bias_lds = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+
+  const float* bias_g = reinterpret_cast<const float*>(a.packed + kPackBiasOff);
+  for (int i = tid; i < kBiasFloats; i += kChain64Threads) bias_lds[i] = bias_g[i];
+
+  // chunks 0 and 1 into ring slots 0 and 1: four waves, 1 KiB per wave and piece (the tail pieces read into the stream's padding)
+  const char* src = a.packed + kPackFwd16Off;
+  char* ring = smem + kBiasLdsBytes;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int frag0 = plan::kFwdChunks.chunk_frag0[c], count = plan::kFwdChunks.chunk_count[c];
+    for (int i = 0; i < (count + 3) / 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(frag0 + wave + 4 * i) * 1024 + lane * 16),
+                                       (lptr_t)(ring + c * kRingSlotBytes + (wave + 4 * i) * 1024), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned bb = lds_addr(smem) + 16u * q;
+  const unsigned ab0 = lds_addr(ring) + 16u * lane, ab1 = ab0 + kRingSlotBytes;
+  const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds_addr(ring) + 1024u * wave);
+  const unsigned voff = 1024u * wave + 16u * lane;
+
+  const int64_t n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * kTileSamples + wave * 64 + c16;
+    bf16x8 xenc[8], denc[4];      // x[4 kk + g], d[g]
+    int64_t nn[4];
+    bool live[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      nn[g] = n0 + 16 * g;
+      live[g] = nn[g] < a.n;
+      const int64_t nc = live[g] ? nn[g] : a.n - 1;
+      bf16x8 xe[2], de[1];
+      if (a.n_samples < 0) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int f = 32 * kk + 8 * q + j;
+            xe[kk][j] = (__bf16)(f < kPosDim ? a.rays_o[nc * kPosDim + f] : (f == kPosDim ? 1.0f : 0.0f));
+          }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int f = 8 * q + j;
+          de[0][j] = (__bf16)(f < kDirDim ? a.rays_d[nc * kDirDim + f] : (f == kDirDim ? 1.0f : 0.0f));
+        }
+      } else {
+        float p[3], v[3];
+        sample_geometry(a, nc, p, v);
+        fourier_operand16<2, kPosDim>(p[0], p[1], p[2], q, xe);
+        fourier_operand16<1, kDirDim>(v[0], v[1], v[2], q, de);
+      }
+      xenc[0 + g] = xe[0];
+      xenc[4 + g] = xe[1];
+      denc[g] = de[0];
+    }
+    float sg[4], col[12];
+    fwd_stream64_pass(ab0, ab1, bb, xenc, denc, src, voff, ldsw, sg, col);
+    if (q == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (live[g]) {
+          a.sigma[nn[g]] = fmaxf(sg[g], 0.0f);
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) a.rgb[nn[g] * 3 + ch] = 1.0f / (1.0f + __expf(-col[3 * g + ch]));
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last pass's look-ahead DMA must not outlive the wave
+}
+
 }  // namespace nerf
 
 using namespace nerf;
@@ -444,10 +527,12 @@ static int mlp_fwd_impl(const void* packed, const float* rays_o, const float* ra
   const bool legacy = !chain_use_stream(n, stash != nullptr);
   // inference: the 16x16x32-shape stream unless option infer_shape32 asks for the 32x32x16 one (A/B)
   const bool shape16 = !legacy && stash == nullptr && !options().infer_shape32;
+  const bool wave64 = shape16 && options().infer64 != 0;        // 64 samples per wave, four waves per workgroup
   const bool img16 = stash != nullptr && !stash_fp8(n);
   const void* kernel = legacy ? (stash != nullptr ? (const void*)mlp_fwd_kernel<true> : (const void*)mlp_fwd_kernel<false>)
                               : (stash != nullptr ? (img16 ? (const void*)mlp_fwd_stream_kernel<true, true> : (const void*)mlp_fwd_stream_kernel<true>)
-                                                  : (shape16 ? (const void*)mlp_fwd_stream16_kernel : (const void*)mlp_fwd_stream_kernel<false>));
+                                                  : (wave64 ? (const void*)mlp_fwd_stream64_kernel
+                                                             : (shape16 ? (const void*)mlp_fwd_stream16_kernel : (const void*)mlp_fwd_stream_kernel<false>)));
   if (int rc = ensure_dynamic_lds(kernel, kChainLds, "nerf_mlp_fwd"); rc != NERF_OK) return rc;
   static unsigned long long* dbg = nullptr;
   if (options().fwd_cycles && !legacy) {
@@ -463,6 +548,8 @@ static int mlp_fwd_impl(const void* packed, const float* rays_o, const float* ra
     hipLaunchKernelGGL((mlp_fwd_stream_kernel<true, true>), dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else if (stash != nullptr)
     hipLaunchKernelGGL(mlp_fwd_stream_kernel<true>, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
+  else if (wave64)
+    hipLaunchKernelGGL(mlp_fwd_stream64_kernel, dim3(grid), dim3(kChain64Threads), kChainLds, as_stream(stream), a);
   else if (shape16)
     hipLaunchKernelGGL(mlp_fwd_stream16_kernel, dim3(grid), dim3(kChainThreads), kChainLds, as_stream(stream), a);
   else

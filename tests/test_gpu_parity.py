@@ -659,14 +659,38 @@ def test_sample_pdf_vs_oracle(ops, S, NF, rand):
     assert float(err.max()) < 0.1
 
 
-@pytest.mark.parametrize("option", [None, "infer_shape32"])
+def test_inference_with_64_samples_per_wave_equals_the_32_sample_stream_bit_for_bit(ops):
+    """Option infer64 (default on: four waves per workgroup, 64 samples per wave, the activations in AGPRs -- every A fragment
+    feeds four MFMAs) runs the same MFMAs on the same operands in the same order per sample as the eight-wave stream (infer64 = 0):
+    rgb and sigma bit for bit, on whole tiles, a ragged batch and the already-encoded entry."""
+    params = O.nerf_init_params(seed=6)
+    packed = ops.mlp_pack(dev(flat_params(params)))
+    gen = torch.Generator().manual_seed(3)
+    for R, S in ((2048, 128), (1000, 64), (3, 2)):
+        o, d = synth_rays(R, 7)
+        z = dev(O.stratified_depths(2.0, 6.0, S, R, True, u=torch.rand(R, S, generator=gen)).contiguous())
+        o, d = dev(o), dev(d)
+        outs = []
+        for mode in (1, 0):
+            ops._lib.set_option("infer64", mode)
+            try:
+                outs.append(ops.mlp_fwd(packed, o, d, z))
+            finally:
+                ops._lib.set_option("infer64", 1)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (R, S)
+        assert bool(torch.isfinite(outs[0][0]).all()) and float(outs[0][0].std()) > 0
+
+
+@pytest.mark.parametrize("option", [None, "infer_shape32", "infer64=0"])
 def test_chain_kernels_bit_identical_under_full_chip_load(ops, option):
     """Races inside the generated streams show as run-to-run differences once every CU holds several waves
     that compete for the matrix pipe (round 2: a fragment read placed between the two MFMAs of a 16x16x32
     pair overwrote the second one's operand on some boxes).  2048 rays x 128 samples = 1024 wave tiles; the
     forward (inference + training stash) and the dgrad outputs must repeat bit for bit."""
+    name, value = (option.split("=") + ["1"])[:2] if option else (None, None)
     if option:
-        ops._lib.set_option(option, 1)
+        previous = ops._lib.get_option(name)
+        ops._lib.set_option(name, int(value))
     try:
         params = O.nerf_init_params(seed=5)
         R, S = 2048, 128
@@ -694,7 +718,7 @@ def test_chain_kernels_bit_identical_under_full_chip_load(ops, option):
                     assert torch.equal(a, b), (rep, i, int((a != b).sum()), (a != b).nonzero()[:4].flatten().tolist())
     finally:
         if option:
-            ops._lib.set_option(option, 0)
+            ops._lib.set_option(name, previous)
 
 
 def test_wgrad_partial_tiles_equal_the_atomic_flush_and_repeat_bit_for_bit(ops):
