@@ -801,6 +801,15 @@ def test_instant_engine_speculative_backward_equals_counted_backward():
             assert eng.spec.calls >= 3, eng.spec.calls                            # steps 2.. took the speculative form
             torch.cuda.synchronize()
             assert int(eng.spec.last_status[7]) == 1 and int(eng.spec.last_status[4]) == 0
+            # a new occupancy grid (another tensor, as update_grid leaves): the estimates are not trusted -- one counted call, then
+            # the speculative form again
+            before = eng.spec.calls
+            eng.binary_grid = grid.clone()
+            u = torch.rand(R, S, generator=torch.Generator().manual_seed(200)).cuda()
+            eng.compute_gradients(o, d, target, S, u=u)
+            assert eng.spec.calls == before
+            eng.compute_gradients(o, d, target, S, u=u)
+            assert eng.spec.calls == before + 1
     for (l1, n1, t1), (l0, n0, t0) in zip(*runs):
         assert abs(l1 - l0) < 1e-6 * max(l0, 1.0) and bool(torch.isfinite(t1).all())
         assert float((n1 - n0).abs().max()) <= 1e-5 * float(n0.abs().max())
