@@ -311,6 +311,48 @@ __device__ __forceinline__ void fourier_operand16(float x0, float x1, float x2, 
   }
 }
 
+// The same operand with the per-lane parameters HOISTED out of the tile loop (the 64-samples-per-wave kernel has the registers for
+// them): feature f = 32 kk + 8 q + j of a lane quarter q has axis f % 3 (for every trig feature), so a lane's three coordinates
+// rotated by a0 = (32 kk + 8 q) % 3 serve its eight features in a static pattern, and scale / phase are loop-invariant per lane.
+// fourier_operand16 re-derives all of that per feature and tile through select chains on q (13 of its ~22 instructions per
+// feature).  Same arithmetic on the same values: the same bits.
+template <int KK, int VALID>
+__device__ __forceinline__ void fourier_lane_constants(int q, float (&sc)[KK][8], float (&ph)[KK][8]) {
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const FeatSpec s0 = feat_spec<VALID>(32 * kk + j), s1 = feat_spec<VALID>(32 * kk + 8 + j),
+                     s2 = feat_spec<VALID>(32 * kk + 16 + j), s3 = feat_spec<VALID>(32 * kk + 24 + j);
+      sc[kk][j] = q == 0 ? s0.scale : (q == 1 ? s1.scale : (q == 2 ? s2.scale : s3.scale));
+      ph[kk][j] = q == 0 ? s0.phase : (q == 1 ? s1.phase : (q == 2 ? s2.phase : s3.phase));
+    }
+}
+
+template <int KK, int VALID>
+__device__ __forceinline__ void fourier_operand16_hoisted(float x0, float x1, float x2, int q, const float (&sc)[KK][8],
+                                                          const float (&ph)[KK][8], bf16x8 (&out)[KK]) {
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int a0 = (32 * kk + 8 * q) % 3;                     // axis of the lane's first feature of this k-step (loop-invariant)
+    const float xr[3] = {a0 == 0 ? x0 : (a0 == 1 ? x1 : x2), a0 == 0 ? x1 : (a0 == 1 ? x2 : x0), a0 == 0 ? x2 : (a0 == 1 ? x0 : x1)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = sincos_rev(xr[j % 3], sc[kk][j], ph[kk][j]);
+      // the few features that are not trigonometric sit at fixed (quarter, j) places: the coordinates themselves, the constant-one
+      // column, the zero padding
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const FeatSpec sp = feat_spec<VALID>(32 * kk + 8 * qq + j);
+        if (sp.raw == 1) v = q == qq ? (sp.axis == 0 ? x0 : (sp.axis == 1 ? x1 : x2)) : v;
+        else if (sp.raw == 2) v = q == qq ? 1.0f : v;
+        else if (sp.raw == 3) v = q == qq ? 0.0f : v;
+      }
+      out[kk][j] = (__bf16)v;
+    }
+  }
+}
+
 // position / unit direction of sample nc in ray, point or (not here) encoded mode
 __device__ __forceinline__ void sample_geometry(const FwdArgs& a, int64_t nc, float (&p)[3], float (&v)[3]) {
   if (a.n_samples > 0) {
@@ -436,12 +478,30 @@ __global__ void __launch_bounds__(kChain64Threads, 1) mlp_fwd_stream64_kernel(co
   const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds_addr(ring) + 1024u * wave);
   const unsigned voff = 1024u * wave + 16u * lane;
 
+  float psc[2][8], pph[2][8], dsc[1][8], dph[1][8];          // scale and phase of this lane's features: loop-invariant
+  fourier_lane_constants<2, kPosDim>(q, psc, pph);
+  fourier_lane_constants<1, kDirDim>(q, dsc, dph);
   const int64_t n_tiles = (a.n + kTileSamples - 1) / kTileSamples;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * kTileSamples + wave * 64 + c16;
     bf16x8 xenc[8], denc[4];      // x[4 kk + g], d[g]
     int64_t nn[4];
     bool live[4];
+    // ray mode with a sample count that is a multiple of 64: the wave's 64 samples lie on ONE ray -- its origin, direction and the
+    // direction's code once per tile instead of once per sample half (an integer division, a square root and three divisions each)
+    const bool one_ray = a.n_samples > 0 && (a.n_samples & 63) == 0;
+    float ro[3] = {0.f, 0.f, 0.f}, rd[3] = {0.f, 0.f, 0.f};
+    bf16x8 de_ray[1];
+    if (one_ray) {
+      const int64_t first = n0 - c16 < a.n ? n0 - c16 : a.n - 1;
+      const int64_t ray = (uint32_t)first / (uint32_t)a.n_samples;
+      float v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { ro[c] = a.rays_o[ray * 3 + c]; rd[c] = a.rays_d[ray * 3 + c]; }
+      const float nrm = sqrtf(add_rn(add_rn(mul_rn(rd[0], rd[0]), mul_rn(rd[1], rd[1])), mul_rn(rd[2], rd[2])));
+      v[0] = rd[0] / nrm; v[1] = rd[1] / nrm; v[2] = rd[2] / nrm;
+      fourier_operand16_hoisted<1, kDirDim>(v[0], v[1], v[2], q, dsc, dph, de_ray);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       nn[g] = n0 + 16 * g;
@@ -461,11 +521,16 @@ __global__ void __launch_bounds__(kChain64Threads, 1) mlp_fwd_stream64_kernel(co
           const int f = 8 * q + j;
           de[0][j] = (__bf16)(f < kDirDim ? a.rays_d[nc * kDirDim + f] : (f == kDirDim ? 1.0f : 0.0f));
         }
+      } else if (one_ray) {
+        const float zz = a.z[nc];
+        fourier_operand16_hoisted<2, kPosDim>(add_rn(ro[0], mul_rn(rd[0], zz)), add_rn(ro[1], mul_rn(rd[1], zz)),
+                                              add_rn(ro[2], mul_rn(rd[2], zz)), q, psc, pph, xe);
+        de[0] = de_ray[0];
       } else {
         float p[3], v[3];
         sample_geometry(a, nc, p, v);
-        fourier_operand16<2, kPosDim>(p[0], p[1], p[2], q, xe);
-        fourier_operand16<1, kDirDim>(v[0], v[1], v[2], q, de);
+        fourier_operand16_hoisted<2, kPosDim>(p[0], p[1], p[2], q, psc, pph, xe);
+        fourier_operand16_hoisted<1, kDirDim>(v[0], v[1], v[2], q, dsc, dph, de);
       }
       xenc[0 + g] = xe[0];
       xenc[4 + g] = xe[1];
