@@ -47,3 +47,27 @@ def test_dgrad_waits_once_per_masked_tile(mode):
     n_mask_loads = len(re.findall(r"global_load_ushort v9[1-4], v90, s\[92:93\]", text))
     assert n_mask_loads >= 68, n_mask_loads
     assert "GEN_CONFIG D=4 NO=\n" in text            # default configuration: no timing ablation leaked into the build
+
+
+def test_inference_stream_with_64_samples_per_wave():
+    """mode infer64: the same fragment stream as infer16 (1184 fragments), every fragment feeding FOUR MFMAs on distinct
+    accumulators; B operands of the hidden layers come from AGPRs, nat operands from the x / d inputs; an accumulator's first MFMA
+    takes the group's bias registers as C; every epilogue pair reaches its AGPR through v_accvgpr_write_b32; two bias reads per
+    group; DMA pieces of four waves (4 KiB apart)."""
+    t16, t64 = _generate("infer16"), _generate("infer64")
+    mfma16 = re.findall(r"v_mfma_f32_16x16x32_bf16 (\S+), %\[w(\d)\], (\S+), (\S+)\\n", t16)
+    mfma64 = re.findall(r"v_mfma_f32_16x16x32_bf16 (\S+), %\[w(\d)\], (\S+), (\S+)\\n", t64)
+    assert len(mfma64) == 2 * len(mfma16) == 4 * 1184
+    reads16 = re.findall(r"ds_read_b128 %\[w\d\], %\[ab[01]\] offset:(\d+)", t16)
+    reads64 = re.findall(r"ds_read_b128 %\[w\d\], %\[ab[01]\] offset:(\d+)", t64)
+    assert reads16 == reads64 and len(reads64) == 1184                  # the same fragments in the same order, once per 64 samples
+    for i in range(0, len(mfma64), 4):                                  # four MFMAs per fragment: one window register, four accumulators
+        quad = mfma64[i:i + 4]
+        assert len({m[1] for m in quad}) == 1 and len({m[0] for m in quad}) == 4
+        assert all(m[2].startswith("a[") or m[2].startswith("%[x") or m[2].startswith("%[d") for m in quad)
+        assert all(m[3] == m[0] or re.fullmatch(r"v\[1(6[0-9]|7[0-5]):1(6[0-9]|7[0-5])\],?", m[3]) for m in quad)   # C: itself or v[160:175]
+    assert len(re.findall(r"v_accvgpr_write_b32 a\d+, v(89|9[0-5])", t64)) == len(re.findall(r"v_cvt_pk_bf16_f32 v(89|9[0-5]),", t64)) == 16 * 76
+    assert len(re.findall(r"ds_read_b128 v\[1(6[0-9]|7[0-5]):1(6[0-9]|7[0-5])\], %\[bb\]", t64)) == 2 * 78
+    dma = [int(x, 16) for x in re.findall(r"v_add_u32 v88, (0x[0-9a-f]+), %\[voff\]", t64)]
+    assert dma and all(d % 4096 == 0 for d in dma)
+    assert "GEN_CONFIG D=4 NO=\n" in t64
