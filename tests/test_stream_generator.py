@@ -69,5 +69,6 @@ def test_inference_stream_with_64_samples_per_wave():
     assert len(re.findall(r"v_accvgpr_write_b32 a\d+, v(89|9[0-5])", t64)) == len(re.findall(r"v_cvt_pk_bf16_f32 v(89|9[0-5]),", t64)) == 16 * 76
     assert len(re.findall(r"ds_read_b128 v\[1(6[0-9]|7[0-5]):1(6[0-9]|7[0-5])\], %\[bb\]", t64)) == 2 * 78
     dma = [int(x, 16) for x in re.findall(r"v_add_u32 v88, (0x[0-9a-f]+), %\[voff\]", t64)]
-    assert dma and all(d % 4096 == 0 for d in dma)
+    steps = [b - a for a, b in zip(dma, dma[1:])]
+    assert dma and sum(1 for d in steps if d == 4096) > 0.9 * len(steps) and 8192 not in steps      # four waves x 1 KiB per piece
     assert "GEN_CONFIG D=4 NO=\n" in t64
